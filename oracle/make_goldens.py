@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference functions.
+
+Runs ONLY in the build container (needs /root/reference).  Usage:
+
+    python3 -B oracle/make_goldens.py
+
+The reference's Python files never leave this container; only the input/output vectors
+written here do.  Third-party modules the reference imports but that are not installed
+(diffusers, peft, lightning, prodigyopt, s4torch, cv2) are replaced in sys.modules by
+thin namespaces whose members are the `oracle/flux_modules.py` / `oracle/s4.py`
+restatements, so what these goldens pin is the reference's OWN arithmetic
+(src/flux/block.py, src/flux/transformer.py, src/train/model.py DUAN/FPP/fuse_*/encoders).
+All weights are re-derivable from seeds (oracle.flux_modules.init_synthetic_), so the
+fixtures hold only inputs, outputs and the config needed to rebuild the modules.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("LX_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import flux_modules as fm  # noqa: E402
+from oracle import s4 as os4  # noqa: E402
+
+
+def _ns(name, **members):
+    m = types.ModuleType(name)
+    m.__dict__.update(members)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import logging
+    log = logging.getLogger("lxref")
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    _ns("diffusers")
+    _ns("diffusers.models")
+    _ns("diffusers.models.attention_processor", Attention=fm.Attention, F=F)
+    _ns("diffusers.models.embeddings", apply_rotary_emb=fm.apply_rotary_emb)
+    _ns("diffusers.models.transformers")
+    _ns("diffusers.models.transformers.transformer_flux", FluxTransformer2DModel=fm.FluxTransformer2DModel,
+        Transformer2DModelOutput=_Dummy, USE_PEFT_BACKEND=False, scale_lora_layers=lambda *a, **k: None,
+        unscale_lora_layers=lambda *a, **k: None, logger=log)
+    _ns("diffusers.pipelines", FluxPipeline=_Dummy)
+    _ns("diffusers.pipelines.flux")
+    _ns("diffusers.pipelines.flux.pipeline_flux", FluxPipelineOutput=_Dummy, calculate_shift=fm.calculate_shift,
+        retrieve_timesteps=fm.retrieve_timesteps, np=np, logger=log)
+    _ns("diffusers.utils", logging=logging)
+    _ns("peft", LoraConfig=_Dummy, get_peft_model_state_dict=lambda *a, **k: {})
+    _ns("peft.tuners")
+    _ns("peft.tuners.tuners_utils", BaseTunerLayer=fm.BaseTunerLayer)
+    _ns("lightning", LightningModule=nn.Module, Callback=object)
+    _ns("prodigyopt")
+    _ns("cv2")
+
+    class S4ModelAdapter(os4.S4Model):
+        def __init__(self, d_input, d_model, d_output, n_blocks, n, l_max):
+            super().__init__(d_input, d_model, d_output, n_blocks, n, l_max, torch.Generator().manual_seed(1234))
+
+    _ns("s4torch", S4Model=S4ModelAdapter)
+    pkg = types.ModuleType("refsrc")
+    pkg.__path__ = [os.path.join(REF, "src")]
+    sys.modules["refsrc"] = pkg
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+TINY = dict(num_layers=2, num_single_layers=2, heads=2, head_dim=128, in_channels=64, joint_dim=64,
+            pooled_dim=32, guidance_embeds=True, lora=True)
+
+
+def tiny_transformer(seed=0, **over):
+    cfg = dict(TINY)
+    cfg.update(over)
+    tr = fm.FluxTransformer2DModel(**cfg)
+    fm.init_synthetic_(tr, seed=seed, std=0.05, bias_std=0.02, norm_jitter=0.1)
+    return tr.eval()
+
+
+def tiny_inputs(seed=1, B=2, T=16, hw=4, cw=4):
+    g = torch.Generator().manual_seed(seed)
+    N, C = hw * hw, cw * cw
+    lat = torch.randn(B, N, 64, generator=g)
+    cond = torch.randn(B, C, 64, generator=g)
+    enc = torch.randn(B, T, 64, generator=g) * 0.5
+    pooled = torch.randn(B, 32, generator=g)
+    txt_ids = torch.zeros(T, 3)
+    img_ids = fm.prepare_latent_image_ids(hw, hw)
+    cond_ids = fm.prepare_latent_image_ids(cw, cw)
+    cond_ids[:, 2] += -cw  # position_delta = [0, -w/16] (inference.py:350-351, condition.py:126-130)
+    return dict(latents=lat, cond=cond, enc=enc, pooled=pooled, txt_ids=txt_ids, img_ids=img_ids,
+                cond_ids=cond_ids, timestep=torch.tensor([0.7, 0.35])[:B], guidance=torch.full((B,), 3.5))
+
+
+def gold_flux():
+    from refsrc.flux import block as rb
+    from refsrc.flux import transformer as rt
+    tr = tiny_transformer()
+    x = tiny_inputs()
+    D = tr.inner_dim
+    g = torch.Generator().manual_seed(7)
+    B, T, N, C = 2, 16, 16, 16
+    hid = torch.randn(B, N, D, generator=g)
+    enc = torch.randn(B, T, D, generator=g)
+    cond = torch.randn(B, C, D, generator=g)
+    temb = torch.randn(B, D, generator=g)
+    ctemb = torch.randn(B, D, generator=g)
+    rope_main = tr.pos_embed(torch.cat([x["txt_ids"], x["img_ids"]], 0))
+    rope_cond = tr.pos_embed(x["cond_ids"])
+    out = dict(hid=t2n(hid), enc=t2n(enc), cond=t2n(cond), temb=t2n(temb), ctemb=t2n(ctemb))
+    with torch.no_grad():
+        # attn_forward, every mask mode, double + single flavour
+        modes = {"default": ({}, None), "no_union": ({"union_cond_attn": False}, None),
+                 "independent": ({"independent_condition": True}, None),
+                 "cfactor_half": ({}, 0.5), "cfactor_two": ({}, 2.0), "latent_lora": ({"latent_lora": True}, None)}
+        dattn, sattn = tr.transformer_blocks[0].attn, tr.single_transformer_blocks[0].attn
+        for name, (mc, cf) in modes.items():
+            for a in (dattn, sattn):
+                if cf is not None:
+                    a.c_factor = torch.ones(1, 1) * cf
+            r = rb.attn_forward(dattn, hid, enc, cond, None, rope_main, rope_cond, mc)
+            out[f"attn_d_{name}_hid"], out[f"attn_d_{name}_enc"], out[f"attn_d_{name}_cond"] = map(t2n, r)
+            hs = torch.cat([enc, hid], 1)
+            r = rb.attn_forward(sattn, hs, None, cond, None, rope_main, rope_cond, mc)
+            out[f"attn_s_{name}_hid"], out[f"attn_s_{name}_cond"] = map(t2n, r)
+            for a in (dattn, sattn):
+                if hasattr(a, "c_factor"):
+                    del a.c_factor
+        r = rb.attn_forward(dattn, hid, enc, None, None, rope_main, None, {})
+        out["attn_d_nocond_hid"], out["attn_d_nocond_enc"] = map(t2n, r)
+        out["attn_s_nocond_hid"] = t2n(rb.attn_forward(sattn, torch.cat([enc, hid], 1), None, None, None, rope_main, None, {}))
+        # blocks
+        for name, mc in {"default": {}, "add_cond": {"add_cond_attn": True}}.items():
+            e, h, c = rb.block_forward(tr.transformer_blocks[1], hid, enc, cond, temb, ctemb, rope_cond, rope_main, mc)
+            out[f"block_{name}_enc"], out[f"block_{name}_hid"], out[f"block_{name}_cond"] = t2n(e), t2n(h), t2n(c)
+        e, h, c = rb.block_forward(tr.transformer_blocks[1], hid, enc, None, temb, None, None, rope_main, {})
+        assert c is None
+        out["block_nocond_enc"], out["block_nocond_hid"] = t2n(e), t2n(h)
+        hs = torch.cat([enc, hid], 1)
+        h, c = rb.single_block_forward(tr.single_transformer_blocks[1], hs, temb, rope_main, cond, ctemb, rope_cond, {})
+        out["single_hid"], out["single_cond"] = t2n(h), t2n(c)
+        out["single_nocond_hid"] = t2n(rb.single_block_forward(tr.single_transformer_blocks[1], hs, temb, rope_main))
+        # full forward
+        for name, kw in {"cond": dict(c=True, g=True), "nocond": dict(c=False, g=True)}.items():
+            r = rt.tranformer_forward(tr, x["cond"] if kw["c"] else None, x["cond_ids"] if kw["c"] else None,
+                                      None, {}, hidden_states=x["latents"], encoder_hidden_states=x["enc"],
+                                      pooled_projections=x["pooled"], timestep=x["timestep"], img_ids=x["img_ids"],
+                                      txt_ids=x["txt_ids"], guidance=x["guidance"], return_dict=False)
+            out[f"fwd_{name}"] = t2n(r[0])
+        r = rt.tranformer_forward(tr, x["cond"], x["cond_ids"], None, {}, c_t=0.25, hidden_states=x["latents"],
+                                  encoder_hidden_states=x["enc"], pooled_projections=x["pooled"],
+                                  timestep=x["timestep"], img_ids=x["img_ids"], txt_ids=x["txt_ids"],
+                                  guidance=x["guidance"], return_dict=False)
+        out["fwd_cond_ct025"] = t2n(r[0])
+        tr2 = tiny_transformer(seed=3, guidance_embeds=False)
+        r = rt.tranformer_forward(tr2, x["cond"], x["cond_ids"], None, {}, hidden_states=x["latents"],
+                                  encoder_hidden_states=x["enc"], pooled_projections=x["pooled"],
+                                  timestep=x["timestep"], img_ids=x["img_ids"], txt_ids=x["txt_ids"],
+                                  guidance=None, return_dict=False)
+        out["fwd_noguidance_seed3"] = t2n(r[0])
+    for k, v in x.items():
+        out["in_" + k] = t2n(v)
+    np.savez_compressed(os.path.join(OUT, "flux_tiny.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+    print("flux_tiny.npz", len(out), "arrays")
+
+
+def gold_cs3():
+    from refsrc.train import model as rm
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        # DUAN
+        for name, (C, L, hid) in {"c16": (16, 48, 8), "c1": (1, 768, 128), "c512": (512, 40, 128)}.items():
+            torch.manual_seed(100 + C)
+            d = rm.DUAN(C, hidden_dim=hid)
+            x, c = torch.randn(2, C, L, generator=g), torch.randn(2, C, L, generator=g)
+            out[f"duan_{name}_x"], out[f"duan_{name}_c"], out[f"duan_{name}_y"] = t2n(x), t2n(c), t2n(d(x, c))
+            out[f"duan_{name}_seed"] = np.array([100 + C, hid])  # weights: torch.manual_seed(seed); DUAN(C, hid)
+        # FPP + adaptive pools on the true lengths / size sets
+        for name, (ch, L, sizes) in {"eeg": (4, 4096, [128, 256, 512, 1024, 2048]), "ppg": (4, 256, [64, 128, 256]),
+                                     "fnirs": (6, 512, [128, 256, 448]), "motion": (6, 128, [32, 64, 124])}.items():
+            x = torch.randn(2, ch, L, generator=g)
+            out[f"fpp_{name}_x"], out[f"fpp_{name}_y"] = t2n(x), t2n(rm.FeaturePyramidPooling(sizes)(x))
+        # spatial_pyramid_pooling pad / truncate / equal
+        x = torch.randn(2, 3, 50, generator=g)
+        out["spp_x"] = t2n(x)
+        for n, o in {"pad": 64, "trunc": 32, "same": 50}.items():
+            out[f"spp_{n}"] = t2n(rm.OminiModel.spatial_pyramid_pooling(None, x, o))
+        # fuse_eeg / fuse_fnirs through the unbound reference methods
+        torch.manual_seed(5)
+        ns = types.SimpleNamespace(duan_norm1=rm.DUAN(512), fusion1=nn.Sequential(nn.Linear(1024, 512)),
+                                   duan_norm2=rm.DUAN(1), fusion2=nn.Sequential(nn.Linear(1536, 768)))
+        e, p = torch.randn(1, 512, 64, generator=g), torch.randn(1, 512, 64, generator=g)
+        out["fuse_eeg_e"], out["fuse_eeg_p"] = t2n(e), t2n(p)
+        out["fuse_eeg_y"] = t2n(rm.OminiModel.fuse_eeg(ns, e, p))
+        f, m = torch.randn(2, 768, generator=g), torch.randn(2, 768, generator=g)
+        out["fuse_fnirs_f"], out["fuse_fnirs_m"] = t2n(f), t2n(m)
+        out["fuse_fnirs_y"] = t2n(rm.OminiModel.fuse_fnirs(ns, f, m))
+        out["fuse_seed"] = np.array([5])  # torch.manual_seed(5); DUAN(512), Linear(1024,512), DUAN(1), Linear(1536,768)
+    np.savez_compressed(os.path.join(OUT, "cs3_dgf.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+    print("cs3_dgf.npz", len(out), "arrays")
+
+
+def gold_encoders():
+    """Reference encoder classes with oracle S4 standing in for s4torch (pins the wrapper:
+    permutes, pools, FPP concat order, MLP head).  Small ones only (weights re-derived by seed)."""
+    from refsrc.train import model as rm
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        for name, cls, shape in (("ppg", rm.PPGEncoder, (2, 4, 256)), ("fnirs", rm.FNIRSEncoder, (2, 6, 512)),
+                                 ("motion", rm.MotionEncoder, (2, 6, 128))):
+            torch.manual_seed(77)
+            enc = cls(device="cpu", dtype=torch.float32).eval()
+            x = torch.randn(*shape, generator=g)
+            y = enc(x)
+            out[f"enc_{name}_x"] = t2n(x)
+            if y.dim() == 3:   # [B,512,4096] is 8 MB: keep a strided sample + full checksum
+                out[f"enc_{name}_y_sample"] = t2n(y[:, ::37, ::53])
+                out[f"enc_{name}_y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum())])
+            else:
+                out[f"enc_{name}_y"] = t2n(y)
+            out[f"enc_{name}_seed"] = np.array([77, 1234])
+    np.savez_compressed(os.path.join(OUT, "cs3_encoders.npz"), **{k: np.asarray(v, dtype=np.float64 if k.endswith("_sum") else np.float32) for k, v in out.items()})
+    print("cs3_encoders.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), f"{REF} not found: goldens can only be regenerated in the build container"
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    torch.set_num_threads(4)
+    gold_flux()
+    gold_cs3()
+    gold_encoders()
