@@ -1,0 +1,184 @@
+/* lx.h -- C ABI of the MI355X-native LoongX denoise hot path (liblx_amd.so).
+ *
+ * Drop-in boundary.  The reference (LanceZPF/loongx) is pure Python and has no FFI of its own:
+ * its hot path calls torch / diffusers / s4torch operators from
+ *   src/flux/block.py        (attn_forward :7-176, block_forward :179-278, single_block_forward :281-339)
+ *   src/flux/transformer.py  (tranformer_forward :47-252)
+ *   src/flux/generate.py     (denoise loop :313-369, scheduler.step :349)
+ *   src/train/model.py       (CS3 encoders :16-373, DUAN/DGF :947-1035, fuse_* :731-779)
+ * Each entry point below replaces the operator(s) named in its comment.  The Python binding a maintainer
+ * would add is a ctypes stub; loongx_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; kernels never allocate, never synchronise,
+ *    never retain a pointer after the call returns (model handles excepted, see lx_dit_*);
+ *  - every call enqueues on `stream` (a hipStream_t passed as void*) and returns LX_OK or a negative
+ *    lx_status; lx_last_error() returns the message of the calling thread's last failure;
+ *  - bf16 = bfloat16 bits (uint16), row-major, leading dimensions in ELEMENTS.
+ */
+#ifndef LX_H_
+#define LX_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LX_VERSION 100 /* 0.1.0 */
+
+typedef enum lx_status {
+  LX_OK = 0,
+  LX_ERR_INVALID = -1,   /* bad argument (shape / alignment / NULL) */
+  LX_ERR_UNSUPPORTED = -2,
+  LX_ERR_LAUNCH = -3,    /* HIP launch failure */
+  LX_ERR_NO_DEVICE = -4
+} lx_status;
+
+int lx_version(void);
+const char* lx_last_error(void);
+/* fills name[0..n) with the gcnArchName of the current device; LX_ERR_NO_DEVICE when there is none */
+int lx_device_arch(char* name, size_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogues  --  replaces every nn.Linear on the DiT path:
+ *   to_q/k/v, add_{q,k,v}_proj (block.py:27-29,46-48,81-83), to_out[0]/to_add_out (:154-160),
+ *   ff / ff_context (:258-265), proj_mlp / proj_out of the single block (:302-333),
+ *   x_embedder / context_embedder / proj_out (transformer.py:92-93,115,244).
+ * C[m,n] = sum_k A[m,k] * W[n,k]  (bf16 x bf16 -> fp32 MFMA accumulate), then per `epilogue`.
+ * LoRA (peft, lora_controller.py:5-42): rows of a problem with lora_t != NULL get
+ *   acc += sum_r lora_t[m, toff + r] * lora_up[n, r],  toff = lora_r * min(n / lora_mod_cols, lora_toff_max)
+ * i.e. y = x W^T + s * (x A^T) B^T evaluated in fp32, with lora_t = x A^T from lx_lora_down and
+ * lora_up = s*B.  The image stream passes lora_t = NULL (enable_lora scales the adapter to 0).
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+  LX_EPI_STORE_BF16 = 0, /* C(bf16)  = act(acc + bias)                      */
+  LX_EPI_STORE_F32 = 1,  /* C(fp32)  = acc + bias                           */
+  LX_EPI_RESID_F32 = 2,  /* C(fp32) += gate[m / rows_per_batch, n] * (acc + bias)   (gate NULL => 1) */
+  LX_EPI_GELU = 0x100    /* OR-able flag: GELU(tanh) on columns n >= gelu_col_start */
+};
+
+typedef struct lx_gemm_desc {
+  const void* A;        /* [M,K] bf16, lda */
+  const void* W;        /* [N,K] bf16, ldw (nn.Linear.weight layout) */
+  const float* bias;    /* [N] or NULL */
+  void* C;              /* [M,N], ldc; bf16 or fp32 per epilogue */
+  const float* gate;    /* [ceil(M/rows_per_batch), gate_ld] or NULL */
+  const float* lora_t;  /* [M, lora_ldt] or NULL */
+  const float* lora_up; /* [N, lora_r] */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc;
+  int32_t rows_per_batch, gate_ld;
+  int32_t lora_r, lora_ldt, lora_mod_cols, lora_toff_max;
+  int32_t epilogue;
+  int32_t gelu_col_start;
+} lx_gemm_desc;
+
+#define LX_GEMM_MAX_GROUP 4
+/* One launch over `n` independent problems (the three token streams of a block share one launch so
+ * that small-M streams still fill the chip).  K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0. */
+int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
+
+/* lora_t[M, R] (fp32, ldt) = X[M,K] (bf16, ldx) . Adown[R,K]^T (bf16).  R <= 16.  (peft lora_A) */
+int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, void* stream);
+
+/* Skinny linear for M <= 16 rows (AdaLayerNorm modulation linears, time/text embedders:
+ * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound.
+ * Y[M,N] fp32 (=|+=) act_out(act_in(X[M,K] fp32) . W[N,K]^T (bf16) + bias).  act: 0 none, 1 SiLU. */
+int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy,
+                     int M, int N, int K, int act_in, int act_out, int accumulate, void* stream);
+
+/* Sinusoidal timestep projection (diffusers get_timestep_embedding, flip_sin_to_cos=True, shift 0):
+ * out[b, 0:half] = cos(t[b]*f_i), out[b, half:2*half] = sin(t[b]*f_i), f_i = exp(-ln(1e4) i/half). */
+int lx_timestep_embed(const float* t, float* out, int B, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (no affine, eps) + AdaLN modulation: Y(bf16)[m,:] = LN(X(fp32)[m,:]) * (1 + scale[b,:]) + shift[b,:]
+ * b = m / rows_per_batch.  Replaces norm1/norm1_context/norm/norm2(+mod)/norm_out (block.py:192-207,238-253,301,305).
+ * shift/scale: fp32 [n_batches, mod_ld].  D % 8 == 0, D <= 8192.
+ * ------------------------------------------------------------------------------------------------ */
+int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* scale, int mod_ld, void* Y, int ldy,
+                   int M, int D, int rows_per_batch, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-head RMSNorm (weight, eps) + interleaved-pair RoPE on Q and K, in place, and V transposed into the
+ * attention kernel's [B*H, dh, Spad] key-major image.  Replaces attn.norm_q/k/added_q/added_k +
+ * apply_rotary_emb (block.py:38-41,60-67,74-78,92-99).
+ *   QKV: bf16 [M, ld] with K at column k_col, V at v_col, Q at q_col (each H*128 wide, head-major).
+ *   rows [row0, row0+n_rows): batch b = r / rows_per_batch, position p = r % rows_per_batch;
+ *   cos/sin fp32 [rows_per_batch, 128] (NULL => no RoPE); wq/wk fp32 [128] (NULL => no RMSNorm);
+ *   VT: bf16 [B, H, 128, vt_ld]; the row's key slot is vt_pos0 + p, stored with the 16-key interleave
+ *   the attention kernel expects (see loongx_amd/csrc/attn.hip).  VT NULL => V untouched.
+ * ------------------------------------------------------------------------------------------------ */
+int lx_qkv_prep(void* QKV, int ld, int q_col, int k_col, int v_col, int row0, int n_rows, int rows_per_batch,
+                int H, const float* wq, const float* wk, float eps, const float* cos_tab, const float* sin_tab,
+                void* VT, int vt_ld, int vt_pos0, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Joint attention over up to 3 token segments [text | image | condition] -- replaces
+ * F.scaled_dot_product_attention + the mask/bias construction of block.py:106-135.
+ *   Q,K: bf16 rows of `ld` elements; head h at column q_col/k_col + h*128; O is written over Q's slot
+ *   layout with row stride ldo at column o_col (may alias Q: each Q tile is read before its O is written).
+ *   Segment s of batch b occupies rows seg_row0[s] + b*seg_len[s] ... (+seg_len[s]); keys of segment s live
+ *   at VT positions seg_vt0[s].. (64-aligned, zero padded).
+ *   bias[3][3]: additive score bias (natural-log units) for (query segment, key segment); -INFINITY masks
+ *   the pair entirely; NULL => all zero.  scale = 1/sqrt(dh).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct lx_attn_desc {
+  const void* Q; const void* K; const void* VT; void* O;
+  int32_t ldq, ldk, ldo, vt_ld;
+  int32_t q_col, k_col, o_col;
+  int32_t B, H;
+  int32_t n_seg;
+  int32_t seg_row0[3], seg_len[3], seg_vt0[3];
+  float bias[3][3];
+  float scale;
+} lx_attn_desc;
+int lx_attn_fwd(const lx_attn_desc* d, void* stream);
+
+/* x(fp32) += dsigma * v   (FlowMatchEulerDiscreteScheduler.step, generate.py:349); v is bf16 or fp32 */
+int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream);
+/* dst(fp32)[i] = src(fp32|bf16)[i] ; dst(bf16) = src(fp32) : layout plumbing between streams */
+int lx_convert(void* dst, int dst_bf16, const void* src, int src_bf16, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CS3 (Cross-Scale State Space) encoder pieces -- src/train/model.py:16-373. fp32, [B,C,L] channel-major.
+ * ------------------------------------------------------------------------------------------------ */
+/* S4 SSM as a modal linear recurrence evaluated by a wavefront prefix scan (fp64 state):
+ *   y[b,h,l] = Re sum_n w[h,n] * s_n[l] + D[h]*u[b,h,l],  s_n[l] = lam[h,n]*s_n[l-1] + u[b,h,l]
+ * lam,w: complex fp64 as (re,im) pairs [H,N,2].  Equals s4torch's FFT convolution with kernel K[h,l]=Re sum_n w lam^l. */
+int lx_s4_scan(const float* u, const double* lam, const double* w, const float* Dskip, float* y,
+               int B, int H, int L, int N, void* stream);
+/* Same operator as a direct causal convolution with the materialised kernel Kker[H,L] (cross-check / fallback). */
+int lx_s4_conv(const float* u, const float* Kker, const float* Dskip, float* y, int B, int H, int L, void* stream);
+/* Pointwise channel mix used by every S4 block and the S4 encoder/decoder Linear:
+ *   z = W[Hout,Hin] . act(x[b,:,l]) + bias (+ resid[b,:,l]);  optional LayerNorm over Hout (gamma,beta,eps 1e-5)
+ *   act: 0 none, 1 GELU(erf).  Hin,Hout <= 64. */
+int lx_chanmix(const float* x, const float* W, const float* bias, const float* resid, const float* ln_g,
+               const float* ln_b, float* y, int B, int Hin, int Hout, int L, int act, void* stream);
+/* Multi-scale adaptive average pooling (FeaturePyramidPooling / nn.AdaptiveAvgPool1d bin rule):
+ *   y[b,c, off_i + j] = mean x[b,c, floor(j L/s_i) : ceil((j+1) L/s_i)], rows of y have ldy elements, y_col0 offset. */
+int lx_pyramid_pool(const float* x, float* y, int B, int C, int L, const int* sizes, int n_sizes, int ldy, int y_col0,
+                    void* stream);
+/* Row LayerNorm(gamma,beta,eps)+ReLU in place over fp32 rows (encoder projection heads, model.py:60-72). */
+int lx_layernorm_relu(float* x, const float* g, const float* b, int M, int D, float eps, void* stream);
+/* fp32 linear Y[M,N] (=|+=) X[M,K] . W[N,K]^T + bias for the encoder heads / fusion linears / LoRA glue.
+ * x_trans != 0: X is stored [K, M] (ldx = its leading dim), i.e. channel-major activations [C,L] consumed per position;
+ * y_trans != 0: Y is stored [N, M] (channel-major output). */
+int lx_linear_f32(const float* X, int ldx, int x_trans, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                  int y_trans, int M, int N, int K, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DGF (Dynamic Gated Fusion; `DUAN` in the reference, src/train/model.py:947-1035). fp32 [B,C,L].
+ * gate: conv1x1 C->Hd (gw1 [Hd,C], gb1) ReLU conv1x1 Hd->C (gw2 [C,Hd], gb2) sigmoid, averaged over L;
+ * mlp: conv1x1 C->Hd (mw1, mb1) ReLU conv1x1 Hd->2C (mw2 [2C,Hd], mb2) on the L-pooled condition.
+ * ws: >= lx_duan_workspace_bytes(B,C,L,Hd) bytes of scratch.
+ * ------------------------------------------------------------------------------------------------ */
+size_t lx_duan_workspace_bytes(int B, int C, int L, int Hd);
+int lx_duan_fwd(const float* x, const float* c, const float* gw1, const float* gb1, const float* gw2, const float* gb2,
+                const float* mw1, const float* mb1, const float* mw2, const float* mb2, float* y,
+                int B, int C, int L, int Hd, float eps, int keep_k, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LX_H_ */

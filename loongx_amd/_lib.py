@@ -1,0 +1,85 @@
+"""ctypes binding of liblx_amd.so (include/lx.h).
+
+This is the FFI stub a maintainer of the reference would add.  The product path has NO
+fallback: if the HIP library is missing or fails to load, importing raises; kernels are never replaced by
+torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
+
+LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU = 0, 1, 2, 0x100
+LX_GEMM_MAX_GROUP = 4
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
+                ("gate", C.c_void_p), ("lora_t", C.c_void_p), ("lora_up", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32),
+                ("rows_per_batch", C.c_int32), ("gate_ld", C.c_int32),
+                ("lora_r", C.c_int32), ("lora_ldt", C.c_int32), ("lora_mod_cols", C.c_int32),
+                ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p), ("O", C.c_void_p),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldo", C.c_int32), ("vt_ld", C.c_int32),
+                ("q_col", C.c_int32), ("k_col", C.c_int32), ("o_col", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
+                ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
+                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float)]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SIGS = {
+    "lx_version": (C.c_int, []),
+    "lx_last_error": (C.c_char_p, []),
+    "lx_device_arch": (C.c_int, [C.c_char_p, _Z]),
+    "lx_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _I, _P]),
+    "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
+    "lx_ln_modulate": (C.c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
+    "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
+    "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
+    "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),
+    "lx_convert": (C.c_int, [_P, _I, _P, _I, _Z, _P]),
+    "lx_s4_scan": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "lx_s4_conv": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "lx_chanmix": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lx_pyramid_pool": (C.c_int, [_P, _P, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P]),
+    "lx_layernorm_relu": (C.c_int, [_P, _P, _P, _I, _I, _F, _P]),
+    "lx_linear_f32": (C.c_int, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lx_duan_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "lx_duan_fwd": (C.c_int, [_P] * 11 + [_I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class LxError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"liblx_amd.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                          f"g.build()'` or loongx_amd/csrc/build.sh -- there is no CPU/torch fallback for the hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so is stale: fail loudly
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        raise LxError(f"{what or 'lx call'} failed ({status}): {lib.lx_last_error().decode()}")

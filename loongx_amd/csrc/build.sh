@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Build liblx_amd.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+#   loongx_amd/csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+OBJ="$HERE/../lib/obj"
+mkdir -p "$OUT" "$OBJ"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@")
+SRCS=(api gemm attn rowops cs3 dgf)
+pids=()
+for s in "${SRCS[@]}"; do
+  if [[ ! -f "$OBJ/$s.o" || "$HERE/$s.hip" -nt "$OBJ/$s.o" || "$HERE/common.h" -nt "$OBJ/$s.o" || "$HERE/../../include/lx.h" -nt "$OBJ/$s.o" ]]; then
+    "$HIPCC" "${FLAGS[@]}" -c "$HERE/$s.hip" -o "$OBJ/$s.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblx_amd.so" $(printf "$OBJ/%s.o " "${SRCS[@]}")
+echo "built $OUT/liblx_amd.so"

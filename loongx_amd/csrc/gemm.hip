@@ -1,0 +1,275 @@
+// gemm.hip -- grouped bf16 GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   C[m,n] = sum_k A[m,k] * W[n,k]       A: activations [M,K], W: nn.Linear weight [N,K]
+//
+// Replaces every nn.Linear of the DiT forward (reference src/flux/block.py:27-29,46-48,81-83,154-160,
+// 258-265,302-333; src/flux/transformer.py:92-93,115,244) -- see include/lx.h.
+//
+// Design (MI355X-first, no CUDA lineage):
+//  * workgroup = 8 waves (512 threads), macro tile BM x 256 x 64 (BM = 256 or 128), 1 workgroup / CU;
+//  * operands go HBM/L2 -> LDS with global_load_lds (16 B / lane, no VGPR round trip), double buffered,
+//    one barrier per K step;
+//  * LDS tile rows are 128 B (64 bf16); the 16-B slot index is XORed with (row>>1)&7 so that the
+//    ds_read_b128 lane groups of an MFMA fragment read hit 16 distinct slots (conflict-free); because
+//    global_load_lds writes lane-linear, the swizzle is applied to the per-lane SOURCE address;
+//  * v_mfma_f32_32x32x16_bf16 with the weight tile as the MFMA "A" operand, so the accumulator layout is
+//    lane = output row m, registers = 4 consecutive output columns n -> vector epilogue loads/stores;
+//  * per-wave tile (BM/2) x 64: 2 W-fragments + BM/64 X-fragments feed 2*BM/64 MFMAs per 16-deep k step;
+//  * epilogue fuses bias, rank-r LoRA up-projection, GELU(tanh), and the gated residual accumulate
+//    X += gate * y in fp32 (block.py:224-234,269-272,326-334);
+//  * blockIdx -> tile map is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous run of tiles,
+//    ordered in 4-tile-tall column groups so co-resident tiles share A / W panels in that L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BN = 256;
+constexpr int BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int GROUP_M = 4;
+
+struct GemmArgs {
+  lx_gemm_desc p[LX_GEMM_MAX_GROUP];
+  int tile_start[LX_GEMM_MAX_GROUP + 1];
+  int n;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM>
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) {
+  constexpr int MI = BM / 64;               // 32-row m-blocks per wave
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int W_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // ---- XCD-aware block -> tile map ---------------------------------------------------------------
+  const int total = args.tile_start[args.n];
+  int lid;
+  {
+    const int pid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, inx = pid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  }
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < LX_GEMM_MAX_GROUP; ++i)
+    if (i < args.n && lid >= args.tile_start[i]) g = i;
+  const lx_gemm_desc& P = args.p[g];
+  const int local = lid - args.tile_start[g];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  int tm, tn;
+  {
+    const int gs = GROUP_M * tiles_n;
+    const int gi = local / gs, in_g = local - gi * gs;
+    const int first_m = gi * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = P.M, N = P.N, K = P.K;
+
+  // ---- per-lane source pointers for the global->LDS stage ----------------------------------------
+  // one global_load_lds moves 1 KiB per wave = 8 tile rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
+  const __bf16* asrc[MI];
+  const __bf16* wsrc[4];
+  {
+    const int rsub = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int row = (j * 8 + wave) * 8 + rsub;
+      const int lslot = pslot ^ ((row >> 1) & 7);
+      const int gm_ = min(m0 + row, M - 1);
+      asrc[j] = (const __bf16*)P.A + (size_t)gm_ * P.lda + lslot * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (j * 8 + wave) * 8 + rsub;
+      const int lslot = pslot ^ ((row >> 1) & 7);
+      const int gn_ = min(n0 + row, N - 1);
+      wsrc[j] = (const __bf16*)P.W + (size_t)gn_ * P.ldw + lslot * 8;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + k0), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets -----------------------------------------------------------------------
+  const int sw = (l31 >> 1) & 7;
+  int slot_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) slot_off[ks] = ((ks * 2 + lhi) ^ sw) * 16;
+  const int a_row_off = (wm * (BM / 2) + l31) * 128;
+  const int w_row_off = A_BYTES + (wn * 64 + l31) * 128;
+
+  f32x16 acc[2][MI];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  const int nkt = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+    const char* sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 wf[2], xf[MI];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 128 + slot_off[ks]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 128 + slot_off[ks]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
+  const int epi = P.epilogue & 0xff;
+  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
+  const int nbase = n0 + wn * 64 + 4 * lhi;
+  const bool has_lora = P.lora_t != nullptr;
+  const int R = P.lora_r;
+  int toff = 0;
+  if (has_lora) toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + l31;
+    if (m >= M) continue;
+    const int b = m / P.rows_per_batch;
+    float tv[16];
+    if (has_lora) {
+      const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff;
+      for (int r = 0; r < R; ++r) tv[r] = tp[r];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int nb = nbase + j * 32 + rq * 8;
+        if (nb >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = acc[j][i][rq * 4 + c];
+        if (P.bias) {
+          const f32x4 bv = *(const f32x4*)(P.bias + nb);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += bv[c];
+        }
+        if (has_lora) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float* up = P.lora_up + (size_t)(nb + c) * R;
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += tv[r] * up[r];
+            v[c] += s;
+          }
+        }
+        if (do_gelu && nb >= P.gelu_col_start) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+        }
+        if (epi == LX_EPI_STORE_BF16) {
+          u32x2 o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)((uint16_t*)P.C + (size_t)m * P.ldc + nb) = o;
+        } else if (epi == LX_EPI_STORE_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + nb) = o;
+        } else {  // LX_EPI_RESID_F32
+          float* cp = (float*)P.C + (size_t)m * P.ldc + nb;
+          f32x4 o = *(const f32x4*)cp;
+          if (P.gate) {
+            const f32x4 gv = *(const f32x4*)(P.gate + (size_t)b * P.gate_ld + nb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += v[c];
+          }
+          *(f32x4*)cp = o;
+        }
+      }
+    }
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
+  LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
+  GemmArgs args;
+  args.n = n;
+  long tiles256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const lx_gemm_desc& p = problems[i];
+    LX_CHECK_ARG(p.A && p.W && p.C, "lx_gemm_bf16[%d]: NULL operand", i);
+    LX_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "lx_gemm_bf16[%d]: bad shape M=%d N=%d K=%d", i, p.M, p.N, p.K);
+    LX_CHECK_ARG(p.K % BK == 0, "lx_gemm_bf16[%d]: K=%d must be a multiple of %d", i, p.K, BK);
+    LX_CHECK_ARG(p.N % 4 == 0, "lx_gemm_bf16[%d]: N=%d must be a multiple of 4", i, p.N);
+    LX_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.lda >= p.K && p.ldw >= p.K, "lx_gemm_bf16[%d]: lda/ldw must be >= K and multiples of 8", i);
+    LX_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "lx_gemm_bf16[%d]: operands must be 16-byte aligned", i);
+    LX_CHECK_ARG(p.ldc % 4 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 4", i, p.ldc);
+    const int epi = p.epilogue & 0xff;
+    LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && epi <= LX_EPI_RESID_F32, "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
+    LX_CHECK_ARG(p.rows_per_batch > 0, "lx_gemm_bf16[%d]: rows_per_batch must be > 0", i);
+    if (p.gate) LX_CHECK_ARG(p.gate_ld >= p.N && p.gate_ld % 4 == 0, "lx_gemm_bf16[%d]: gate_ld=%d", i, p.gate_ld);
+    if (p.lora_t) {
+      LX_CHECK_ARG(p.lora_up && p.lora_r >= 1 && p.lora_r <= 16, "lx_gemm_bf16[%d]: LoRA needs lora_up and 1 <= r <= 16", i);
+      LX_CHECK_ARG(p.lora_mod_cols <= 0 || p.lora_mod_cols % BN == 0, "lx_gemm_bf16[%d]: lora_mod_cols must be a multiple of %d", i, BN);
+    }
+    if (p.bias) LX_CHECK_ARG(((uintptr_t)p.bias & 15) == 0, "lx_gemm_bf16[%d]: bias must be 16-byte aligned", i);
+    args.p[i] = p;
+    tiles256 += (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  }
+  int bm = env_int("LX_GEMM_BM", 0);
+  if (bm != 128 && bm != 256) bm = (tiles256 < 208) ? 128 : 256;  // < ~0.8 of 256 CUs: halve the tile to fill the chip
+  int t = 0;
+  for (int i = 0; i < n; ++i) {
+    args.tile_start[i] = t;
+    t += ((problems[i].M + bm - 1) / bm) * ((problems[i].N + BN - 1) / BN);
+  }
+  for (int i = n; i <= LX_GEMM_MAX_GROUP; ++i) args.tile_start[i] = t;
+  hipStream_t s = (hipStream_t)stream;
+  if (bm == 256)
+    hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, args);
+  else
+    hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, args);
+  LX_LAUNCH_CHECK("lx_gemm_bf16");
+  return LX_OK;
+}

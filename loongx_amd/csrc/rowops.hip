@@ -1,0 +1,409 @@
+// rowops.hip -- HBM-bound row kernels of the DiT step (gfx950): AdaLN LayerNorm+modulate, per-head
+// RMSNorm+RoPE(+V^T image), LoRA down-projection, skinny (M<=16) linears, timestep embedding, Euler step.
+// All loads/stores are 8-16 B per lane and coalesced; reductions are wave64 shuffles (no LDS, no atomics).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm(no affine) + (1+scale)*x + shift, fp32 in -> bf16 out. One wave per row, row kept in VGPRs.
+// Reference: AdaLayerNormZero/ZeroSingle/Continuous + norm2 modulation (block.py:192-207,238-253,301,305).
+// ------------------------------------------------------------------------------------------------------
+template <int NCH>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale, int mod_ld, uint16_t* __restrict__ Y,
+                                                          int ldy, int M, int D, int rows_per_batch, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = X + (size_t)row * ldx;
+  f32x4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = v[i][c] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const int b = row / rows_per_batch;
+  const float* sh = shift + (size_t)b * mod_ld;
+  const float* sc = scale + (size_t)b * mod_ld;
+  uint16_t* yr = Y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    const f32x4 a = *(const f32x4*)(sc + col);
+    const f32x4 bsh = *(const f32x4*)(sh + col);
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mean) * rstd * (1.0f + a[c]) + bsh[c];
+    u32x2 w;
+    w[0] = pack_bf16x2(o[0], o[1]);
+    w[1] = pack_bf16x2(o[2], o[3]);
+    *(u32x2*)(yr + col) = w;
+  }
+}
+
+// generic D (multiple of 4): three passes over the (L2-resident) row
+__global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restrict__ X, int ldx, const float* __restrict__ shift,
+                                                           const float* __restrict__ scale, int mod_ld, uint16_t* __restrict__ Y,
+                                                           int ldy, int M, int D, int rows_per_batch, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = X + (size_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q += (v[k] - mean) * (v[k] - mean);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const int b = row / rows_per_batch;
+  const float* sh = shift + (size_t)b * mod_ld;
+  const float* sc = scale + (size_t)b * mod_ld;
+  uint16_t* yr = Y + (size_t)row * ldy;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *(const f32x4*)(xr + c);
+    const f32x4 a = *(const f32x4*)(sc + c);
+    const f32x4 bsh = *(const f32x4*)(sh + c);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (v[k] - mean) * rstd * (1.0f + a[k]) + bsh[k];
+    u32x2 w;
+    w[0] = pack_bf16x2(o[0], o[1]);
+    w[1] = pack_bf16x2(o[2], o[3]);
+    *(u32x2*)(yr + c) = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Q/K: RMSNorm(128, weight) + RoPE in place; V -> V^T image. Block = 64 positions x 1 head x 1 batch.
+// 16 lanes own one (row, head) vector of 128 bf16 (8 elements = 4 rotary pairs each).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vt_interleave(int key) {  // within every 16 keys: [0-3, 8-11, 4-7, 12-15]
+  return (key & ~15) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
+}
+
+__global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
+                                                       int row0, int rows_per_batch, const float* __restrict__ wq,
+                                                       const float* __restrict__ wk, float eps, const float* __restrict__ cos_tab,
+                                                       const float* __restrict__ sin_tab, uint16_t* __restrict__ VT, int vt_ld,
+                                                       int vt_pos0, int H) {
+  __shared__ uint16_t vt_s[64][128 + 8];
+  const int p0 = blockIdx.x * 64;
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int sub = tid & 15;        // 16-B chunk within the 128-wide head vector
+  const int rloc = tid >> 4;       // 0..15 : row within a 16-row pass
+  const size_t rbase = (size_t)row0 + (size_t)b * rows_per_batch;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int p = p0 + pass * 16 + rloc;
+    const bool valid = p < rows_per_batch;
+    uint16_t* rowp = QKV + (rbase + (valid ? p : 0)) * ld + h * 128 + sub * 8;
+    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (cos_tab && valid) {
+      const float* ct = cos_tab + (size_t)p * 128 + sub * 8;
+      const float* st = sin_tab + (size_t)p * 128 + sub * 8;
+      c0 = *(const f32x4*)ct; c1 = *(const f32x4*)(ct + 4);
+      s0 = *(const f32x4*)st; s1 = *(const f32x4*)(st + 4);
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {   // 0: q, 1: k
+      const float* wn = which ? wk : wq;
+      uint16_t* ptr = rowp + (which ? k_col : q_col);
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (valid) raw = *(const u32x4*)ptr;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[2 * i] = __uint_as_float(raw[i] << 16);
+        x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+      }
+      if (wn) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+        const f32x4 w0 = *(const f32x4*)(wn + sub * 8), w1 = *(const f32x4*)(wn + sub * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = x[i] * r * w0[i]; x[4 + i] = x[4 + i] * r * w1[i]; }
+      }
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // pairs (2i, 2i+1): out = x*cos + rot*sin, rot = (-x_odd, x_even)
+        const float ce = i < 2 ? c0[2 * i] : c1[2 * i - 4], co = i < 2 ? c0[2 * i + 1] : c1[2 * i - 3];
+        const float se = i < 2 ? s0[2 * i] : s1[2 * i - 4], so = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
+        y[2 * i] = x[2 * i] * ce - x[2 * i + 1] * se;
+        y[2 * i + 1] = x[2 * i + 1] * co + x[2 * i] * so;
+      }
+      if (valid) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(y[2 * i], y[2 * i + 1]);
+        *(u32x4*)ptr = o;
+      }
+    }
+    if (VT) {  // stash V[key][d] for the transpose
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (valid) raw = *(const u32x4*)(rowp + v_col);
+      *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = raw;
+    }
+  }
+  if (!VT) return;
+  __syncthreads();
+  // write V^T rows: thread -> (d, 8 consecutive slots); slot -> source key via the (involutive) interleave
+  uint16_t* vtb = VT + ((size_t)(b * H + h) * 128) * vt_ld + vt_pos0 + p0;
+  for (int item = tid; item < 128 * 8; item += 256) {
+    const int d = item >> 3, g = item & 7;
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = vt_s[vt_interleave(g * 8 + i)][d];
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (uint32_t)e[2 * i] | ((uint32_t)e[2 * i + 1] << 16);
+    *(u32x4*)(vtb + (size_t)d * vt_ld + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LoRA down-projection: T[M,R] = X[M,K] . A[R,K]^T   (bf16 in, fp32 out). Wave = 4 rows, lanes split K.
+// ------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void lora_down_kernel(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ A,
+                                                        float* __restrict__ T, int ldt, int M, int K) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m0 = (blockIdx.x * 4 + wave) * 4;
+  if (m0 >= M) return;
+  float acc[4][R];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[i][r] = 0.f;
+  const uint16_t* xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = X + (size_t)min(m0 + i, M - 1) * ldx;
+  for (int k = lane * 8; k < K; k += 512) {
+    float xv[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 raw = *(const u32x4*)(xr[i] + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[i][2 * j] = __uint_as_float(raw[j] << 16); xv[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u32x4 raw = *(const u32x4*)(A + (size_t)r * K + k);
+      float av[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { av[2 * j] = __uint_as_float(raw[j] << 16); av[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][r] = fmaf(xv[i][j], av[j], acc[i][r]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float s = wave_sum(acc[i][r]);
+      if (lane == 0 && m0 + i < M) T[(size_t)(m0 + i) * ldt + r] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Skinny linear: Y[M<=16,N] fp32 = act_out(act_in(X[M,K]) . W[N,K]^T + bias). Weight-streaming (HBM bound):
+// a wave owns 4 consecutive output columns, lanes split K in 16-B chunks, rows processed 4 at a time.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ X, int ldx, const uint16_t* __restrict__ W,
+                                                            int ldw, const float* __restrict__ bias, float* __restrict__ Y,
+                                                            int ldy, int M, int N, int K, int act_in, int act_out, int accumulate) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  if (n0 >= N) return;
+  const uint16_t* wr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wr[c] = W + (size_t)min(n0 + c, N - 1) * ldw;
+  for (int mb = 0; mb < M; mb += 4) {
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float wv[4][8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x4 raw = *(const u32x4*)(wr[c] + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wv[c][2 * j] = __uint_as_float(raw[j] << 16); wv[c][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (mb + i < M) {
+          const float* xp = X + (size_t)(mb + i) * ldx + k;
+          const f32x4 x0 = *(const f32x4*)xp, x1 = *(const f32x4*)(xp + 4);
+          float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          if (act_in == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = silu(xv[j]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][c] = fmaf(xv[j], wv[c][j], acc[i][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s = wave_sum(acc[i][c]);
+        if (lane == 0 && mb + i < M && n0 + c < N) {
+          if (bias) s += bias[n0 + c];
+          if (act_out == 1) s = silu(s);
+          float* yp = Y + (size_t)(mb + i) * ldy + n0 + c;
+          *yp = accumulate ? (*yp + s) : s;
+        }
+      }
+  }
+}
+
+__global__ void timestep_embed_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, j = i % half;
+  const float f = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+  const float a = t[b] * f;
+  out[(size_t)b * dim + j] = cosf(a);          // flip_sin_to_cos=True: [cos | sin]
+  out[(size_t)b * dim + half + j] = sinf(a);
+}
+
+__global__ void euler_kernel(float* __restrict__ x, const void* __restrict__ v, int v_bf16, float ds, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float vv = v_bf16 ? bf16_to_f32(((const uint16_t*)v)[i]) : ((const float*)v)[i];
+    x[i] = fmaf(ds, vv, x[i]);
+  }
+}
+
+__global__ void convert_kernel(void* __restrict__ dst, int dst_bf16, const void* __restrict__ src, int src_bf16, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = src_bf16 ? bf16_to_f32(((const uint16_t*)src)[i]) : ((const float*)src)[i];
+    if (dst_bf16) ((uint16_t*)dst)[i] = f32_to_bf16(v);
+    else ((float*)dst)[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* scale, int mod_ld, void* Y, int ldy,
+                              int M, int D, int rows_per_batch, float eps, void* stream) {
+  LX_CHECK_ARG(X && shift && scale && Y, "lx_ln_modulate: NULL operand");
+  LX_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 16384, "lx_ln_modulate: D=%d must be a multiple of 4 and <= 16384", D);
+  LX_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0 && rows_per_batch > 0, "lx_ln_modulate: ldx/ldy/mod_ld must be multiples of 4");
+  LX_CHECK_ARG((((uintptr_t)X | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)Y & 7) == 0, "lx_ln_modulate: misaligned operand");
+  const dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t* y = (uint16_t*)Y;
+  if (D == 3072) hipLaunchKernelGGL(ln_modulate_kernel<12>, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
+  else if (D == 256) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
+  else hipLaunchKernelGGL(ln_modulate_generic, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
+  LX_LAUNCH_CHECK("lx_ln_modulate");
+  return LX_OK;
+}
+
+extern "C" int lx_qkv_prep(void* QKV, int ld, int q_col, int k_col, int v_col, int row0, int n_rows, int rows_per_batch, int H,
+                           const float* wq, const float* wk, float eps, const float* cos_tab, const float* sin_tab, void* VT,
+                           int vt_ld, int vt_pos0, void* stream) {
+  LX_CHECK_ARG(QKV && n_rows > 0 && rows_per_batch > 0 && n_rows % rows_per_batch == 0, "lx_qkv_prep: n_rows=%d must be a multiple of rows_per_batch=%d", n_rows, rows_per_batch);
+  LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep: ld and column offsets must be multiples of 8");
+  LX_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "lx_qkv_prep: cos/sin tables must come together");
+  if (VT) LX_CHECK_ARG(vt_ld % 64 == 0 && vt_pos0 % 64 == 0, "lx_qkv_prep: vt_ld and vt_pos0 must be multiples of 64");
+  const dim3 grid((rows_per_batch + 63) / 64, H, n_rows / rows_per_batch);
+  hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col, v_col, row0,
+                     rows_per_batch, wq, wk, eps, cos_tab, sin_tab, (uint16_t*)VT, vt_ld, vt_pos0, H);
+  LX_LAUNCH_CHECK("lx_qkv_prep");
+  return LX_OK;
+}
+
+extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, void* stream) {
+  LX_CHECK_ARG(X && Adown && T && M > 0, "lx_lora_down: NULL operand");
+  LX_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldt >= R, "lx_lora_down: K and ldx must be multiples of 8, ldt >= R");
+  const dim3 grid((M + 15) / 16), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const uint16_t* x = (const uint16_t*)X;
+  const uint16_t* a = (const uint16_t*)Adown;
+  switch (R) {
+    case 4: hipLaunchKernelGGL(lora_down_kernel<4>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
+    case 8: hipLaunchKernelGGL(lora_down_kernel<8>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
+    case 12: hipLaunchKernelGGL(lora_down_kernel<12>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
+    case 16: hipLaunchKernelGGL(lora_down_kernel<16>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
+    default: lx_set_error("lx_lora_down: R=%d unsupported (4, 8, 12, 16)", R); return LX_ERR_UNSUPPORTED;
+  }
+  LX_LAUNCH_CHECK("lx_lora_down");
+  return LX_OK;
+}
+
+extern "C" int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy, int M, int N,
+                                int K, int act_in, int act_out, int accumulate, void* stream) {
+  LX_CHECK_ARG(X && W && Y, "lx_linear_skinny: NULL operand");
+  LX_CHECK_ARG(M >= 1 && M <= 16, "lx_linear_skinny: M=%d must be in [1,16]", M);
+  LX_CHECK_ARG(K % 8 == 0 && ldw % 8 == 0 && ldx % 4 == 0, "lx_linear_skinny: K %% 8, ldw %% 8, ldx %% 4 required (K=%d)", K);
+  const dim3 grid((N + 15) / 16), block(256);
+  hipLaunchKernelGGL(linear_skinny_kernel, grid, block, 0, (hipStream_t)stream, X, ldx, (const uint16_t*)W, ldw, bias, Y, ldy, M, N,
+                     K, act_in, act_out, accumulate);
+  LX_LAUNCH_CHECK("lx_linear_skinny");
+  return LX_OK;
+}
+
+extern "C" int lx_timestep_embed(const float* t, float* out, int B, int dim, void* stream) {
+  LX_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0, "lx_timestep_embed: bad arguments");
+  const int n = B * dim / 2;
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim);
+  LX_LAUNCH_CHECK("lx_timestep_embed");
+  return LX_OK;
+}
+
+extern "C" int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream) {
+  LX_CHECK_ARG(x && v, "lx_euler_step: NULL operand");
+  if (n == 0) return LX_OK;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(euler_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, v, v_is_bf16, dsigma, n);
+  LX_LAUNCH_CHECK("lx_euler_step");
+  return LX_OK;
+}
+
+extern "C" int lx_convert(void* dst, int dst_bf16, const void* src, int src_bf16, size_t n, void* stream) {
+  LX_CHECK_ARG(dst && src, "lx_convert: NULL operand");
+  if (n == 0) return LX_OK;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(convert_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, dst_bf16, src, src_bf16, n);
+  LX_LAUNCH_CHECK("lx_convert");
+  return LX_OK;
+}

@@ -1,0 +1,160 @@
+"""Thin torch-tensor -> C-ABI wrappers (one function per include/lx.h entry point).
+
+torch is used for device memory and streams only; every function here launches a hand-written HIP kernel
+from liblx_amd.so on the current torch stream and raises LxError on failure.  There is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, AttnDesc, GemmDesc, check, lib)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (the hot path has no CPU fallback)")
+
+
+def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
+              gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
+              gelu_col_start=0, M=None, N=None, K=None) -> GemmDesc:
+    """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome)."""
+    _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
+    d = GemmDesc()
+    d.A, d.W, d.C = A.data_ptr(), W.data_ptr(), C_.data_ptr()
+    d.bias = _p(bias)
+    d.M = A.shape[0] if M is None else M
+    d.K = A.shape[1] if K is None else K
+    d.N = W.shape[0] if N is None else N
+    d.lda, d.ldw, d.ldc = A.stride(0), W.stride(0), C_.stride(0)
+    d.rows_per_batch = d.M if rows_per_batch is None else rows_per_batch
+    d.gate = _p(gate)
+    d.gate_ld = gate.stride(0) if gate is not None else 0
+    d.lora_t, d.lora_up = _p(lora_t), _p(lora_up)
+    if lora_t is not None:
+        d.lora_r, d.lora_ldt = lora_up.shape[1], lora_t.stride(0)
+    d.lora_mod_cols, d.lora_toff_max = lora_mod_cols, lora_toff_max
+    d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
+    want = torch.bfloat16 if (epilogue & 0xff) == LX_EPI_STORE_BF16 else torch.float32
+    _req(C_, want, "C")
+    return d
+
+
+def gemm(problems: Sequence[GemmDesc]) -> None:
+    n = len(problems)
+    arr = (GemmDesc * n)(*problems)
+    check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
+
+
+def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor) -> None:
+    _req(X, torch.bfloat16, "X"); _req(Adown, torch.bfloat16, "Adown"); _req(T, torch.float32, "T")
+    check(lib.lx_lora_down(X.data_ptr(), X.stride(0), Adown.data_ptr(), T.data_ptr(), T.stride(0), X.shape[0], X.shape[1],
+                           Adown.shape[0], _stream()), "lx_lora_down")
+
+
+def linear_skinny(X, W, bias, Y, act_in=0, act_out=0, accumulate=False) -> None:
+    _req(X, torch.float32, "X"); _req(W, torch.bfloat16, "W"); _req(Y, torch.float32, "Y")
+    check(lib.lx_linear_skinny(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), _p(bias), Y.data_ptr(), Y.stride(0),
+                               X.shape[0], W.shape[0], W.shape[1], act_in, act_out, int(accumulate), _stream()), "lx_linear_skinny")
+
+
+def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> None:
+    _req(t, torch.float32, "t"); _req(out, torch.float32, "out")
+    check(lib.lx_timestep_embed(t.data_ptr(), out.data_ptr(), out.shape[0], out.shape[1], _stream()), "lx_timestep_embed")
+
+
+def ln_modulate(X, shift, scale, Y, rows_per_batch, eps=1e-6, mod_ld=None) -> None:
+    _req(X, torch.float32, "X"); _req(Y, torch.bfloat16, "Y"); _req(shift, torch.float32, "shift"); _req(scale, torch.float32, "scale")
+    check(lib.lx_ln_modulate(X.data_ptr(), X.stride(0), shift.data_ptr(), scale.data_ptr(),
+                             shift.stride(0) if mod_ld is None else mod_ld, Y.data_ptr(), Y.stride(0), X.shape[0], X.shape[1],
+                             rows_per_batch, eps, _stream()), "lx_ln_modulate")
+
+
+def qkv_prep(QKV, q_col, k_col, v_col, row0, n_rows, rows_per_batch, H, wq, wk, cos, sin, VT, vt_pos0, eps=1e-6) -> None:
+    _req(QKV, torch.bfloat16, "QKV")
+    check(lib.lx_qkv_prep(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, row0, n_rows, rows_per_batch, H, _p(wq), _p(wk), eps,
+                          _p(cos), _p(sin), _p(VT), VT.shape[-1] if VT is not None else 0, vt_pos0, _stream()), "lx_qkv_prep")
+
+
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+    d = AttnDesc()
+    d.Q, d.K, d.VT, d.O = Q.data_ptr(), K.data_ptr(), VT.data_ptr(), O.data_ptr()
+    d.ldq, d.ldk, d.ldo, d.vt_ld = Q.stride(0), K.stride(0), O.stride(0), VT.shape[-1]
+    d.q_col, d.k_col, d.o_col, d.B, d.H, d.n_seg = q_col, k_col, o_col, B, H, len(seg_len)
+    for i in range(len(seg_len)):
+        d.seg_row0[i], d.seg_len[i], d.seg_vt0[i] = seg_row0[i], seg_len[i], seg_vt0[i]
+    for i in range(3):
+        for j in range(3):
+            d.bias[i][j] = 0.0 if bias is None else float(bias[i][j])
+    d.scale = (1.0 / math.sqrt(128.0)) if scale is None else scale
+    check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
+
+
+def euler_step(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> None:
+    _req(x, torch.float32, "x")
+    check(lib.lx_euler_step(x.data_ptr(), v.data_ptr(), int(v.dtype == torch.bfloat16), float(dsigma), x.numel(), _stream()), "lx_euler_step")
+
+
+def convert(dst: torch.Tensor, src: torch.Tensor) -> None:
+    assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    check(lib.lx_convert(dst.data_ptr(), int(dst.dtype == torch.bfloat16), src.data_ptr(), int(src.dtype == torch.bfloat16),
+                         dst.numel(), _stream()), "lx_convert")
+
+
+# ---- CS3 / DGF -------------------------------------------------------------------------------------------
+def s4_scan(u, lam, w, D, y) -> None:
+    B, H, Lq = u.shape
+    check(lib.lx_s4_scan(u.data_ptr(), lam.data_ptr(), w.data_ptr(), D.data_ptr(), y.data_ptr(), B, H, Lq, lam.shape[1], _stream()), "lx_s4_scan")
+
+
+def s4_conv(u, K, D, y) -> None:
+    B, H, Lq = u.shape
+    check(lib.lx_s4_conv(u.data_ptr(), K.data_ptr(), D.data_ptr(), y.data_ptr(), B, H, Lq, _stream()), "lx_s4_conv")
+
+
+def chanmix(x, W, bias, resid, ln_g, ln_b, y, act=0) -> None:
+    B, Hin, Lq = x.shape
+    check(lib.lx_chanmix(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(ln_g), _p(ln_b), y.data_ptr(), B, Hin, W.shape[0], Lq,
+                         act, _stream()), "lx_chanmix")
+
+
+def pyramid_pool(x, y, sizes, y_col0=0) -> None:
+    B, Cc, Lq = x.shape
+    arr = (C.c_int * len(sizes))(*sizes)
+    check(lib.lx_pyramid_pool(x.data_ptr(), y.data_ptr(), B, Cc, Lq, arr, len(sizes), y.stride(-2), y_col0, _stream()), "lx_pyramid_pool")
+
+
+def layernorm_relu(x, g, b, eps=1e-5) -> None:
+    check(lib.lx_layernorm_relu(x.data_ptr(), g.data_ptr(), b.data_ptr(), x.shape[0], x.shape[1], eps, _stream()), "lx_layernorm_relu")
+
+
+def linear_f32(X, W, bias, Y, *, M, N, K, ldx, ldy, x_trans=False, y_trans=False, accumulate=False, ldw=None) -> None:
+    check(lib.lx_linear_f32(X.data_ptr(), ldx, int(x_trans), W.data_ptr(), W.stride(0) if ldw is None else ldw, _p(bias), Y.data_ptr(),
+                            ldy, int(y_trans), M, N, K, int(accumulate), _stream()), "lx_linear_f32")
+
+
+def duan_fwd(x, c, p, y, keep_k, eps=1e-3) -> None:
+    """p: dict with gate.0.weight/bias, gate.2.weight/bias, mlp.0.weight/bias, mlp.2.weight/bias (conv1x1 as [out,in])."""
+    B, Cc, Lq = x.shape
+    Hd = p["gate.0.weight"].shape[0]
+    nbytes = lib.lx_duan_workspace_bytes(B, Cc, Lq, Hd)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.lx_duan_fwd(x.data_ptr(), c.data_ptr(), p["gate.0.weight"].data_ptr(), p["gate.0.bias"].data_ptr(),
+                          p["gate.2.weight"].data_ptr(), p["gate.2.bias"].data_ptr(), p["mlp.0.weight"].data_ptr(),
+                          p["mlp.0.bias"].data_ptr(), p["mlp.2.weight"].data_ptr(), p["mlp.2.bias"].data_ptr(), y.data_ptr(),
+                          B, Cc, Lq, Hd, eps, keep_k, ws.data_ptr(), nbytes, _stream()), "lx_duan_fwd")

@@ -1,0 +1,397 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point vs a torch fp32/fp64 restatement of the same op
+(oracle/ for the domain ops).  Run with `pytest -m gpu` through gpurun."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import relerr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from loongx_amd import ops as o
+    return o
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("bm", [256, 128])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (2560, 3072, 3072)])
+def test_gemm_store_bf16_bias(ops, M, N, K, bm, monkeypatch):
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3)
+    Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias)])
+    ref = A.float() @ W.float().T + bias
+    assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
+    assert torch.isfinite(Cc.float()).all()
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I detects a transposed / permuted accumulator mapping (asymmetric W)."""
+    K = 256
+    A = torch.eye(K, dtype=torch.bfloat16, device=DEV)
+    W = (torch.arange(512 * K, device=DEV).reshape(512, K) % 251).to(torch.bfloat16)
+    Cc = torch.empty(K, 512, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, epilogue=ops.LX_EPI_STORE_F32)])
+    assert torch.equal(Cc, W.float().T)
+
+
+@pytest.mark.parametrize("bm", [256, 128])
+def test_gemm_gelu_colstart_and_f32(ops, bm, monkeypatch):
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    M, N, K = 520, 1024, 192
+    A = rnd(M, K, seed=4, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=5, scale=0.1, dtype=torch.bfloat16)
+    bias = rnd(N, seed=6, scale=0.1)
+    Cc = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=512)])
+    ref = A.float() @ W.float().T + bias
+    ref[:, 512:] = torch.nn.functional.gelu(ref[:, 512:], approximate="tanh")
+    assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
+    C32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    assert relerr(C32.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("bm", [256, 128])
+def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
+    """Three-stream launch: text (own weights), image (base weights), condition (base + LoRA), gated residual."""
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    B, T, Nn, Cn, D, K, r = 2, 48, 80, 96, 512, 256, 4
+    Wt = rnd(D, K, seed=1, scale=0.05, dtype=torch.bfloat16)
+    Wi = rnd(D, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bt, bi = rnd(D, seed=3, scale=0.1), rnd(D, seed=4, scale=0.1)
+    At = rnd(B * T, K, seed=5, dtype=torch.bfloat16)
+    Ai = rnd(B * Nn, K, seed=6, dtype=torch.bfloat16)
+    Ac = rnd(B * Cn, K, seed=7, dtype=torch.bfloat16)
+    X = rnd(B * (T + Nn + Cn), D, seed=8)
+    X0 = X.clone()
+    gate = rnd(3 * B, D, seed=9)                       # [text b0,b1 | image b0,b1 | cond b0,b1]
+    Ad = rnd(r, K, seed=10, scale=0.1, dtype=torch.bfloat16)
+    Bu = rnd(D, r, seed=11, scale=0.1)
+    Tl = torch.empty(B * Cn, r, dtype=torch.float32, device=DEV)
+    ops.lora_down(Ac, Ad, Tl)
+    tref = Ac.float() @ Ad.float().T
+    assert relerr(Tl.cpu(), tref.cpu()) < 1e-5
+    Xt, Xi, Xc = X[: B * T], X[B * T: B * (T + Nn)], X[B * (T + Nn):]
+    ops.gemm([
+        ops.gemm_desc(At, Wt, Xt, bias=bt, epilogue=ops.LX_EPI_RESID_F32, gate=gate[0:B], rows_per_batch=T),
+        ops.gemm_desc(Ai, Wi, Xi, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[B:2 * B], rows_per_batch=Nn),
+        ops.gemm_desc(Ac, Wi, Xc, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[2 * B:], rows_per_batch=Cn,
+                      lora_t=Tl, lora_up=Bu),
+    ])
+    def gated(y, g, L):
+        return y * g.repeat_interleave(L, dim=0)
+    ref_t = X0[: B * T] + gated(At.float() @ Wt.float().T + bt, gate[0:B], T)
+    ref_i = X0[B * T: B * (T + Nn)] + gated(Ai.float() @ Wi.float().T + bi, gate[B:2 * B], Nn)
+    ref_c = X0[B * (T + Nn):] + gated(Ac.float() @ Wi.float().T + bi + tref @ Bu.T, gate[2 * B:], Cn)
+    for got, ref in ((Xt, ref_t), (Xi, ref_i), (Xc, ref_c)):
+        assert relerr(got.cpu(), ref.cpu()) < 2e-5
+
+
+def test_gemm_lora_module_offsets(ops):
+    """Fused [k|v|q|mlp]-style output: LoRA column blocks pick their own r-slice of t."""
+    M, K, r, mod = 200, 128, 4, 256
+    N = 4 * mod
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    Ad = rnd(3 * r, K, seed=3, scale=0.1, dtype=torch.bfloat16)   # 3 modules; module 2 spans 2*mod columns
+    Bu = rnd(N, r, seed=4, scale=0.2)
+    Tl = torch.empty(M, 3 * r, dtype=torch.float32, device=DEV)
+    ops.lora_down(A, Ad, Tl)
+    Cc = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, epilogue=ops.LX_EPI_STORE_F32, lora_t=Tl, lora_up=Bu, lora_mod_cols=mod, lora_toff_max=2)])
+    t = A.float() @ Ad.float().T
+    ref = A.float() @ W.float().T
+    for blk in range(4):
+        m = min(blk, 2)
+        ref[:, blk * mod:(blk + 1) * mod] += t[:, m * r:(m + 1) * r] @ Bu[blk * mod:(blk + 1) * mod].T
+    assert relerr(Cc.cpu(), ref.cpu()) < 2e-5
+
+
+def test_gemm_rejects_bad_k(ops):
+    A = rnd(64, 96, dtype=torch.bfloat16)
+    W = rnd(64, 96, dtype=torch.bfloat16)
+    Cc = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm([ops.gemm_desc(A, W, Cc)])
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("D", [256, 3072, 1024])
+def test_ln_modulate(ops, D):
+    B, Lr = 3, 37
+    X = rnd(B * Lr, D, seed=1, scale=2.0) + 0.5
+    sh, sc = rnd(B, D, seed=2), rnd(B, D, seed=3, scale=0.3)
+    Y = torch.empty(B * Lr, D, dtype=torch.bfloat16, device=DEV)
+    ops.ln_modulate(X, sh, sc, Y, rows_per_batch=Lr)
+    ref = torch.nn.functional.layer_norm(X, (D,), eps=1e-6).view(B, Lr, D) * (1 + sc[:, None]) + sh[:, None]
+    assert relerr(Y.float().cpu(), ref.reshape(B * Lr, D).cpu()) < 3e-3
+
+
+def test_skinny_linear_and_timestep(ops):
+    from oracle.flux_modules import get_timestep_embedding
+    for M, N, K in [(1, 1000, 3072), (5, 18432, 3072), (16, 96, 256), (2, 3072, 768)]:
+        X = rnd(M, K, seed=1)
+        W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+        b = rnd(N, seed=3)
+        Y = torch.empty(M, N, device=DEV)
+        ops.linear_skinny(X, W, b, Y, act_in=1)
+        ref = torch.nn.functional.silu(X) @ W.float().T + b
+        assert relerr(Y.cpu(), ref.cpu()) < 1e-5
+        ops.linear_skinny(X, W, None, Y, act_out=1, accumulate=True)
+        ref2 = ref + torch.nn.functional.silu(X @ W.float().T)
+        assert relerr(Y.cpu(), ref2.cpu()) < 1e-5
+    t = torch.tensor([0.0, 3.7, 700.0, 999.0], device=DEV)
+    out = torch.empty(4, 256, device=DEV)
+    ops.timestep_embed(t, out)
+    assert (out.cpu() - get_timestep_embedding(t.cpu(), 256)).abs().max() < 2e-4
+
+
+def test_euler_and_convert(ops):
+    x = rnd(1000, seed=1)
+    v16 = rnd(1000, seed=2, dtype=torch.bfloat16)
+    x0 = x.clone()
+    ops.euler_step(x, v16, -0.125)
+    assert torch.allclose(x, x0 - 0.125 * v16.float(), atol=1e-6)
+    v32 = rnd(1000, seed=3)
+    ops.euler_step(x, v32, 0.5)
+    assert torch.allclose(x, x0 - 0.125 * v16.float() + 0.5 * v32, atol=1e-6)
+    d = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
+    ops.convert(d, v32)
+    assert torch.equal(d, v32.to(torch.bfloat16))
+
+
+def _qkv_buffer(B, lens, H, seed):
+    M = B * sum(lens)
+    return rnd(M, 3 * H * 128, seed=seed, dtype=torch.bfloat16)
+
+
+def _segments(B, lens):
+    row0, vt0, r, p = [], [], 0, 0
+    for Ls in lens:
+        row0.append(r); vt0.append(p)
+        r += B * Ls
+        p += (Ls + 63) // 64 * 64
+    return row0, vt0, p
+
+
+def test_qkv_prep_rmsnorm_rope(ops):
+    from oracle.flux_modules import apply_rotary_emb, rope_tables
+    B, H, Ls = 2, 3, 70
+    buf = _qkv_buffer(B, [Ls], H, seed=1)
+    orig = buf.clone()
+    wq, wk = 1 + 0.1 * rnd(128, seed=2), 1 + 0.1 * rnd(128, seed=3)
+    ids = torch.zeros(Ls, 3)
+    ids[:, 1] = torch.arange(Ls) // 8
+    ids[:, 2] = torch.arange(Ls) % 8 - 3
+    cos, sin = rope_tables(ids)
+    VT = torch.zeros(B, H, 128, 128, dtype=torch.bfloat16, device=DEV)
+    D = H * 128
+    ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=0, n_rows=B * Ls, rows_per_batch=Ls, H=H, wq=wq, wk=wk,
+                 cos=cos.to(DEV), sin=sin.to(DEV), VT=VT, vt_pos0=0)
+    o = orig.float().cpu().view(B, Ls, 3, H, 128)
+    def ref(x, w):
+        x = x.permute(0, 2, 1, 3)                                   # [B,H,L,128]
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w.cpu()
+        return apply_rotary_emb(x, (cos, sin)).permute(0, 2, 1, 3)  # [B,L,H,128]
+    got = buf.float().cpu().view(B, Ls, 3, H, 128)
+    assert relerr(got[:, :, 2], ref(o[:, :, 2], wq)) < 3e-3       # q
+    assert relerr(got[:, :, 0], ref(o[:, :, 0], wk)) < 3e-3       # k
+    assert torch.equal(got[:, :, 1], o[:, :, 1])                  # v untouched in place
+    # V^T image: slot s of every 16-key group holds key perm[s]
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    vt = VT.float().cpu()                                          # [B,H,128,128]
+    v = torch.zeros(B, 128, H, 128)
+    v[:, :Ls] = o[:, :, 1]
+    slots = (torch.arange(128) // 16) * 16 + perm[torch.arange(128) % 16]
+    expect = v[:, slots].permute(0, 2, 3, 1)                      # [B,H,d,slot]
+    assert torch.equal(vt, expect)
+
+
+def _attn_reference(buf, B, H, lens, bias, q_col, k_col, v_col):
+    """fp32 SDPA over the concatenated segments with the block bias."""
+    S = sum(lens)
+    D = H * 128
+    x = buf.float().cpu()
+    row0, _, _ = _segments(B, lens)
+    def gather(col):
+        out = torch.zeros(B, S, H, 128)
+        p = 0
+        for s, Ls in enumerate(lens):
+            blk = x[row0[s]: row0[s] + B * Ls, col: col + D].view(B, Ls, H, 128)
+            out[:, p:p + Ls] = blk
+            p += Ls
+        return out.permute(0, 2, 1, 3)
+    q, k, v = gather(q_col), gather(k_col), gather(v_col)
+    mask = torch.zeros(S, S)
+    edges = np.cumsum([0] + list(lens))
+    for i in range(len(lens)):
+        for j in range(len(lens)):
+            mask[edges[i]:edges[i + 1], edges[j]:edges[j + 1]] = bias[i][j]
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    return o.permute(0, 2, 1, 3), edges       # [B,S,H,128]
+
+
+NEG = float("-inf")
+BIASES = {
+    "none": [[0.0] * 3] * 3,
+    "cfactor": [[0, 0, math.log(0.5)], [0, 0, math.log(0.5)], [math.log(0.5), math.log(0.5), 0]],
+    "no_union": [[0, 0, NEG], [0, 0, NEG], [NEG, NEG, 0]],
+    "independent": [[0, 0, 0], [0, 0, 0], [NEG, NEG, 0]],
+}
+
+
+@pytest.mark.parametrize("mode", list(BIASES))
+@pytest.mark.parametrize("lens", [(16, 16, 16), (64, 128, 200), (512, 1024, 1024)])
+def test_attention_segments(ops, lens, mode):
+    B, H = (1, 2) if lens[0] == 512 else (2, 3)
+    D = H * 128
+    buf = _qkv_buffer(B, lens, H, seed=5)
+    orig = buf.clone()
+    row0, vt0, vt_len = _segments(B, lens)
+    VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=DEV)
+    for s, Ls in enumerate(lens):
+        ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=row0[s], n_rows=B * Ls, rows_per_batch=Ls, H=H, wq=None, wk=None,
+                     cos=None, sin=None, VT=VT, vt_pos0=vt0[s])
+    assert torch.equal(buf, orig)
+    bias = BIASES[mode]
+    ops.attn_fwd(buf, buf, VT, buf, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=bias)
+    ref, edges = _attn_reference(orig, B, H, lens, bias, 2 * D, 0, D)
+    got = buf.float().cpu()
+    for s, Ls in enumerate(lens):
+        o = got[row0[s]: row0[s] + B * Ls, 2 * D: 3 * D].view(B, Ls, H, 128)
+        assert relerr(o, ref[:, edges[s]:edges[s + 1]]) < 6e-3, f"segment {s}"
+    assert torch.equal(buf[:, : 2 * D], orig[:, : 2 * D])   # K and V columns untouched
+
+
+def test_attention_single_segment_spike(ops):
+    """One segment; a spiked key forces a large running-max jump mid-sequence (online-softmax rescale path)."""
+    B, H, Ls = 1, 1, 320
+    D = 128
+    buf = _qkv_buffer(B, [Ls], H, seed=9)
+    buf[200, 0:128] = buf[7, 256:384] * 6.0      # k[200] aligned with q[7]
+    orig = buf.clone()
+    VT = torch.zeros(B, H, 128, 320, dtype=torch.bfloat16, device=DEV)
+    ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=0, n_rows=Ls, rows_per_batch=Ls, H=H, wq=None, wk=None, cos=None, sin=None,
+                 VT=VT, vt_pos0=0)
+    ops.attn_fwd(buf, buf, VT, buf, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=[0], seg_len=[Ls], seg_vt0=[0])
+    ref, _ = _attn_reference(orig, B, H, (Ls,), [[0.0] * 3] * 3, 2 * D, 0, D)
+    assert relerr(buf.float().cpu()[:, 2 * D:].view(1, Ls, 1, 128), ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------ CS3 / DGF
+@pytest.mark.parametrize("H,N,L", [(4, 4, 256), (6, 6, 512), (6, 6, 128), (64, 64, 4096)])
+def test_s4_scan_and_conv(ops, H, N, L):
+    from oracle import s4
+    lay = s4.S4Layer(H, N, L, torch.Generator().manual_seed(3))
+    pr = lay.params_np()
+    K = s4.kernel_genfunc(pr, L)
+    lam, w = s4.diagonalize(pr, L)
+    B = 2
+    u = torch.randn(B, H, L, generator=torch.Generator().manual_seed(4))
+    yref = s4.causal_conv_direct(u.permute(0, 2, 1).numpy(), K, pr["D"]).transpose(0, 2, 1)
+    ud = u.to(DEV)
+    lam_t = torch.from_numpy(np.stack([lam.real, lam.imag], -1)).to(DEV)
+    w_t = torch.from_numpy(np.stack([w.real, w.imag], -1)).to(DEV)
+    Dk = torch.from_numpy(pr["D"]).float().to(DEV)
+    y = torch.empty_like(ud)
+    ops.s4_scan(ud, lam_t, w_t, Dk, y)
+    assert np.abs(y.cpu().numpy() - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
+    y2 = torch.empty_like(ud)
+    ops.s4_conv(ud, torch.from_numpy(K).float().to(DEV), Dk, y2)
+    assert np.abs(y2.cpu().numpy() - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
+
+
+@pytest.mark.parametrize("hin,hout", [(4, 64), (64, 64), (4, 4), (6, 6)])
+def test_chanmix(ops, hin, hout):
+    B, L = 2, 300
+    x, W, b = rnd(B, hin, L, seed=1), rnd(hout, hin, seed=2, scale=0.3), rnd(hout, seed=3)
+    res = rnd(B, hout, L, seed=4)
+    g, be = 1 + 0.1 * rnd(hout, seed=5), rnd(hout, seed=6, scale=0.1)
+    y = torch.empty(B, hout, L, device=DEV)
+    ops.chanmix(x, W, b, res, g, be, y, act=1)
+    z = torch.einsum("oi,bil->bol", W, torch.nn.functional.gelu(x)) + b[None, :, None] + res
+    ref = torch.nn.functional.layer_norm(z.permute(0, 2, 1), (hout,), g, be, 1e-5).permute(0, 2, 1)
+    assert relerr(y.cpu(), ref.cpu()) < 1e-5
+    ops.chanmix(x, W, b, None, None, None, y, act=0)
+    assert relerr(y.cpu(), (torch.einsum("oi,bil->bol", W, x) + b[None, :, None]).cpu()) < 1e-5
+
+
+def test_pyramid_pool_golden(ops):
+    from tests.helpers import load
+    G = load("cs3_dgf.npz")
+    for name, sizes in {"eeg": [128, 256, 512, 1024, 2048], "ppg": [64, 128, 256], "fnirs": [128, 256, 448], "motion": [32, 64, 124]}.items():
+        x = G[f"fpp_{name}_x"].to(DEV)
+        ref = G[f"fpp_{name}_y"]
+        y = torch.empty(ref.shape, device=DEV)
+        ops.pyramid_pool(x, y, sizes)
+        assert relerr(y.cpu(), ref) < 1e-6
+
+
+def test_layernorm_relu_and_linear_f32(ops):
+    x = rnd(5, 1000, seed=1, scale=3.0)
+    g, b = 1 + 0.1 * rnd(1000, seed=2), rnd(1000, seed=3, scale=0.2)
+    ref = torch.relu(torch.nn.functional.layer_norm(x, (1000,), g, b, 1e-5))
+    ops.layernorm_relu(x, g, b)
+    assert relerr(x.cpu(), ref.cpu()) < 1e-5
+    for M, N, K in [(3, 70, 1356), (130, 65, 8), (257, 512, 1024)]:
+        X, W, bias = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
+        ref = X @ W.T + bias
+        Y = torch.empty(M, N, device=DEV)
+        ops.linear_f32(X, W, bias, Y, M=M, N=N, K=K, ldx=K, ldy=N)
+        assert relerr(Y.cpu(), ref.cpu()) < 1e-5
+        Xt = X.T.contiguous()
+        Yt = torch.zeros(N, M, device=DEV)
+        ops.linear_f32(Xt, W, bias, Yt, M=M, N=N, K=K, ldx=M, ldy=M, x_trans=True, y_trans=True)
+        ops.linear_f32(Xt, W, None, Yt, M=M, N=N, K=K, ldx=M, ldy=M, x_trans=True, y_trans=True, accumulate=True)
+        assert relerr(Yt.cpu(), (ref + X @ W.T).T.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("name,C", [("c16", 16), ("c1", 1), ("c512", 512)])
+def test_duan_golden(ops, name, C):
+    """DGF kernel vs the golden produced by the REAL reference DUAN class."""
+    from oracle import cs3
+    from tests.helpers import load
+    G = load("cs3_dgf.npz")
+    seed, hid = [int(v) for v in G[f"duan_{name}_seed"]]
+    torch.manual_seed(seed)
+    d = cs3.DUAN(C, hidden_dim=hid)
+    p = {k: v.detach().reshape(v.shape[0], -1).contiguous().to(DEV) if v.dim() == 3 else v.detach().to(DEV) for k, v in d.state_dict().items()}
+    x, c = G[f"duan_{name}_x"].to(DEV), G[f"duan_{name}_c"].to(DEV)
+    y = torch.empty_like(x)
+    ops.duan_fwd(x, c, p, y, keep_k=max(1, int(C * 0.7)))
+    ref = G[f"duan_{name}_y"]
+    assert torch.equal((y.cpu().abs().sum(2) > 0), (ref.abs().sum(2) > 0))   # same channels kept
+    assert relerr(y.cpu(), ref) < 2e-5
+
+
+def test_duan_full_size(ops):
+    from oracle import cs3
+    torch.manual_seed(1)
+    d = cs3.DUAN(512)
+    B, C, L = 2, 512, 4096
+    x, c = torch.randn(B, C, L), torch.randn(B, C, L)
+    with torch.no_grad():
+        ref = d(x, c)
+    p = {k: v.detach().reshape(v.shape[0], -1).contiguous().to(DEV) if v.dim() == 3 else v.detach().to(DEV) for k, v in d.state_dict().items()}
+    y = torch.empty(B, C, L, device=DEV)
+    ops.duan_fwd(x.to(DEV), c.to(DEV), p, y, keep_k=358)
+    assert relerr(y.cpu(), ref) < 2e-5
