@@ -91,6 +91,10 @@ int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const floa
  * out[b, 0:half] = cos(t[b]*f_i), out[b, half:2*half] = sin(t[b]*f_i), f_i = exp(-ln(1e4) i/half). */
 int lx_timestep_embed(const float* t, float* out, int B, int dim, void* stream);
 
+/* RoPE tables (diffusers FluxPosEmbed, transformer.py:130-134): ids fp32 [L,3]; cos/sin fp32 [L, a0+a1+a2],
+ * frequencies 1/theta^(2j/d_axis) and angles in fp64, each value repeated for the pair (2j, 2j+1). */
+int lx_rope_table(const float* ids, int L, int a0, int a1, int a2, double theta, float* cos_t, float* sin_t, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (no affine, eps) + AdaLN modulation: Y(bf16)[m,:] = LN(X(fp32)[m,:]) * (1 + scale[b,:]) + shift[b,:]
  * b = m / rows_per_batch.  Replaces norm1/norm1_context/norm/norm2(+mod)/norm_out (block.py:192-207,238-253,301,305).

@@ -44,6 +44,7 @@ _SIGS = {
     "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
+    "lx_rope_table": (C.c_int, [_P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),
     "lx_ln_modulate": (C.c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),

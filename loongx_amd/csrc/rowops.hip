@@ -407,3 +407,35 @@ extern "C" int lx_convert(void* dst, int dst_bf16, const void* src, int src_bf16
   LX_LAUNCH_CHECK("lx_convert");
   return LX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// RoPE tables (diffusers FluxPosEmbed / get_1d_rotary_pos_embed, transformer.py:130-134): fp64 frequencies,
+// repeat-interleaved real layout, stored fp32. One thread per (position, rotary pair).
+// ------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void rope_table_kernel(const float* __restrict__ ids, int n_axes, int a0, int a1, int a2, double theta,
+                                  float* __restrict__ cos_t, float* __restrict__ sin_t, int L) {
+  const int dims[3] = {a0, a1, a2};
+  const int total = a0 + a1 + a2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * (total / 2)) return;
+  const int p = i / (total / 2);
+  int j = i % (total / 2), axis = 0, off = 0;
+  while (axis < n_axes - 1 && j >= dims[axis] / 2) { j -= dims[axis] / 2; off += dims[axis]; ++axis; }
+  const double freq = 1.0 / pow(theta, (double)(2 * j) / (double)dims[axis]);
+  const double ang = (double)ids[(size_t)p * n_axes + axis] * freq;
+  const float c = (float)cos(ang), s = (float)sin(ang);
+  const size_t o = (size_t)p * total + off + 2 * j;
+  cos_t[o] = c; cos_t[o + 1] = c;
+  sin_t[o] = s; sin_t[o + 1] = s;
+}
+}  // namespace
+
+extern "C" int lx_rope_table(const float* ids, int L, int a0, int a1, int a2, double theta, float* cos_t, float* sin_t, void* stream) {
+  LX_CHECK_ARG(ids && cos_t && sin_t && L > 0, "lx_rope_table: bad arguments");
+  LX_CHECK_ARG(a0 > 0 && a1 > 0 && a2 > 0 && a0 % 2 == 0 && a1 % 2 == 0 && a2 % 2 == 0, "lx_rope_table: axes dims must be positive and even");
+  const int n = L * (a0 + a1 + a2) / 2;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, 3, a0, a1, a2, theta, cos_t, sin_t, L);
+  LX_LAUNCH_CHECK("lx_rope_table");
+  return LX_OK;
+}

@@ -1,0 +1,340 @@
+"""DiT engine: one LoongX/Flux denoise step on MI355X, composed from the liblx_amd.so kernels.
+
+Implements the arithmetic of the reference's `tranformer_forward` (src/flux/transformer.py:47-252) and
+`block_forward` / `single_block_forward` / `attn_forward` (src/flux/block.py) on a stream-major token layout:
+
+    X  fp32 [B*T text rows | B*N image rows | B*C condition rows, D]   residual stream (fp32 accumulate)
+    XN bf16 same rows                                                  AdaLN-normalised GEMM operand
+    Y  bf16 [rows, 7D] = [k | v | q/attn-out | mlp]                    projections; attention writes O over q
+
+Per step the engine hoists everything that does not depend on the timestep (reference recomputes it 28x):
+context_embedder(prompt_embeds), x_embedder(condition_latents), both RoPE tables, the guidance/text parts of
+temb, cond_temb (c_t is fixed, transformer.py:108-114) and therefore EVERY modulation vector of the condition stream.
+LoRA semantics follow lora_controller.enable_lora: the condition stream runs W + s*B*A, the image stream the base
+weights unless model_config["latent_lora"]; evaluated as a rank-r epilogue term, never by merging weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..ops import LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_STORE_BF16, LX_EPI_STORE_F32
+from .weights import FluxConfig, PackedWeights
+
+NEG_INF = float("-inf")
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class DiTEngine:
+    def __init__(self, weights: PackedWeights, device="cuda"):
+        self.w = weights
+        self.cfg: FluxConfig = weights.cfg
+        self.device = torch.device(device)
+        if self.cfg.attention_head_dim != 128:
+            raise ValueError("the gfx950 attention kernel is specialised for head_dim 128 (FLUX.1)")
+        self.shape = None
+        self.cond_ready = False
+        self.model_config: Dict = {}
+        self.c_factor: Optional[float] = None
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def setup(self, B: int, T: int, N: int, C: int) -> None:
+        if self.shape == (B, T, N, C):
+            return
+        cfg, dev = self.cfg, self.device
+        D, H = cfg.inner_dim, cfg.num_attention_heads
+        self.B, self.T, self.N, self.C = B, T, N, C
+        self.r_txt, self.r_img, self.r_cond = 0, B * T, B * (T + N)
+        self.M = B * (T + N + C)
+        M = self.M
+        f32, bf16 = torch.float32, torch.bfloat16
+        self.X = torch.zeros(M, D, dtype=f32, device=dev)
+        self.XN = torch.zeros(M, D, dtype=bf16, device=dev)
+        self.Y = torch.zeros(M, 7 * D, dtype=bf16, device=dev)
+        self.vt0 = [0, _pad64(T), _pad64(T) + _pad64(N)]
+        self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
+        self.TL = torch.zeros(M, 16, dtype=f32, device=dev)
+        self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
+        self.out = torch.zeros(B * N, cfg.in_channels, dtype=f32, device=dev)
+        self.temb = torch.zeros(B, D, dtype=f32, device=dev)
+        self.temb_base = torch.zeros(B, D, dtype=f32, device=dev)
+        self.cond_temb = torch.zeros(B, D, dtype=f32, device=dev)
+        self.tproj = torch.zeros(B, 256, dtype=f32, device=dev)
+        self.thid = torch.zeros(B, D, dtype=f32, device=dev)
+        self.t1000 = torch.zeros(B, dtype=f32, device=dev)
+        self.mods = torch.zeros(B, cfg.n_mod, dtype=f32, device=dev)
+        self.cmods = torch.zeros(B, cfg.n_mod, dtype=f32, device=dev)
+        nb = cfg.num_layers + cfg.num_single_layers
+        self.tmod = torch.zeros(B, max(nb * cfg.lora_r, 4), dtype=f32, device=dev)
+        self.X_txt_init = torch.zeros(B * T, D, dtype=f32, device=dev)
+        self.X_cond_init = torch.zeros(max(B * C, 1), D, dtype=f32, device=dev)
+        self.shape = (B, T, N, C)
+        self.cond_ready = False
+
+    # row views ---------------------------------------------------------------------------------------
+    def rows(self, buf: torch.Tensor, stream: str) -> torch.Tensor:
+        if stream == "txt":
+            return buf[self.r_txt:self.r_img]
+        if stream == "img":
+            return buf[self.r_img:self.r_cond]
+        return buf[self.r_cond:self.M]
+
+    def _streams(self):
+        s = [("txt", self.T), ("img", self.N)]
+        if self.C:
+            s.append(("cond", self.C))
+        return s
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _lin_skinny(self, x, name, out, act_in=0, act_out=0, accumulate=False):
+        ops.linear_skinny(x, self.w.t[name + ".w"], self.w.t[name + ".b"], out, act_in=act_in, act_out=act_out,
+                          accumulate=accumulate)
+
+    def _time_text_embed(self, t1000: torch.Tensor, out: torch.Tensor, base: torch.Tensor) -> None:
+        """out = base + timestep_embedder(sinusoid(t1000))   (CombinedTimestep[Guidance]TextProjEmbeddings)."""
+        ops.timestep_embed(t1000, self.tproj)
+        self._lin_skinny(self.tproj, "tte.timestep_embedder.linear_1", self.thid, act_out=1)
+        out.copy_(base)
+        self._lin_skinny(self.thid, "tte.timestep_embedder.linear_2", out, accumulate=True)
+
+    def _compute_mods(self, temb: torch.Tensor, out: torch.Tensor, lora: bool) -> None:
+        """All AdaLN modulation vectors of the model from one weight-streaming launch (+ rank-r LoRA glue)."""
+        w = self.w
+        ops.linear_skinny(temb, w.t["mod.w"], w.t["mod.b"], out, act_in=1)
+        if lora and "mod.lora_down" in w.t:
+            cfg, r, D = self.cfg, self.cfg.lora_r, self.cfg.inner_dim
+            nb = cfg.num_layers + cfg.num_single_layers
+            tm = self.tmod[:, : nb * r]
+            ops.linear_skinny(temb, w.t["mod.lora_down"], None, tm, act_in=1)
+            for idx in range(nb):
+                if idx < cfg.num_layers:
+                    base, width = cfg.mod_base_double(idx), 6 * D
+                else:
+                    base, width = cfg.mod_base_single(idx - cfg.num_layers), 3 * D
+                ops.linear_f32(tm[:, idx * r:], w.t[f"mod.lora_up.{idx}"], None, out[:, base:], M=self.B, N=width, K=r,
+                               ldx=tm.stride(0), ldy=out.stride(0), accumulate=True)
+
+    def _attn_bias(self) -> List[List[float]]:
+        """block.py:106-128 as a (query segment, key segment) table over [text, image, cond]."""
+        b = [[0.0] * 3 for _ in range(3)]
+        mc = self.model_config
+        if self.C:
+            if not mc.get("union_cond_attn", True):
+                for i in (0, 1):
+                    b[i][2] = NEG_INF
+                    b[2][i] = NEG_INF
+            elif mc.get("independent_condition", False):
+                b[2][0] = b[2][1] = NEG_INF
+            if self.c_factor is not None:
+                lb = math.log(self.c_factor)
+                b = [[0.0] * 3 for _ in range(3)]
+                for i in (0, 1):
+                    b[i][2] = lb
+                    b[2][i] = lb
+        return b
+
+    # --------------------------------------------------------------------------------- step-invariant part
+    def set_conditioning(self, prompt_embeds, pooled, guidance, txt_ids, img_ids, condition_latents=None,
+                         condition_ids=None, c_t: float = 0.0, model_config: Optional[Dict] = None,
+                         c_factor: Optional[float] = None) -> None:
+        cfg, w, dev = self.cfg, self.w, self.device
+        B, T = prompt_embeds.shape[0], prompt_embeds.shape[1]
+        N = img_ids.shape[0]
+        C = 0 if condition_latents is None else condition_latents.shape[1]
+        self.setup(B, T, N, C)
+        self.model_config = dict(model_config or {})
+        self.c_factor = c_factor
+        self.latent_lora = bool(self.model_config.get("latent_lora", False))
+        if self.model_config.get("add_cond_attn", False) and C and C != N:
+            raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
+        f32, bf16 = torch.float32, torch.bfloat16
+        # context_embedder(prompt_embeds) -> cached text rows
+        pe = prompt_embeds.to(device=dev, dtype=bf16).reshape(B * T, -1).contiguous()
+        ops.gemm([ops.gemm_desc(pe, w.t["context_embedder.w"], self.X_txt_init, bias=w.t["context_embedder.b"],
+                                epilogue=LX_EPI_STORE_F32)])
+        # x_embedder(condition_latents) with LoRA active -> cached condition rows
+        if C:
+            cl = condition_latents.to(device=dev, dtype=bf16).reshape(B * C, -1).contiguous()
+            lo = w.lora.get("x_embedder")
+            tl = None
+            if lo is not None:
+                tl = self.TL[: B * C, : cfg.lora_r]
+                ops.lora_down(cl, lo.down, tl)
+            ops.gemm([ops.gemm_desc(cl, w.t["x_embedder.w"], self.X_cond_init, bias=w.t["x_embedder.b"], epilogue=LX_EPI_STORE_F32,
+                                    lora_t=tl, lora_up=lo.up if lo is not None else None)])
+        # RoPE tables: [text; image] and condition (transformer.py:130-134)
+        ids = torch.cat([txt_ids.to(dev, f32).reshape(-1, 3), img_ids.to(dev, f32).reshape(-1, 3)], 0)
+        self.cos_main, self.sin_main = ops.rope_table(ids, cfg.axes_dims_rope)
+        if C:
+            self.cos_cond, self.sin_cond = ops.rope_table(condition_ids.to(dev, f32).reshape(-1, 3), cfg.axes_dims_rope)
+        # temb_base = text_embedder(pooled) [+ guidance_embedder(sinusoid(1000 g))]
+        pooled = pooled.to(device=dev, dtype=f32).contiguous()
+        self._lin_skinny(pooled, "tte.text_embedder.linear_1", self.thid, act_out=1)
+        self._lin_skinny(self.thid, "tte.text_embedder.linear_2", self.temb_base)
+        if cfg.guidance_embeds:
+            if guidance is None:
+                raise ValueError("this transformer has guidance_embeds=True: pass `guidance`")
+            g1000 = (guidance.to(device=dev, dtype=f32) * 1000.0).contiguous()
+            ops.timestep_embed(g1000, self.tproj)
+            self._lin_skinny(self.tproj, "tte.guidance_embedder.linear_1", self.thid, act_out=1)
+            self._lin_skinny(self.thid, "tte.guidance_embedder.linear_2", self.temb_base, accumulate=True)
+        # cond_temb and all condition-stream modulations (LoRA on norm1.linear / norm.linear)
+        if C:
+            ct = torch.full((B,), float(c_t) * 1000.0, dtype=f32, device=dev)
+            self._time_text_embed(ct, self.cond_temb, self.temb_base)
+            self._compute_mods(self.cond_temb, self.cmods, lora=True)
+        self.attn_bias = self._attn_bias()
+        self.cond_ready = True
+
+    # ------------------------------------------------------------------------------------------ building blocks
+    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
+        D = self.cfg.inner_dim
+        for s, L in self._streams():
+            mods = self.cmods if s == "cond" else self.mods
+            b0 = base_by_stream[s]
+            ops.ln_modulate(self.rows(self.X, s), mods[:, b0 + shift_off:], mods[:, b0 + scale_off:], self.rows(self.XN, s),
+                            rows_per_batch=L, mod_ld=mods.stride(0))
+
+    def _lora_rows(self, include_txt: bool):
+        """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
+        model_config["latent_lora"] also the image stream and, where text shares the module (single blocks), text."""
+        if self.latent_lora:
+            r0 = self.r_txt if include_txt else self.r_img
+            return r0, self.M - r0
+        return self.r_cond, self.M - self.r_cond
+
+    def _lora_t(self, A: torch.Tensor, name: str, include_txt: bool = False):
+        lo = self.w.lora.get(name)
+        if lo is None or (self.C == 0 and not self.latent_lora):
+            return None, None
+        r0, n = self._lora_rows(include_txt)
+        t = self.TL[r0:r0 + n, : lo.down.shape[0]]
+        ops.lora_down(A[r0:r0 + n], lo.down, t)
+        return lo, r0
+
+    def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
+                      gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
+                      gelu_col_start: int = 0) -> None:
+        """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
+        (None => text rows use `main` too: single blocks)."""
+        w = self.w
+        lo, lr0 = self._lora_t(A, main, include_txt=txt is None)
+        probs = []
+        for s, L in self._streams():
+            name = txt if (s == "txt" and txt is not None) else main
+            a, c = self.rows(A, s), self.rows(Cbuf, s)
+            kw = dict(bias=w.t[name + ".b"], epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
+            if gate_off is not None:
+                mods = self.cmods if s == "cond" else self.mods
+                kw["gate"] = mods[:, gate_off[s]:]
+            if lo is not None and name == main and (s == "cond" or (s == "img" and self.latent_lora) or
+                                                    (s == "txt" and self.latent_lora and txt is None)):
+                row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
+                if row0 >= lr0:
+                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up, lora_mod_cols=lora_mod_cols,
+                              lora_toff_max=lora_toff_max)
+            probs.append(ops.gemm_desc(a, w.t[name + ".w"], c, **kw))
+        ops.gemm(probs)
+
+    def _attention(self, wq, wk, wq_txt, wk_txt) -> None:
+        cfg = self.cfg
+        D, H, B = cfg.inner_dim, cfg.num_attention_heads, self.B
+        Y = self.Y
+        seg_row0, seg_len, seg_vt0 = [], [], []
+        off = 0
+        for idx, (s, L) in enumerate(self._streams()):
+            row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
+            if s == "cond":
+                cos, sin = self.cos_cond, self.sin_cond
+            else:
+                cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
+                off += L
+            ops.qkv_prep(Y, q_col=2 * D, k_col=0, v_col=D, row0=row0, n_rows=B * L, rows_per_batch=L, H=H,
+                         wq=wq_txt if s == "txt" else wq, wk=wk_txt if s == "txt" else wk, cos=cos, sin=sin,
+                         VT=self.VT, vt_pos0=self.vt0[idx])
+            seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[idx])
+        ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
+                     seg_vt0=seg_vt0, bias=self.attn_bias)
+
+    # ------------------------------------------------------------------------------------------ blocks
+    def double_block(self, i: int) -> None:
+        cfg, w = self.cfg, self.w
+        D = cfg.inner_dim
+        b = cfg.mod_base_double(i)
+        base = {"img": b, "cond": b, "txt": b + 6 * D}
+        p = f"d{i}"
+        Yq, Ya, Yf = self.Y[:, : 3 * D], self.Y[:, 2 * D: 3 * D], self.Y[:, 3 * D:]
+        self._ln(base, 0, D)                                                               # norm1 / norm1_context
+        self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2)
+        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+        gate = {s: base[s] + 2 * D for s in base}
+        self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
+        if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
+            lo = w.lora.get(p + ".out")
+            a = self.rows(Ya, "cond")
+            kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up) if lo is not None else {}
+            ops.gemm([ops.gemm_desc(a, w.t[p + ".out.w"], self.rows(self.X, "img"), bias=w.t[p + ".out.b"], epilogue=LX_EPI_RESID_F32,
+                                    rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)])
+        self._ln(base, 3 * D, 4 * D)                                                       # norm2 + (scale_mlp, shift_mlp)
+        self._gemm_streams(self.XN, Yf, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU)
+        gate = {s: base[s] + 5 * D for s in base}
+        self._gemm_streams(Yf, self.X, p + ".ff2", p + ".ff2_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
+
+    def single_block(self, j: int) -> None:
+        cfg, w = self.cfg, self.w
+        D = cfg.inner_dim
+        b = cfg.mod_base_single(j)
+        base = {"img": b, "cond": b, "txt": b}
+        p = f"s{j}"
+        self._ln(base, 0, D)
+        self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
+                           lora_mod_cols=D, lora_toff_max=3)
+        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
+        gate = {s: b + 2 * D for s in base}
+        self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate)
+
+    # ------------------------------------------------------------------------------------------ one step
+    def embed_step_inputs(self, latents: torch.Tensor, timestep: torch.Tensor) -> None:
+        """x_embedder(latents), reset text/condition rows, temb(t) and every image/text modulation vector."""
+        w, cfg = self.w, self.cfg
+        ops.convert(self.lat16, latents.reshape(self.B * self.N, -1).contiguous())
+        lo = w.lora.get("x_embedder") if self.latent_lora else None
+        tl = None
+        if lo is not None:
+            tl = self.TL[: self.B * self.N, : cfg.lora_r]
+            ops.lora_down(self.lat16, lo.down, tl)
+        ops.gemm([ops.gemm_desc(self.lat16, w.t["x_embedder.w"], self.rows(self.X, "img"), bias=w.t["x_embedder.b"],
+                                epilogue=LX_EPI_STORE_F32, lora_t=tl, lora_up=lo.up if lo is not None else None)])
+        self.rows(self.X, "txt").copy_(self.X_txt_init)
+        if self.C:
+            self.rows(self.X, "cond").copy_(self.X_cond_init)
+        torch.mul(timestep.to(device=self.device, dtype=torch.float32), 1000.0, out=self.t1000)
+        self._time_text_embed(self.t1000, self.temb, self.temb_base)
+        self._compute_mods(self.temb, self.mods, lora=self.latent_lora)
+
+    def final_layer(self) -> torch.Tensor:
+        """norm_out (AdaLayerNormContinuous: chunk order scale, shift) + proj_out on the image rows."""
+        cfg, w = self.cfg, self.w
+        D, o = cfg.inner_dim, cfg.mod_base_out
+        ops.ln_modulate(self.rows(self.X, "img"), self.mods[:, o + D:], self.mods[:, o:], self.rows(self.XN, "img"),
+                        rows_per_batch=self.N, mod_ld=self.mods.stride(0))
+        ops.gemm([ops.gemm_desc(self.rows(self.XN, "img"), w.t["proj_out.w"], self.out, bias=w.t["proj_out.b"],
+                                epilogue=LX_EPI_STORE_F32)])
+        return self.out.view(self.B, self.N, cfg.in_channels)
+
+    def forward(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """latents fp32 [B,N,in_channels], timestep [B] in 0..1 -> velocity fp32 [B,N,in_channels] (engine-owned buffer)."""
+        if not self.cond_ready:
+            raise RuntimeError("call set_conditioning() before forward()")
+        self.embed_step_inputs(latents, timestep)
+        for i in range(self.cfg.num_layers):
+            self.double_block(i)
+        for j in range(self.cfg.num_single_layers):
+            self.single_block(j)
+        return self.final_layer()

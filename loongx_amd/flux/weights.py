@@ -1,0 +1,229 @@
+"""Weight packing for the MI355X DiT engine.
+
+Maps a diffusers-style `FluxTransformer2DModel` state_dict (optionally PEFT-LoRA wrapped: `<mod>.base_layer.weight`,
+`<mod>.lora_A.<adapter>.weight`, `<mod>.lora_B.<adapter>.weight`; the checkpoint format the reference loads at
+inference.py:46-53 / model.py:464-477) to the fused device layout the HIP kernels consume, or draws synthetic
+weights of the same layout directly on the GPU (N(0, 0.02^2), zero bias, unit norms).
+
+Fused layout (D = heads*128, r = LoRA rank; all GEMM weights bf16 [out, in], biases / norm weights / LoRA-up fp32):
+  double block : qkv   [3D, D] rows = [to_k; to_v; to_q]     qkv_txt [3D, D] = [add_k; add_v; add_q]
+                 out   [D, D]  (to_out.0)                     out_txt [D, D]  (to_add_out)
+                 ff1   [4D, D] (ff.net.0.proj)                ff1_txt          (ff_context.net.0.proj)
+                 ff2   [D, 4D] (ff.net.2)                     ff2_txt          (ff_context.net.2)
+  single block : fused [7D, D] rows = [to_k; to_v; to_q; proj_mlp]      out [D, 5D] (proj_out, input = [attn | mlp])
+  The [k | v | q] column order lets the attention output overwrite the q slot so that [attn | mlp] is one
+  contiguous K=5D operand for proj_out (no torch.cat copy, block.py:326).
+  modulation   : every AdaLN linear of the model stacked into ONE [n_mod, D] matrix (one weight-streaming launch
+                 per step): per double block [norm1 (6D); norm1_context (6D)], per single block [norm (3D)],
+                 then norm_out (2D: scale, shift).
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class FluxConfig:
+    num_layers: int = 19
+    num_single_layers: int = 38
+    num_attention_heads: int = 24
+    attention_head_dim: int = 128
+    in_channels: int = 64
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = True
+    axes_dims_rope: tuple = (16, 56, 56)
+    lora_r: int = 4
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+    @property
+    def n_mod(self) -> int:
+        return (12 * self.num_layers + 3 * self.num_single_layers + 2) * self.inner_dim
+
+    def mod_base_double(self, i: int) -> int:
+        return 12 * self.inner_dim * i
+
+    def mod_base_single(self, j: int) -> int:
+        return (12 * self.num_layers + 3 * j) * self.inner_dim
+
+    @property
+    def mod_base_out(self) -> int:
+        return (12 * self.num_layers + 3 * self.num_single_layers) * self.inner_dim
+
+
+class Lora:
+    """A_down [n_mod*r, K] bf16 (rows stacked per fused module), B_up [N, r] fp32 (already times alpha/r)."""
+    __slots__ = ("down", "up")
+
+    def __init__(self, down: torch.Tensor, up: torch.Tensor):
+        self.down, self.up = down, up
+
+
+@dataclass
+class PackedWeights:
+    cfg: FluxConfig
+    t: Dict[str, torch.Tensor] = field(default_factory=dict)     # name -> tensor
+    lora: Dict[str, Lora] = field(default_factory=dict)          # name -> Lora (absent => no adapter)
+
+    def nbytes(self) -> int:
+        n = sum(v.numel() * v.element_size() for v in self.t.values())
+        n += sum(l.down.numel() * 2 + l.up.numel() * 4 for l in self.lora.values())
+        return n
+
+
+# --------------------------------------------------------------------------------------------------------------
+def _sd_get(sd, name: str, what: str) -> Optional[torch.Tensor]:
+    for k in (f"{name}.{what}", f"{name}.base_layer.{what}"):
+        if k in sd:
+            return sd[k]
+    return None
+
+
+def _sd_lora(sd, name: str):
+    a = b = None
+    pa, pb = re.compile(re.escape(name) + r"\.lora_A\.[^.]+\.weight$"), re.compile(re.escape(name) + r"\.lora_B\.[^.]+\.weight$")
+    for k in sd:
+        if pa.match(k):
+            a = sd[k]
+        elif pb.match(k):
+            b = sd[k]
+    return (a, b) if a is not None and b is not None else None
+
+
+def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_scale: float = 1.0,
+                    prefix: str = "") -> PackedWeights:
+    """sd: diffusers FluxTransformer2DModel names (optionally under `prefix`, e.g. 'transformer.')."""
+    if prefix:
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    pw = PackedWeights(cfg)
+    D = cfg.inner_dim
+
+    def W(names: List[str]) -> torch.Tensor:
+        ws = []
+        for n in names:
+            w = _sd_get(sd, n, "weight")
+            if w is None:
+                raise KeyError(f"missing weight for '{n}' in state_dict")
+            ws.append(w.float())
+        return torch.cat(ws, 0).to(device=device, dtype=torch.bfloat16).contiguous()
+
+    def Bv(names: List[str], sizes: List[int]) -> torch.Tensor:
+        bs = []
+        for n, s in zip(names, sizes):
+            b = _sd_get(sd, n, "bias")
+            bs.append(b.float() if b is not None else torch.zeros(s))
+        return torch.cat(bs, 0).to(device=device, dtype=torch.float32).contiguous()
+
+    def Lr(names: List[str]) -> Optional[Lora]:
+        parts = [_sd_lora(sd, n) for n in names]
+        if all(p is None for p in parts):
+            return None
+        if any(p is None for p in parts):
+            raise ValueError(f"LoRA adapters must cover all of {names} or none")
+        down = torch.cat([p[0].float() for p in parts], 0).to(device=device, dtype=torch.bfloat16).contiguous()
+        up = torch.cat([p[1].float() * lora_scale for p in parts], 0).to(device=device, dtype=torch.float32).contiguous()
+        return Lora(down, up)
+
+    def put(name, w_names, out_sizes):
+        pw.t[name + ".w"] = W(w_names)
+        pw.t[name + ".b"] = Bv(w_names, out_sizes)
+        l = Lr(w_names)
+        if l is not None:
+            pw.lora[name] = l
+
+    def vec(name, key):
+        pw.t[name] = sd[key].float().to(device).contiguous()
+
+    mod_w, mod_b, mod_lora = [], [], []
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        put(f"d{i}.qkv", [p + "attn.to_k", p + "attn.to_v", p + "attn.to_q"], [D] * 3)
+        put(f"d{i}.qkv_txt", [p + "attn.add_k_proj", p + "attn.add_v_proj", p + "attn.add_q_proj"], [D] * 3)
+        put(f"d{i}.out", [p + "attn.to_out.0"], [D])
+        put(f"d{i}.out_txt", [p + "attn.to_add_out"], [D])
+        put(f"d{i}.ff1", [p + "ff.net.0.proj"], [4 * D])
+        put(f"d{i}.ff1_txt", [p + "ff_context.net.0.proj"], [4 * D])
+        put(f"d{i}.ff2", [p + "ff.net.2"], [D])
+        put(f"d{i}.ff2_txt", [p + "ff_context.net.2"], [D])
+        vec(f"d{i}.wq", p + "attn.norm_q.weight"); vec(f"d{i}.wk", p + "attn.norm_k.weight")
+        vec(f"d{i}.wq_txt", p + "attn.norm_added_q.weight"); vec(f"d{i}.wk_txt", p + "attn.norm_added_k.weight")
+        for n, sz in ((p + "norm1.linear", 6 * D), (p + "norm1_context.linear", 6 * D)):
+            mod_w.append(_sd_get(sd, n, "weight").float()); mod_b.append(_sd_get(sd, n, "bias").float())
+        mod_lora.append(_sd_lora(sd, p + "norm1.linear"))
+    for j in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{j}."
+        put(f"s{j}.fused", [p + "attn.to_k", p + "attn.to_v", p + "attn.to_q", p + "proj_mlp"], [D, D, D, 4 * D])
+        put(f"s{j}.out", [p + "proj_out"], [D])
+        vec(f"s{j}.wq", p + "attn.norm_q.weight"); vec(f"s{j}.wk", p + "attn.norm_k.weight")
+        mod_w.append(_sd_get(sd, p + "norm.linear", "weight").float()); mod_b.append(_sd_get(sd, p + "norm.linear", "bias").float())
+        mod_lora.append(_sd_lora(sd, p + "norm.linear"))
+    mod_w.append(sd["norm_out.linear.weight"].float()); mod_b.append(sd["norm_out.linear.bias"].float())
+    pw.t["mod.w"] = torch.cat(mod_w, 0).to(device=device, dtype=torch.bfloat16).contiguous()
+    pw.t["mod.b"] = torch.cat(mod_b, 0).to(device=device, dtype=torch.float32).contiguous()
+    if any(m is not None for m in mod_lora):
+        if any(m is None for m in mod_lora):
+            raise ValueError("LoRA must cover every norm1.linear / norm.linear or none")
+        pw.t["mod.lora_down"] = torch.cat([m[0].float() for m in mod_lora], 0).to(device=device, dtype=torch.bfloat16).contiguous()
+        for idx, m in enumerate(mod_lora):
+            pw.t[f"mod.lora_up.{idx}"] = (m[1].float() * lora_scale).to(device).contiguous()
+    put("x_embedder", ["x_embedder"], [D])
+    put("context_embedder", ["context_embedder"], [D])
+    put("proj_out", ["proj_out"], [cfg.in_channels])
+    emb = ["timestep_embedder", "text_embedder"] + (["guidance_embedder"] if cfg.guidance_embeds else [])
+    for e in emb:
+        for l in ("linear_1", "linear_2"):
+            put(f"tte.{e}.{l}", [f"time_text_embed.{e}.{l}"], [D])
+    return pw
+
+
+def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True) -> PackedWeights:
+    """Random weights of the fused layout generated on the GPU (full FLUX.1-dev scale = 23.8 GB bf16)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    pw = PackedWeights(cfg)
+    D, r = cfg.inner_dim, cfg.lora_r
+
+    def rn(*shape, dtype=torch.bfloat16, s=std):
+        out = torch.empty(*shape, dtype=dtype, device=device)
+        out.normal_(0.0, s, generator=g)
+        return out
+
+    def put(name, n_out, n_in, n_lora_mod=0):
+        pw.t[name + ".w"] = rn(n_out, n_in)
+        pw.t[name + ".b"] = torch.zeros(n_out, dtype=torch.float32, device=device)
+        if lora and n_lora_mod:
+            pw.lora[name] = Lora(rn(n_lora_mod * r, n_in), rn(n_out, r, dtype=torch.float32))
+
+    for i in range(cfg.num_layers):
+        put(f"d{i}.qkv", 3 * D, D, 3); put(f"d{i}.qkv_txt", 3 * D, D)
+        put(f"d{i}.out", D, D, 1); put(f"d{i}.out_txt", D, D)
+        put(f"d{i}.ff1", 4 * D, D); put(f"d{i}.ff1_txt", 4 * D, D)
+        put(f"d{i}.ff2", D, 4 * D, 1); put(f"d{i}.ff2_txt", D, 4 * D)
+        for n in ("wq", "wk", "wq_txt", "wk_txt"):
+            pw.t[f"d{i}.{n}"] = torch.ones(128, dtype=torch.float32, device=device)
+    for j in range(cfg.num_single_layers):
+        put(f"s{j}.fused", 7 * D, D, 4); put(f"s{j}.out", D, 5 * D, 1)
+        pw.t[f"s{j}.wq"] = torch.ones(128, dtype=torch.float32, device=device)
+        pw.t[f"s{j}.wk"] = torch.ones(128, dtype=torch.float32, device=device)
+    pw.t["mod.w"] = rn(cfg.n_mod, D)
+    pw.t["mod.b"] = torch.zeros(cfg.n_mod, dtype=torch.float32, device=device)
+    if lora:
+        nb = cfg.num_layers + cfg.num_single_layers
+        pw.t["mod.lora_down"] = rn(nb * r, D)
+        for idx in range(nb):
+            pw.t[f"mod.lora_up.{idx}"] = rn(6 * D if idx < cfg.num_layers else 3 * D, r, dtype=torch.float32)
+    put("x_embedder", D, cfg.in_channels, 1)
+    put("context_embedder", D, cfg.joint_attention_dim)
+    put("proj_out", cfg.in_channels, D)
+    emb = [("timestep_embedder", 256), ("text_embedder", cfg.pooled_projection_dim)]
+    if cfg.guidance_embeds:
+        emb.append(("guidance_embedder", 256))
+    for e, k in emb:
+        put(f"tte.{e}.linear_1", D, k); put(f"tte.{e}.linear_2", D, D)
+    return pw

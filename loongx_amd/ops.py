@@ -78,6 +78,17 @@ def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> None:
     check(lib.lx_timestep_embed(t.data_ptr(), out.data_ptr(), out.shape[0], out.shape[1], _stream()), "lx_timestep_embed")
 
 
+def rope_table(ids: torch.Tensor, axes=(16, 56, 56), theta: float = 10000.0):
+    """ids fp32 [L,3] on the GPU -> (cos, sin) fp32 [L, sum(axes)]."""
+    _req(ids, torch.float32, "ids")
+    ids = ids.contiguous()
+    Lq, tot = ids.shape[0], sum(axes)
+    cos = torch.empty(Lq, tot, dtype=torch.float32, device=ids.device)
+    sin = torch.empty_like(cos)
+    check(lib.lx_rope_table(ids.data_ptr(), Lq, axes[0], axes[1], axes[2], float(theta), cos.data_ptr(), sin.data_ptr(), _stream()), "lx_rope_table")
+    return cos, sin
+
+
 def ln_modulate(X, shift, scale, Y, rows_per_batch, eps=1e-6, mod_ld=None) -> None:
     _req(X, torch.float32, "X"); _req(Y, torch.bfloat16, "Y"); _req(shift, torch.float32, "shift"); _req(scale, torch.float32, "scale")
     check(lib.lx_ln_modulate(X.data_ptr(), X.stride(0), shift.data_ptr(), scale.data_ptr(),
