@@ -57,7 +57,7 @@ class DiTEngine:
         self.X = torch.zeros(M, D, dtype=f32, device=dev)
         self.XN = torch.zeros(M, D, dtype=bf16, device=dev)
         self.Y = torch.zeros(M, 7 * D, dtype=bf16, device=dev)
-        self.vt0 = [0, _pad64(T), _pad64(T) + _pad64(N)]
+        self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.TL = torch.zeros(M, 16, dtype=f32, device=dev)
         self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
@@ -72,7 +72,7 @@ class DiTEngine:
         self.cmods = torch.zeros(B, cfg.n_mod, dtype=f32, device=dev)
         nb = cfg.num_layers + cfg.num_single_layers
         self.tmod = torch.zeros(B, max(nb * cfg.lora_r, 4), dtype=f32, device=dev)
-        self.X_txt_init = torch.zeros(B * T, D, dtype=f32, device=dev)
+        self.X_txt_init = torch.zeros(max(B * T, 1), D, dtype=f32, device=dev)
         self.X_cond_init = torch.zeros(max(B * C, 1), D, dtype=f32, device=dev)
         self.shape = (B, T, N, C)
         self.cond_ready = False
@@ -86,10 +86,7 @@ class DiTEngine:
         return buf[self.r_cond:self.M]
 
     def _streams(self):
-        s = [("txt", self.T), ("img", self.N)]
-        if self.C:
-            s.append(("cond", self.C))
-        return s
+        return [(n, l) for n, l in (("txt", self.T), ("img", self.N), ("cond", self.C)) if l > 0]
 
     # ------------------------------------------------------------------------------------------ helpers
     def _lin_skinny(self, x, name, out, act_in=0, act_out=0, accumulate=False):
@@ -120,23 +117,24 @@ class DiTEngine:
                 ops.linear_f32(tm[:, idx * r:], w.t[f"mod.lora_up.{idx}"], None, out[:, base:], M=self.B, N=width, K=r,
                                ldx=tm.stride(0), ldy=out.stride(0), accumulate=True)
 
-    def _attn_bias(self) -> List[List[float]]:
-        """block.py:106-128 as a (query segment, key segment) table over [text, image, cond]."""
-        b = [[0.0] * 3 for _ in range(3)]
+    def _attn_bias(self) -> Dict[str, Dict[str, float]]:
+        """block.py:106-128 as a (query stream, key stream) table: 0, log(c_factor) or -inf."""
+        names = ("txt", "img", "cond")
+        b = {q: {k: 0.0 for k in names} for q in names}
         mc = self.model_config
         if self.C:
             if not mc.get("union_cond_attn", True):
-                for i in (0, 1):
-                    b[i][2] = NEG_INF
-                    b[2][i] = NEG_INF
+                for o in ("txt", "img"):
+                    b[o]["cond"] = NEG_INF
+                    b["cond"][o] = NEG_INF
             elif mc.get("independent_condition", False):
-                b[2][0] = b[2][1] = NEG_INF
-            if self.c_factor is not None:
+                b["cond"]["txt"] = b["cond"]["img"] = NEG_INF
+            if self.c_factor is not None:            # evaluated last in the reference: replaces any boolean mask
                 lb = math.log(self.c_factor)
-                b = [[0.0] * 3 for _ in range(3)]
-                for i in (0, 1):
-                    b[i][2] = lb
-                    b[2][i] = lb
+                b = {q: {k: 0.0 for k in names} for q in names}
+                for o in ("txt", "img"):
+                    b[o]["cond"] = lb
+                    b["cond"][o] = lb
         return b
 
     # --------------------------------------------------------------------------------- step-invariant part
@@ -248,19 +246,26 @@ class DiTEngine:
         Y = self.Y
         seg_row0, seg_len, seg_vt0 = [], [], []
         off = 0
-        for idx, (s, L) in enumerate(self._streams()):
+        streams = self._streams()
+        bias = [[0.0] * 3 for _ in range(3)]
+        for qi, (qs, _) in enumerate(streams):
+            for ki, (ks, _) in enumerate(streams):
+                bias[qi][ki] = self.attn_bias[qs][ks]
+        for s, L in streams:
             row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
             if s == "cond":
                 cos, sin = self.cos_cond, self.sin_cond
+            elif self.cos_main is None:
+                cos = sin = None
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
             ops.qkv_prep(Y, q_col=2 * D, k_col=0, v_col=D, row0=row0, n_rows=B * L, rows_per_batch=L, H=H,
                          wq=wq_txt if s == "txt" else wq, wk=wk_txt if s == "txt" else wk, cos=cos, sin=sin,
-                         VT=self.VT, vt_pos0=self.vt0[idx])
-            seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[idx])
+                         VT=self.VT, vt_pos0=self.vt0[s])
+            seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
-                     seg_vt0=seg_vt0, bias=self.attn_bias)
+                     seg_vt0=seg_vt0, bias=bias)
 
     # ------------------------------------------------------------------------------------------ blocks
     def double_block(self, i: int) -> None:
@@ -338,3 +343,70 @@ class DiTEngine:
         for j in range(self.cfg.num_single_layers):
             self.single_block(j)
         return self.final_layer()
+
+    # ------------------------------------------------------------------------------------------ block-level entry points
+    # (used by the reference-API mirrors in block.py: same arithmetic as forward(), driven one block at a time)
+    def load_streams(self, enc: Optional[torch.Tensor], hid: torch.Tensor, cond: Optional[torch.Tensor], dst: str = "X") -> None:
+        """Copy [B,L,D] per-stream tensors into the stream-major rows of X (fp32) or XN (bf16)."""
+        buf = self.X if dst == "X" else self.XN
+        for s, t in (("txt", enc), ("img", hid), ("cond", cond)):
+            if t is not None:
+                self.rows(buf, s).copy_(t.reshape(-1, t.shape[-1]))
+
+    def read_stream(self, s: str, L: int, src: str = "X", cols: Optional[slice] = None) -> torch.Tensor:
+        buf = {"X": self.X, "XN": self.XN, "Y": self.Y}[src]
+        r = self.rows(buf, s)
+        if cols is not None:
+            r = r[:, cols]
+        return r.float().reshape(self.B, L, -1).clone()
+
+    def block_mods(self, kind: str, idx: int, temb: torch.Tensor, cond_temb: Optional[torch.Tensor]) -> None:
+        """Modulation vectors of ONE block from explicit temb / cond_temb (block.py:191-207, 301-305)."""
+        cfg, w, D, r = self.cfg, self.w, self.cfg.inner_dim, self.cfg.lora_r
+        base, width, lw = (cfg.mod_base_double(idx), 12 * D, 6 * D) if kind == "double" else (cfg.mod_base_single(idx), 3 * D, 3 * D)
+        li = idx if kind == "double" else cfg.num_layers + idx
+        for vec, out, lora in ((temb, self.mods, self.latent_lora), (cond_temb, self.cmods, True)):
+            if vec is None:
+                continue
+            vec = vec.to(device=self.device, dtype=torch.float32).contiguous()
+            ops.linear_skinny(vec, w.t["mod.w"][base:base + width], w.t["mod.b"][base:base + width], out[:, base:], act_in=1)
+            if lora and "mod.lora_down" in w.t:
+                tm = self.tmod[:, :r]
+                ops.linear_skinny(vec, w.t["mod.lora_down"][li * r:(li + 1) * r], None, tm, act_in=1)
+                ops.linear_f32(tm, w.t[f"mod.lora_up.{li}"], None, out[:, base:], M=self.B, N=lw, K=r, ldx=tm.stride(0),
+                               ldy=out.stride(0), accumulate=True)
+
+    def configure(self, B, T, N, C, model_config=None, c_factor=None, rope_main=None, rope_cond=None) -> None:
+        """Shape + config + RoPE tables without the prompt/condition embedders (block-level use)."""
+        self.setup(B, T, N, C)
+        self.model_config = dict(model_config or {})
+        self.c_factor = c_factor
+        self.latent_lora = bool(self.model_config.get("latent_lora", False))
+        self.attn_bias = self._attn_bias()
+        f32 = torch.float32
+        if rope_main is not None:
+            self.cos_main, self.sin_main = (t.to(self.device, f32).contiguous() for t in rope_main)
+        else:
+            self.cos_main = self.sin_main = None
+        if rope_cond is not None:
+            self.cos_cond, self.sin_cond = (t.to(self.device, f32).contiguous() for t in rope_cond)
+        else:
+            self.cos_cond = self.sin_cond = None
+        self.cond_ready = True
+
+    def attention_module(self, kind: str, idx: int, project_out: bool) -> None:
+        """attn_forward (block.py:7-176) on the normalised activations already in XN: QKV projections, QK-RMSNorm,
+        RoPE, joint attention; double blocks also apply to_out / to_add_out into X (plain store)."""
+        cfg, w, D = self.cfg, self.w, self.cfg.inner_dim
+        if kind == "double":
+            p = f"d{idx}"
+            self._gemm_streams(self.XN, self.Y[:, : 3 * D], p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16,
+                               lora_mod_cols=D, lora_toff_max=2)
+            self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+            if project_out:
+                self._gemm_streams(self.Y[:, 2 * D: 3 * D], self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_STORE_F32)
+        else:
+            p = f"s{idx}"
+            self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
+                               lora_mod_cols=D, lora_toff_max=3)
+            self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])

@@ -1,0 +1,176 @@
+"""`LxFluxPipeline`: the slice of diffusers' FluxPipeline that the reference's generate() touches
+(src/flux/generate.py:72-394), for MI355X.  Restated from diffusers==0.31.0 (train/requirements.txt:1): latent packing,
+latent image ids, calculate_shift, FlowMatchEulerDiscreteScheduler.  The Euler update runs in HIP (lx_euler_step).
+
+Text encoders (T5/CLIP) and the VAE are outside the denoise hot path ("next"): pass `prompt_embeds`,
+`pooled_prompt_embeds` and `output_type="latent"`, or plug callables in via `text_encoder=` / `vae=`.
+"""
+from __future__ import annotations
+
+import math
+from contextlib import contextmanager
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class FluxPipelineOutput(SimpleNamespace):
+    pass
+
+
+def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5,
+                    max_shift: float = 1.16):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    return image_seq_len * m + (base_shift - m * base_seq_len)
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """FLUX.1-dev scheduler config; sigma schedule on the host in fp64 -> fp32 like diffusers, step on the GPU."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                 base_image_seq_len=256, max_image_seq_len=4096):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=use_dynamic_shifting,
+                                      base_shift=base_shift, max_shift=max_shift, base_image_seq_len=base_image_seq_len,
+                                      max_image_seq_len=max_image_seq_len)
+        self.timesteps = self.sigmas = None
+        self._step_index = None
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        if sigmas is None:
+            sigmas = np.linspace(self.config.num_train_timesteps, 1, num_inference_steps) / self.config.num_train_timesteps
+        sigmas = np.asarray(sigmas, dtype=np.float64)
+        if self.config.use_dynamic_shifting:
+            if mu is None:
+                raise ValueError("use_dynamic_shifting=True needs mu")
+            sigmas = math.exp(mu) / (math.exp(mu) + (1.0 / sigmas - 1.0))
+        else:
+            s = self.config.shift
+            sigmas = s * sigmas / (1 + (s - 1) * sigmas)
+        sig = sigmas.astype(np.float32)
+        self._sig_host = np.concatenate([sig, np.zeros(1, np.float32)])
+        self.timesteps = torch.from_numpy(sig * np.float32(self.config.num_train_timesteps)).to(device)
+        self.sigmas = torch.from_numpy(self._sig_host).to(device)
+        self._step_index = 0
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = False):
+        """prev = sample(fp32) + (sigma_next - sigma) * model_output, cast to model_output.dtype (diffusers semantics)."""
+        i = self._step_index
+        ds = float(np.float32(self._sig_host[i + 1]) - np.float32(self._sig_host[i]))
+        x = sample.to(torch.float32).clone() if (sample.dtype != torch.float32 or not sample.is_contiguous()) else sample.clone()
+        v = model_output if model_output.dtype in (torch.float32, torch.bfloat16) else model_output.float()
+        ops.euler_step(x, v.contiguous(), ds)
+        self._step_index += 1
+        return (x.to(model_output.dtype),)
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
+    if timesteps is not None:
+        raise ValueError("custom `timesteps` are not supported by the flow-match scheduler")
+    scheduler.set_timesteps(num_inference_steps, device=device, sigmas=sigmas, **kwargs)
+    return scheduler.timesteps, len(scheduler.timesteps)
+
+
+class LxFluxPipeline:
+    vae_scale_factor = 16
+    default_sample_size = 64
+
+    def __init__(self, transformer, scheduler=None, vae=None, text_encoder=None, image_processor=None):
+        self.transformer = transformer
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+        self.vae, self.text_encoder, self.image_processor = vae, text_encoder, image_processor
+        self.device = transformer.device
+        self.dtype = torch.float32
+        self._guidance_scale, self._joint_attention_kwargs, self._interrupt, self._num_timesteps = 3.5, None, False, 0
+
+    # ---- properties generate() reads ------------------------------------------------------------
+    @property
+    def _execution_device(self):
+        return self.device
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    @property
+    def joint_attention_kwargs(self):
+        return self._joint_attention_kwargs
+
+    def to(self, *a, **k):
+        return self
+
+    def set_adapters(self, *a, **k):
+        """Adapters are baked into the packed weights (one LoRA per checkpoint, inference.py:114 default_lora=True)."""
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    @contextmanager
+    def progress_bar(self, total=None):
+        yield SimpleNamespace(update=lambda *a, **k: None)
+
+    # ---- input handling ---------------------------------------------------------------------------
+    def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
+                     callback_on_step_end_tensor_inputs=None, max_sequence_length=None):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed.")
+        if max_sequence_length is not None and max_sequence_length > 512:
+            raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+
+    def encode_prompt(self, prompt=None, prompt_2=None, prompt_embeds=None, pooled_prompt_embeds=None, device=None,
+                      num_images_per_prompt: int = 1, max_sequence_length: int = 512, lora_scale=None):
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise NotImplementedError("T5/CLIP text encoding is outside the MI355X hot path: pass prompt_embeds / "
+                                          "pooled_prompt_embeds, or construct LxFluxPipeline(text_encoder=callable)")
+            prompt_embeds, pooled_prompt_embeds = self.text_encoder(prompt, prompt_2, max_sequence_length)
+        if num_images_per_prompt != 1:
+            prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+            pooled_prompt_embeds = pooled_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device or self.device, dtype=torch.float32)
+        return prompt_embeds.to(device or self.device), pooled_prompt_embeds.to(device or self.device), text_ids
+
+    # ---- latents -----------------------------------------------------------------------------------
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        x = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2).permute(0, 2, 4, 1, 3, 5)
+        return x.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        b, n, ch = latents.shape
+        h, w = height // vae_scale_factor, width // vae_scale_factor
+        x = latents.view(b, h, w, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+        return x.reshape(b, ch // 4, h * 2, w * 2)
+
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        """diffusers 0.31: `height`/`width` are the UNPACKED latent sizes; ids live on the (h/2, w/2) grid."""
+        h2, w2 = height // 2, width // 2
+        ids = torch.zeros(h2, w2, 3)
+        ids[..., 1] += torch.arange(h2)[:, None]
+        ids[..., 2] += torch.arange(w2)[None, :]
+        return ids.reshape(h2 * w2, 3).to(device=device, dtype=dtype)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        height = 2 * (int(height) // self.vae_scale_factor)
+        width = 2 * (int(width) // self.vae_scale_factor)
+        ids = self._prepare_latent_image_ids(batch_size, height, width, device, torch.float32)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), ids
+        shape = (batch_size, num_channels_latents, height, width)
+        gdev = generator.device if isinstance(generator, torch.Generator) else device
+        noise = torch.randn(shape, generator=generator if isinstance(generator, torch.Generator) else None, device=gdev, dtype=dtype)
+        return self._pack_latents(noise.to(device), batch_size, num_channels_latents, height, width), ids

@@ -320,3 +320,42 @@ def synthetic_cs3_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
             sd[f"{name}.{sub}.weight"] = t(rng.standard_normal((o, i, 1)) / np.sqrt(i))
             sd[f"{name}.{sub}.bias"] = t(rng.standard_normal(o) * 0.01)
     return sd
+
+
+class OminiModel(CS3DGF):
+    """Inference surface of the reference's `OminiModel` (model.py:376-511, 731-779) that `generate()` and
+    `inference.py` consume: `.flux_pipe`, `.transformer`, `.model_config`, `.device`, the four `*_projection` encoders,
+    `fuse_eeg` / `fuse_fnirs`, the DUAN instances and `spatial_pyramid_pooling`.  Training (LoRA init, optimizers,
+    `training_step`) is out of scope.  Weights come from a Lightning-style full state_dict (inference.py:46-53:
+    `transformer.*` + the brain-side modules) or are synthetic."""
+
+    def __init__(self, flux_pipe, cs3_state_dict: Dict[str, torch.Tensor], model_config: Optional[dict] = None, device="cuda",
+                 use_brain_condition: bool = True, fuse_flag: bool = True):
+        super().__init__(cs3_state_dict, device)
+        self.flux_pipe = flux_pipe
+        self.transformer = flux_pipe.transformer
+        self.model_config = dict(model_config or {})
+        self.use_brain_condition, self.fuse_flag = use_brain_condition, fuse_flag
+
+    @classmethod
+    def from_state_dict(cls, state_dict: Dict[str, torch.Tensor], flux_config=None, model_config=None, device="cuda",
+                        lora_scale: float = 1.0):
+        """state_dict in the reference's checkpoint naming: `transformer.<diffusers names>` + `eeg_projection.*` ... """
+        from ..flux.pipeline import LxFluxPipeline
+        from ..flux.transformer import LxFluxTransformer
+        from ..flux.weights import FluxConfig
+        tr = LxFluxTransformer.from_state_dict(state_dict, flux_config or FluxConfig(), device, lora_scale, prefix="transformer.")
+        return cls(LxFluxPipeline(tr), state_dict, model_config, device)
+
+    @classmethod
+    def synthetic(cls, flux_config=None, model_config=None, device="cuda", seed: int = 0):
+        from ..flux.pipeline import LxFluxPipeline
+        from ..flux.transformer import LxFluxTransformer
+        tr = LxFluxTransformer.synthetic(flux_config, device, seed)
+        return cls(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self

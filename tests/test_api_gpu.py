@@ -1,0 +1,200 @@
+"""The reference-API mirrors (loongx_amd.flux.block / transformer / generate) on the GPU vs the reference-generated
+goldens and the CPU oracle: these tests read like the reference's call sites."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cs3 as ocs3  # noqa: E402
+from oracle import flux_modules as fm  # noqa: E402
+from oracle import flux_ref as fr  # noqa: E402
+from tests.helpers import load, relerr, tiny_transformer  # noqa: E402
+
+TOL_BLOCK = 1.2e-2    # one block, bf16 GEMM operands vs fp32
+TOL_FWD = 2.5e-2
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return load("flux_tiny.npz")
+
+
+@pytest.fixture(scope="module")
+def lx(G):
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
+    tr = tiny_transformer()
+    c = tr.config
+    cfg = FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, in_channels=64, joint_attention_dim=64,
+                     pooled_projection_dim=32, guidance_embeds=True)
+    return tr, LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, "cuda")
+
+
+def _ropes(tr, G):
+    return tr.pos_embed(torch.cat([G["in_txt_ids"], G["in_img_ids"]], 0)), tr.pos_embed(G["in_cond_ids"])
+
+
+def cu(t):
+    return t.cuda()
+
+
+MODES = {"default": ({}, None), "no_union": ({"union_cond_attn": False}, None), "independent": ({"independent_condition": True}, None),
+         "cfactor_half": ({}, 0.5), "cfactor_two": ({}, 2.0), "latent_lora": ({"latent_lora": True}, None)}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_attn_forward_mirror(G, lx, mode):
+    from loongx_amd.flux.block import attn_forward
+    tr, m = lx
+    mc, cf = MODES[mode]
+    main, cond = _ropes(tr, G)
+    d, s = m.transformer_blocks[0].attn, m.single_transformer_blocks[0].attn
+    s.text_len = 16
+    try:
+        if cf is not None:
+            d.c_factor = s.c_factor = torch.ones(1, 1) * cf
+        r = attn_forward(d, cu(G["hid"]), cu(G["enc"]), cu(G["cond"]), None, main, cond, mc)
+        for got, key in zip(r, ("hid", "enc", "cond")):
+            assert relerr(got.cpu(), G[f"attn_d_{mode}_{key}"]) < TOL_BLOCK, key
+        r = attn_forward(s, cu(torch.cat([G["enc"], G["hid"]], 1)), None, cu(G["cond"]), None, main, cond, mc)
+        for got, key in zip(r, ("hid", "cond")):
+            assert relerr(got.cpu(), G[f"attn_s_{mode}_{key}"]) < TOL_BLOCK, key
+    finally:
+        for a in (d, s):
+            if hasattr(a, "c_factor"):
+                del a.c_factor
+
+
+def test_attn_forward_mirror_nocond(G, lx):
+    from loongx_amd.flux.block import attn_forward
+    tr, m = lx
+    main, _ = _ropes(tr, G)
+    r = attn_forward(m.transformer_blocks[0].attn, cu(G["hid"]), cu(G["enc"]), None, None, main, None, {})
+    assert len(r) == 2 and relerr(r[0].cpu(), G["attn_d_nocond_hid"]) < TOL_BLOCK and relerr(r[1].cpu(), G["attn_d_nocond_enc"]) < TOL_BLOCK
+    s = m.single_transformer_blocks[0].attn
+    s.text_len = 16
+    r = attn_forward(s, cu(torch.cat([G["enc"], G["hid"]], 1)), None, None, None, main, None, {})
+    assert relerr(r.cpu(), G["attn_s_nocond_hid"]) < TOL_BLOCK
+    with pytest.raises(NotImplementedError):
+        attn_forward(s, cu(G["hid"]), None, None, torch.ones(1), main, None, {})
+
+
+@pytest.mark.parametrize("name,mc", [("default", {}), ("add_cond", {"add_cond_attn": True})])
+def test_block_forward_mirror(G, lx, name, mc):
+    from loongx_amd.flux.block import block_forward
+    tr, m = lx
+    main, cond = _ropes(tr, G)
+    e, h, c = block_forward(m.transformer_blocks[1], cu(G["hid"]), cu(G["enc"]), cu(G["cond"]), cu(G["temb"]), cu(G["ctemb"]), cond, main, mc)
+    assert relerr(e.cpu(), G[f"block_{name}_enc"]) < TOL_BLOCK
+    assert relerr(h.cpu(), G[f"block_{name}_hid"]) < TOL_BLOCK
+    assert relerr(c.cpu(), G[f"block_{name}_cond"]) < TOL_BLOCK
+
+
+def test_block_forward_mirror_nocond(G, lx):
+    from loongx_amd.flux.block import block_forward
+    tr, m = lx
+    main, _ = _ropes(tr, G)
+    e, h, c = block_forward(m.transformer_blocks[1], cu(G["hid"]), cu(G["enc"]), None, cu(G["temb"]), None, None, main, {})
+    assert c is None and relerr(e.cpu(), G["block_nocond_enc"]) < TOL_BLOCK and relerr(h.cpu(), G["block_nocond_hid"]) < TOL_BLOCK
+
+
+def test_single_block_forward_mirror(G, lx):
+    from loongx_amd.flux.block import single_block_forward
+    tr, m = lx
+    main, cond = _ropes(tr, G)
+    blk = m.single_transformer_blocks[1]
+    blk.text_len = 16
+    hs = cu(torch.cat([G["enc"], G["hid"]], 1))
+    h, c = single_block_forward(blk, hs, cu(G["temb"]), main, cu(G["cond"]), cu(G["ctemb"]), cond, {})
+    assert relerr(h.cpu(), G["single_hid"]) < TOL_BLOCK and relerr(c.cpu(), G["single_cond"]) < TOL_BLOCK
+    h2 = single_block_forward(blk, hs, cu(G["temb"]), main)
+    assert relerr(h2.cpu(), G["single_nocond_hid"]) < TOL_BLOCK
+
+
+def test_tranformer_forward_mirror(G, lx):
+    from loongx_amd.flux.transformer import tranformer_forward
+    tr, m = lx
+    kw = dict(hidden_states=cu(G["in_latents"]), encoder_hidden_states=cu(G["in_enc"]), pooled_projections=cu(G["in_pooled"]),
+              timestep=cu(G["in_timestep"]), img_ids=cu(G["in_img_ids"]), txt_ids=cu(G["in_txt_ids"]), guidance=cu(G["in_guidance"]))
+    out = tranformer_forward(m, cu(G["in_cond"]), cu(G["in_cond_ids"]), None, {}, return_dict=False, **kw)
+    assert isinstance(out, tuple) and relerr(out[0].cpu(), G["fwd_cond"]) < TOL_FWD
+    out = tranformer_forward(m, None, None, None, {}, **kw)
+    assert relerr(out.sample.cpu(), G["fwd_nocond"]) < TOL_FWD
+    with pytest.raises(NotImplementedError):
+        tranformer_forward(m, None, None, None, {}, controlnet_block_samples=[1], **kw)
+
+
+# ------------------------------------------------------------------------------------------ generate()
+def _mk_model(tr):
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
+    from loongx_amd.train.model import OminiModel
+    cfg = FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, in_channels=64, joint_attention_dim=4096,
+                     pooled_projection_dim=768, guidance_embeds=True)
+    torch.manual_seed(0)
+    ref_cs3 = ocs3.CS3DGF(seed=0).eval()
+    lxtr = LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, "cuda")
+    return ref_cs3, OminiModel(LxFluxPipeline(lxtr), ref_cs3.state_dict(), {}, "cuda")
+
+
+def test_generate_matches_oracle_loop():
+    """4-step 64x64 edit with EEG+PPG / fNIRS+Motion conditioning, latents in/out (no T5, no VAE)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    tr = fm.FluxTransformer2DModel(num_layers=2, num_single_layers=2, heads=2, head_dim=128, in_channels=64, joint_dim=4096,
+                                   pooled_dim=768, guidance_embeds=True, lora=True)
+    fm.init_synthetic_(tr, seed=4, std=0.03, bias_std=0.02, norm_jitter=0.1)
+    tr.eval()
+    ref_cs3, model = _mk_model(tr)
+    g = torch.Generator().manual_seed(3)
+    B, hw = 1, 4
+    lat = torch.randn(B, hw * hw, 64, generator=g)
+    cond = torch.randn(B, hw * hw, 64, generator=g)
+    pe, pooled = torch.randn(B, 512, 4096, generator=g) * 0.1, torch.randn(B, 768, generator=g)
+    eeg, ppg = torch.randn(4, 3000, generator=g), torch.randn(4, 256, generator=g)
+    fnirs, motion = torch.randn(6, 600, generator=g), torch.randn(6, 128, generator=g)
+    for fuse_flag, sig in ((False, dict(eeg=eeg)), (False, dict(eeg=eeg, ppg=ppg, fnirs=fnirs, motion=motion)),
+                           (True, dict(eeg=eeg, ppg=ppg, fnirs=fnirs, motion=motion)), (False, {})):
+        with torch.no_grad():
+            s = {k: v.unsqueeze(0) for k, v in sig.items()}
+            rpe, rpool = ref_cs3.brain_embeds(pe, pooled, s.get("eeg"), s.get("fnirs"), s.get("ppg"), s.get("motion"), fuse_flag=fuse_flag)
+            ids = fm.prepare_latent_image_ids(hw, hw)
+            cids = ids.clone()
+            cids[:, 2] -= hw
+            want = fr.denoise_loop(tr, fm.FlowMatchEulerDiscreteScheduler(), lat, rpe, rpool, torch.zeros(512, 3), ids, cond, cids,
+                                   num_inference_steps=4)
+        c = Condition("subject", latents=cond.cuda(), latent_hw=(hw, hw), position_delta=[0, -hw])
+        out = generate(model, model.flux_pipe, conditions=[c], height=hw * 16, width=hw * 16, num_inference_steps=4, latents=lat.cuda(),
+                       prompt_embeds=pe.cuda(), pooled_prompt_embeds=pooled.cuda(), output_type="latent", model_config={},
+                       default_lora=True, additional_condition1=sig.get("eeg"), additional_condition2=sig.get("fnirs"),
+                       additional_condition3=sig.get("ppg"), additional_condition4=sig.get("motion"),
+                       use_brain_condition=bool(sig), fuse_flag=fuse_flag)
+        assert relerr(out.images.cpu(), want) < 3e-2, (fuse_flag, list(sig))
+
+
+def test_scheduler_and_latent_utils_match_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from loongx_amd.flux.pipeline import FlowMatchEulerDiscreteScheduler, LxFluxPipeline, calculate_shift
+    a, b = FlowMatchEulerDiscreteScheduler(), fm.FlowMatchEulerDiscreteScheduler()
+    sig = np.linspace(1.0, 1 / 28, 28)
+    mu = calculate_shift(1024, 256, 4096, 0.5, 1.15)
+    assert mu == fm.calculate_shift(1024, 256, 4096, 0.5, 1.15)
+    a.set_timesteps(sigmas=sig, mu=mu, device="cuda"); b.set_timesteps(sigmas=sig, mu=mu)
+    assert torch.equal(a.timesteps.cpu(), b.timesteps) and torch.equal(a.sigmas.cpu(), b.sigmas)
+    x, v = torch.randn(2, 16, 64), torch.randn(2, 16, 64)
+    for i in range(3):
+        xa = a.step(v.cuda(), a.timesteps[i], x.cuda())[0].cpu()
+        xb = b.step(v, b.timesteps[i], x)[0]
+        assert torch.allclose(xa, xb, atol=1e-6)
+        x = xb
+    z = torch.randn(2, 16, 8, 8)
+    p = LxFluxPipeline._pack_latents(z, 2, 16, 8, 8)
+    assert torch.equal(p, fm.pack_latents(z)) and torch.equal(LxFluxPipeline._unpack_latents(p, 64, 64, 16), z)
+    assert torch.equal(LxFluxPipeline._prepare_latent_image_ids(1, 8, 8, "cpu", torch.float32), fm.prepare_latent_image_ids(4, 4))
