@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- edited images/s @512x512, 28-step Flux denoise (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: `generate()` = CS3 EEG encode (once per image,
+as in the reference) + 28 three-stream DiT forwards + Euler updates, packed latents in -> packed latents out
+(T5/VAE are outside the metric).  Workload = BASELINE.json configs[1]: EEG-only CS3 conditioning,
+512x512 edit (512 text + 1024 image + 1024 condition tokens), 28 steps, bf16 MFMA, batch 1 per GPU, full FLUX.1-dev
+shape (19 double + 38 single blocks, D=3072, 11.9 B params) with synthetic weights (no network for checkpoints).
+Multi-GPU: data parallel, one process per GPU, independent images per rank, no collective inside the loop; rank 0
+draws the weights and broadcasts them over RCCL/xGMI before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+D, T_TXT, STEPS = 3072, 512, 28
+
+
+def flops_per_image(n_img_tokens: int, n_cond_tokens: int, layers: int = 57) -> float:
+    """per block per sample 24*S*D^2 + 4*S^2*D (2*MAC), x57 blocks x28 steps."""
+    S = T_TXT + n_img_tokens + n_cond_tokens
+    return STEPS * layers * (24.0 * S * D * D + 4.0 * S * S * D)
+
+
+def cpu_baseline(threads: int):
+    """The oracle (torch-CPU fp32 restatement, oracle/flux_ref.py) timed on this box's host cores on a BOUNDED sample:
+    one double + one single block at full width (B=1, S=2560), extrapolated to 19/38 blocks x 28 steps."""
+    from oracle import flux_modules as fm
+    from oracle import flux_ref as fr
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    dbl = fm.FluxTransformerBlock(D, 24, 128, lora=True)
+    sgl = fm.FluxSingleTransformerBlock(D, 24, 128, lora=True)
+    fm.init_synthetic_(dbl, 0); fm.init_synthetic_(sgl, 1)
+    hid, enc, cond = (torch.randn(1, n, D, generator=g) for n in (1024, 512, 1024))
+    temb, ctemb = torch.randn(1, D, generator=g), torch.randn(1, D, generator=g)
+    ids = fm.prepare_latent_image_ids(32, 32)
+    cids = ids.clone(); cids[:, 2] -= 32
+    pe = fm.FluxPosEmbed()
+    main, rc = pe(torch.cat([torch.zeros(512, 3), ids])), pe(cids)
+    with torch.no_grad():
+        t0 = time.time(); fr.block_forward(dbl, hid, enc, cond, temb, ctemb, rc, main, {}); td = time.time() - t0
+        t0 = time.time(); fr.single_block_forward(sgl, torch.cat([enc, hid], 1), temb, main, cond, ctemb, rc, {}); ts = time.time() - t0
+    per_image = STEPS * (19 * td + 38 * ts)
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32: 1 double block ({td:.2f}s) + 1 single block ({ts:.2f}s) at full width B=1 S=2560, "
+                      f"extrapolated x(19,38) blocks x28 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed images (batches) per GPU")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    a = ap.parse_args()
+
+    from loongx_amd import dist as lxd
+    from loongx_amd import ops
+    rank, local, world = lxd.init()
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig, synthetic_weights
+    from loongx_amd.train.model import OminiModel, synthetic_cs3_state_dict
+
+    cfg = FluxConfig()
+    t0 = time.time()
+    pw = synthetic_weights(cfg, dev, seed=0 if rank == 0 else 1000 + rank)   # non-zero ranks hold garbage until the broadcast
+    moved = lxd.broadcast_packed_weights(pw, src=0)
+    torch.cuda.synchronize()
+    t_weights = time.time() - t0
+    model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), {"union_cond_attn": True}, dev)
+
+    B, hw = a.batch, 32
+    N = hw * hw
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)     # every rank edits different images
+    def batch():
+        return dict(lat=torch.randn(B, N, 64, device=dev, generator=g), cond=torch.randn(B, N, 64, device=dev, generator=g),
+                    pe=torch.randn(B, T_TXT, 4096, device=dev, generator=g) * 0.1, pooled=torch.randn(B, 768, device=dev, generator=g),
+                    eeg=torch.randn(B, 4, 4096, device=dev, generator=g))
+    def run(x):
+        c = Condition("subject", latents=x["cond"], latent_hw=(hw, hw), position_delta=[0, -hw])
+        return generate(model, model.flux_pipe, conditions=[c], height=512, width=512, num_inference_steps=STEPS, latents=x["lat"],
+                        prompt_embeds=x["pe"], pooled_prompt_embeds=x["pooled"], output_type="latent", model_config=model.model_config,
+                        default_lora=True, additional_condition1=x["eeg"], use_brain_condition=True, fuse_flag=False).images
+
+    batches = [batch() for _ in range(a.warmup + a.steps)]
+    for i in range(a.warmup):
+        out = run(batches[i])
+    timer = None
+    if rank == 0 and not a.no_roofline_events:
+        timer = ops.LaunchTimer()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = run(batches[a.warmup + i])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed_ms = (time.perf_counter() - t0) * 1e3
+    ops.TIMER = None
+    elapsed_ms = lxd.barrier_max_ms(elapsed_ms, dev)
+    finite = bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        images = world * B * a.steps
+        value = images / (elapsed_ms / 1e3)
+        fpi = flops_per_image(N, N)
+        res = {"metric": "edited images/s @512x512, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed_ms / a.steps, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: EEG-only CS3 conditioning, 512x512 edit (512 txt + 1024 img + 1024 cond "
+                                      "tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, D=3072), LoRA r=4 on the condition stream",
+                          "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
+                          "weight_broadcast_GB": round(moved / 1e9, 2), "init_s": round(t_weights, 2)},
+               "outputs_finite": finite,
+               "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
+               "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if timer is not None:
+            s = timer.summary()
+            gm, at = s.get("gemm"), s.get("attn")
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
+                               "share_of_step_time": round(gm["ms"] / elapsed_ms, 3)}
+            if at:
+                aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
+                res["roofline_attention"] = {"bound": "mfma", "kernel": "lx_attn_kernel", "achieved": round(aa, 1), "peak": PEAK_BF16_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": round(aa / PEAK_BF16_TFLOPS, 4), "launches": at["launches"],
+                                             "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
+                                             "share_of_step_time": round(at["ms"] / elapsed_ms, 3)}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

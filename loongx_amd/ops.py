@@ -55,9 +55,38 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
     return d
 
 
+class LaunchTimer:
+    """Brackets selected kernel launches with HIP events on the launch stream (bench.py roofline measurement)."""
+
+    def __init__(self):
+        self.records = {}   # kind -> list of (start_event, end_event, algorithmic_flops)
+
+    def bracket(self, kind: str, flops: float):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(kind, []).append((s, e, flops))
+        return s, e
+
+    def summary(self):
+        """kind -> dict(launches, flops, ms) ; call after torch.cuda.synchronize()."""
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[kind] = dict(launches=len(recs), flops=sum(f for _, _, f in recs), ms=ms)
+        return out
+
+
+TIMER: Optional[LaunchTimer] = None
+
+
 def gemm(problems: Sequence[GemmDesc]) -> None:
     n = len(problems)
     arr = (GemmDesc * n)(*problems)
+    if TIMER is not None:
+        s, e = TIMER.bracket("gemm", sum(2.0 * p.M * p.N * p.K for p in problems))
+        s.record()
+        check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
+        e.record()
+        return
     check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
 
 
@@ -113,6 +142,13 @@ def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_v
         for j in range(3):
             d.bias[i][j] = 0.0 if bias is None else float(bias[i][j])
     d.scale = (1.0 / math.sqrt(128.0)) if scale is None else scale
+    if TIMER is not None:
+        S = sum(seg_len)
+        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        s.record()
+        check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
+        e.record()
+        return
     check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
 
 
