@@ -51,6 +51,7 @@ def cpu_baseline(threads: int):
     pe = fm.FluxPosEmbed()
     main, rc = pe(torch.cat([torch.zeros(512, 3), ids])), pe(cids)
     with torch.no_grad():
+        _ = torch.randn(2048, 2048) @ torch.randn(2048, 2048)        # spin the thread pool up before timing
         t0 = time.time(); fr.block_forward(dbl, hid, enc, cond, temb, ctemb, rc, main, {}); td = time.time() - t0
         t0 = time.time(); fr.single_block_forward(sgl, torch.cat([enc, hid], 1), temb, main, cond, ctemb, rc, {}); ts = time.time() - t0
     per_image = STEPS * (19 * td + 38 * ts)

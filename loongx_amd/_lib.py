@@ -9,6 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; liblx_amd.so needs the SAME runtime instance (streams and device
+# pointers are shared with torch), so torch -- and with it its HIP runtime -- must be loaded before our library.
+import torch  # noqa: F401  (import order is load-bearing)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
