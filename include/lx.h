@@ -102,6 +102,11 @@ int lx_rope_table(const float* ids, int L, int a0, int a1, int a2, double theta,
  * ------------------------------------------------------------------------------------------------ */
 int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* scale, int mod_ld, void* Y, int ldy,
                    int M, int D, int rows_per_batch, float eps, void* stream);
+/* Same, over up to 3 row segments (the text / image / condition token streams) in ONE launch: segment i covers rows
+ * [row0, row0+n_rows) of X and Y with its own shift/scale tables; batch = (row - row0) / rows_per_batch. */
+typedef struct lx_ln_seg { int32_t row0, n_rows, rows_per_batch, _pad; const float* shift; const float* scale; } lx_ln_seg;
+int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                        float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-head RMSNorm (weight, eps) + interleaved-pair RoPE on Q and K, in place, and V transposed into the
@@ -116,6 +121,14 @@ int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* sca
 int lx_qkv_prep(void* QKV, int ld, int q_col, int k_col, int v_col, int row0, int n_rows, int rows_per_batch,
                 int H, const float* wq, const float* wk, float eps, const float* cos_tab, const float* sin_tab,
                 void* VT, int vt_ld, int vt_pos0, void* stream);
+
+/* Same, over up to 3 token segments in ONE launch (each with its own norm weights, RoPE table and V^T slot). */
+typedef struct lx_qkv_seg {
+  int32_t row0, rows_per_batch, vt_pos0, _pad;
+  const float* wq; const float* wk; const float* cos_tab; const float* sin_tab;
+} lx_qkv_seg;
+int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                     int H, float eps, void* VT, int vt_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Joint attention over up to 3 token segments [text | image | condition] -- replaces

@@ -39,6 +39,16 @@ class AttnDesc(C.Structure):
                 ("bias", (C.c_float * 3) * 3), ("scale", C.c_float)]
 
 
+class LnSeg(C.Structure):
+    _fields_ = [("row0", C.c_int32), ("n_rows", C.c_int32), ("rows_per_batch", C.c_int32), ("_pad", C.c_int32),
+                ("shift", C.c_void_p), ("scale", C.c_void_p)]
+
+
+class QkvSeg(C.Structure):
+    _fields_ = [("row0", C.c_int32), ("rows_per_batch", C.c_int32), ("vt_pos0", C.c_int32), ("_pad", C.c_int32),
+                ("wq", C.c_void_p), ("wk", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p)]
+
+
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGS = {
     "lx_version": (C.c_int, []),
@@ -50,6 +60,8 @@ _SIGS = {
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
     "lx_rope_table": (C.c_int, [_P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),
     "lx_ln_modulate": (C.c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
+    "lx_ln_modulate_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P]),
+    "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),

@@ -9,12 +9,25 @@ namespace {
 // LayerNorm(no affine) + (1+scale)*x + shift, fp32 in -> bf16 out. One wave per row, row kept in VGPRs.
 // Reference: AdaLayerNormZero/ZeroSingle/Continuous + norm2 modulation (block.py:192-207,238-253,301,305).
 // ------------------------------------------------------------------------------------------------------
+struct LnSegs {   // up to 3 row segments (token streams), each with its own modulation table
+  int n;
+  int row0[3], n_rows[3], rows_per_batch[3];
+  const float* shift[3];
+  const float* scale[3];
+};
+
 template <int NCH>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ shift,
-                                                          const float* __restrict__ scale, int mod_ld, uint16_t* __restrict__ Y,
-                                                          int ldy, int M, int D, int rows_per_batch, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
+                                                          uint16_t* __restrict__ Y, int ldy, int M, int D, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  int sg = 0, acc_rows = 0;
+  while (sg < segs.n - 1 && row >= acc_rows + segs.n_rows[sg]) { acc_rows += segs.n_rows[sg]; ++sg; }
+  const int rin = row - acc_rows;
+  row = segs.row0[sg] + rin;
+  const float* shift = segs.shift[sg];
+  const float* scale = segs.scale[sg];
+  const int rows_per_batch = segs.rows_per_batch[sg];
   const int lane = threadIdx.x & 63;
   const float* xr = X + (size_t)row * ldx;
   f32x4 v[NCH];
@@ -34,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
       q += d * d;
     }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-  const int b = row / rows_per_batch;
+  const int b = rin / rows_per_batch;
   const float* sh = shift + (size_t)b * mod_ld;
   const float* sc = scale + (size_t)b * mod_ld;
   uint16_t* yr = Y + (size_t)row * ldy;
@@ -54,11 +67,17 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 }
 
 // generic D (multiple of 4): three passes over the (L2-resident) row
-__global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restrict__ X, int ldx, const float* __restrict__ shift,
-                                                           const float* __restrict__ scale, int mod_ld, uint16_t* __restrict__ Y,
-                                                           int ldy, int M, int D, int rows_per_batch, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
+                                                           uint16_t* __restrict__ Y, int ldy, int M, int D, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  int sg = 0, acc_rows = 0;
+  while (sg < segs.n - 1 && row >= acc_rows + segs.n_rows[sg]) { acc_rows += segs.n_rows[sg]; ++sg; }
+  const int rin = row - acc_rows;
+  row = segs.row0[sg] + rin;
+  const float* shift = segs.shift[sg];
+  const float* scale = segs.scale[sg];
+  const int rows_per_batch = segs.rows_per_batch[sg];
   const int lane = threadIdx.x & 63;
   const float* xr = X + (size_t)row * ldx;
   float s = 0.f;
@@ -74,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restri
     for (int k = 0; k < 4; ++k) q += (v[k] - mean) * (v[k] - mean);
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-  const int b = row / rows_per_batch;
+  const int b = rin / rows_per_batch;
   const float* sh = shift + (size_t)b * mod_ld;
   const float* sc = scale + (size_t)b * mod_ld;
   uint16_t* yr = Y + (size_t)row * ldy;
@@ -100,13 +119,23 @@ __device__ __forceinline__ int vt_interleave(int key) {  // within every 16 keys
   return (key & ~15) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
 }
 
+struct QkvSegs {
+  int n;
+  int row0[3], rows_per_batch[3], vt_pos0[3], tile0[4];
+  const float* wq[3]; const float* wk[3]; const float* cos_tab[3]; const float* sin_tab[3];
+};
+
 __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
-                                                       int row0, int rows_per_batch, const float* __restrict__ wq,
-                                                       const float* __restrict__ wk, float eps, const float* __restrict__ cos_tab,
-                                                       const float* __restrict__ sin_tab, uint16_t* __restrict__ VT, int vt_ld,
-                                                       int vt_pos0, int H) {
+                                                       const QkvSegs segs, float eps, uint16_t* __restrict__ VT, int vt_ld, int H) {
   __shared__ uint16_t vt_s[64][128 + 8];
-  const int p0 = blockIdx.x * 64;
+  int sg = 0;
+  while (sg < segs.n - 1 && (int)blockIdx.x >= segs.tile0[sg + 1]) ++sg;
+  const int p0 = ((int)blockIdx.x - segs.tile0[sg]) * 64;
+  const int row0 = segs.row0[sg], rows_per_batch = segs.rows_per_batch[sg], vt_pos0 = segs.vt_pos0[sg];
+  const float* __restrict__ wq = segs.wq[sg];
+  const float* __restrict__ wk = segs.wk[sg];
+  const float* __restrict__ cos_tab = segs.cos_tab[sg];
+  const float* __restrict__ sin_tab = segs.sin_tab[sg];
   const int h = blockIdx.y;
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
@@ -186,49 +215,41 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
 }
 
 // ------------------------------------------------------------------------------------------------------
-// LoRA down-projection: T[M,R] = X[M,K] . A[R,K]^T   (bf16 in, fp32 out). Wave = 4 rows, lanes split K.
+// LoRA down-projection: T[M,R<=16] = X[M,K] . A[R,K]^T (bf16 in, fp32 out) on v_mfma_f32_16x16x32_bf16.
+// Workgroup = 8 waves = 16 rows; the waves split K eight ways and reduce through LDS. A is the MFMA "A"
+// operand (rows = r), X the "B" operand (cols = m): each lane ends with 4 consecutive r of one row m.
 // ------------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256) void lora_down_kernel(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ A,
-                                                        float* __restrict__ T, int ldt, int M, int K) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m0 = (blockIdx.x * 4 + wave) * 4;
-  if (m0 >= M) return;
-  float acc[4][R];
+__global__ __launch_bounds__(512) void lora_down_mfma_kernel(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ A,
+                                                             float* __restrict__ T, int ldt, int M, int K, int R) {
+  __shared__ f32x4 red[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 16;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const uint16_t* xp = X + (size_t)min(m0 + l15, M - 1) * ldx + kq * 8;
+  const uint16_t* ap = A + (size_t)min(l15, R - 1) * K + kq * 8;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = wave * 32; k < K; k += 8 * 32) {
+    const bf16x8 af = *(const bf16x8*)(ap + k);
+    const bf16x8 xf = *(const bf16x8*)(xp + k);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, acc, 0, 0, 0);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[i][r] = 0.f;
-  const uint16_t* xr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) xr[i] = X + (size_t)min(m0 + i, M - 1) * ldx;
-  for (int k = lane * 8; k < K; k += 512) {
-    float xv[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x4 raw = *(const u32x4*)(xr[i] + k);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { xv[i][2 * j] = __uint_as_float(raw[j] << 16); xv[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
+    for (int w = 1; w < 8; ++w) {
+      const f32x4 o = red[w][lane];
+      acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u32x4 raw = *(const u32x4*)(A + (size_t)r * K + k);
-      float av[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { av[2 * j] = __uint_as_float(raw[j] << 16); av[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][r] = fmaf(xv[i][j], av[j], acc[i][r]);
+    // acc[j]: r = 4*kq + j, m = m0 + l15
+    const int m = m0 + l15, r0 = 4 * kq;
+    if (m < M && r0 < R) {
+      float* tp = T + (size_t)m * ldt + r0;
+      if (r0 + 4 <= R && (ldt & 3) == 0) *(f32x4*)tp = acc;
+      else
+        for (int j = 0; j < 4 && r0 + j < R; ++j) tp[j] = acc[j];
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float s = wave_sum(acc[i][r]);
-      if (lane == 0 && m0 + i < M) T[(size_t)(m0 + i) * ldt + r] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -322,50 +343,98 @@ __global__ void convert_kernel(void* __restrict__ dst, int dst_bf16, const void*
 
 }  // namespace
 
-extern "C" int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* scale, int mod_ld, void* Y, int ldy,
-                              int M, int D, int rows_per_batch, float eps, void* stream) {
-  LX_CHECK_ARG(X && shift && scale && Y, "lx_ln_modulate: NULL operand");
-  LX_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 16384, "lx_ln_modulate: D=%d must be a multiple of 4 and <= 16384", D);
-  LX_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0 && rows_per_batch > 0, "lx_ln_modulate: ldx/ldy/mod_ld must be multiples of 4");
-  LX_CHECK_ARG((((uintptr_t)X | (uintptr_t)shift | (uintptr_t)scale) & 15) == 0 && ((uintptr_t)Y & 7) == 0, "lx_ln_modulate: misaligned operand");
+static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, void* Y, int ldy, int D, float eps, void* stream) {
+  int M = 0;
+  for (int i = 0; i < segs.n; ++i) {
+    LX_CHECK_ARG(segs.shift[i] && segs.scale[i] && segs.n_rows[i] > 0 && segs.rows_per_batch[i] > 0, "lx_ln_modulate: bad segment %d", i);
+    LX_CHECK_ARG((((uintptr_t)segs.shift[i] | (uintptr_t)segs.scale[i]) & 15) == 0, "lx_ln_modulate: misaligned modulation table");
+    M += segs.n_rows[i];
+  }
+  LX_CHECK_ARG(X && Y, "lx_ln_modulate: NULL operand");
+  LX_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 16384, "lx_ln_modulate: D=%d must be a multiple of 4 and <= 16384", D);
+  LX_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && mod_ld % 4 == 0, "lx_ln_modulate: ldx/ldy/mod_ld must be multiples of 4");
+  LX_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 7) == 0, "lx_ln_modulate: misaligned operand");
   const dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   uint16_t* y = (uint16_t*)Y;
-  if (D == 3072) hipLaunchKernelGGL(ln_modulate_kernel<12>, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
-  else if (D == 256) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
-  else hipLaunchKernelGGL(ln_modulate_generic, grid, block, 0, s, X, ldx, shift, scale, mod_ld, y, ldy, M, D, rows_per_batch, eps);
+  if (D == 3072) hipLaunchKernelGGL(ln_modulate_kernel<12>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
+  else if (D == 256) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
+  else hipLaunchKernelGGL(ln_modulate_generic, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
   LX_LAUNCH_CHECK("lx_ln_modulate");
+  return LX_OK;
+}
+
+extern "C" int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* scale, int mod_ld, void* Y, int ldy,
+                              int M, int D, int rows_per_batch, float eps, void* stream) {
+  LX_CHECK_ARG(M > 0, "lx_ln_modulate: M must be > 0");
+  LnSegs segs;
+  segs.n = 1;
+  segs.row0[0] = 0; segs.n_rows[0] = M; segs.rows_per_batch[0] = rows_per_batch; segs.shift[0] = shift; segs.scale[0] = scale;
+  return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream);
+}
+
+extern "C" int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                                   float eps, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_ln_modulate_segs: 1..3 segments");
+  LnSegs segs;
+  segs.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.n_rows[i] = seg[i].n_rows; segs.rows_per_batch[i] = seg[i].rows_per_batch;
+    segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
+  }
+  return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream);
+}
+
+static int qkv_launch(void* QKV, int ld, int q_col, int k_col, int v_col, QkvSegs& segs, int n_batches, int H, float eps, void* VT,
+                      int vt_ld, void* stream) {
+  LX_CHECK_ARG(QKV && n_batches > 0 && H > 0, "lx_qkv_prep: bad arguments");
+  LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep: ld and column offsets must be multiples of 8");
+  if (VT) LX_CHECK_ARG(vt_ld % 64 == 0, "lx_qkv_prep: vt_ld must be a multiple of 64");
+  int t = 0;
+  for (int i = 0; i < segs.n; ++i) {
+    LX_CHECK_ARG(segs.rows_per_batch[i] > 0, "lx_qkv_prep: empty segment %d", i);
+    LX_CHECK_ARG((segs.cos_tab[i] == nullptr) == (segs.sin_tab[i] == nullptr), "lx_qkv_prep: cos/sin tables must come together");
+    if (VT) LX_CHECK_ARG(segs.vt_pos0[i] % 64 == 0, "lx_qkv_prep: vt_pos0 must be a multiple of 64");
+    segs.tile0[i] = t;
+    t += (segs.rows_per_batch[i] + 63) / 64;
+  }
+  segs.tile0[segs.n] = t;
+  hipLaunchKernelGGL(qkv_prep_kernel, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col, v_col,
+                     segs, eps, (uint16_t*)VT, vt_ld, H);
+  LX_LAUNCH_CHECK("lx_qkv_prep");
   return LX_OK;
 }
 
 extern "C" int lx_qkv_prep(void* QKV, int ld, int q_col, int k_col, int v_col, int row0, int n_rows, int rows_per_batch, int H,
                            const float* wq, const float* wk, float eps, const float* cos_tab, const float* sin_tab, void* VT,
                            int vt_ld, int vt_pos0, void* stream) {
-  LX_CHECK_ARG(QKV && n_rows > 0 && rows_per_batch > 0 && n_rows % rows_per_batch == 0, "lx_qkv_prep: n_rows=%d must be a multiple of rows_per_batch=%d", n_rows, rows_per_batch);
-  LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep: ld and column offsets must be multiples of 8");
-  LX_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "lx_qkv_prep: cos/sin tables must come together");
-  if (VT) LX_CHECK_ARG(vt_ld % 64 == 0 && vt_pos0 % 64 == 0, "lx_qkv_prep: vt_ld and vt_pos0 must be multiples of 64");
-  const dim3 grid((rows_per_batch + 63) / 64, H, n_rows / rows_per_batch);
-  hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col, v_col, row0,
-                     rows_per_batch, wq, wk, eps, cos_tab, sin_tab, (uint16_t*)VT, vt_ld, vt_pos0, H);
-  LX_LAUNCH_CHECK("lx_qkv_prep");
-  return LX_OK;
+  LX_CHECK_ARG(n_rows > 0 && rows_per_batch > 0 && n_rows % rows_per_batch == 0, "lx_qkv_prep: n_rows=%d must be a multiple of rows_per_batch=%d", n_rows, rows_per_batch);
+  QkvSegs segs;
+  segs.n = 1;
+  segs.row0[0] = row0; segs.rows_per_batch[0] = rows_per_batch; segs.vt_pos0[0] = vt_pos0;
+  segs.wq[0] = wq; segs.wk[0] = wk; segs.cos_tab[0] = cos_tab; segs.sin_tab[0] = sin_tab;
+  return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_rows / rows_per_batch, H, eps, VT, vt_ld, stream);
+}
+
+extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                                int H, float eps, void* VT, int vt_ld, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_qkv_prep_segs: 1..3 segments");
+  QkvSegs segs;
+  segs.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.rows_per_batch[i] = seg[i].rows_per_batch; segs.vt_pos0[i] = seg[i].vt_pos0;
+    segs.wq[i] = seg[i].wq; segs.wk[i] = seg[i].wk; segs.cos_tab[i] = seg[i].cos_tab; segs.sin_tab[i] = seg[i].sin_tab;
+  }
+  return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_batches, H, eps, VT, vt_ld, stream);
 }
 
 extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, void* stream) {
   LX_CHECK_ARG(X && Adown && T && M > 0, "lx_lora_down: NULL operand");
-  LX_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldt >= R, "lx_lora_down: K and ldx must be multiples of 8, ldt >= R");
-  const dim3 grid((M + 15) / 16), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  const uint16_t* x = (const uint16_t*)X;
-  const uint16_t* a = (const uint16_t*)Adown;
-  switch (R) {
-    case 4: hipLaunchKernelGGL(lora_down_kernel<4>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
-    case 8: hipLaunchKernelGGL(lora_down_kernel<8>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
-    case 12: hipLaunchKernelGGL(lora_down_kernel<12>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
-    case 16: hipLaunchKernelGGL(lora_down_kernel<16>, grid, block, 0, s, x, ldx, a, T, ldt, M, K); break;
-    default: lx_set_error("lx_lora_down: R=%d unsupported (4, 8, 12, 16)", R); return LX_ERR_UNSUPPORTED;
-  }
+  LX_CHECK_ARG(R >= 1 && R <= 16, "lx_lora_down: R=%d must be in [1,16]", R);
+  LX_CHECK_ARG(K % 32 == 0 && ldx % 8 == 0 && ldt >= R, "lx_lora_down: K %% 32, ldx %% 8 and ldt >= R required (K=%d)", K);
+  LX_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Adown & 15) == 0 && ((uintptr_t)T & 15) == 0, "lx_lora_down: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)X, ldx,
+                     (const uint16_t*)Adown, T, ldt, M, K, R);
   LX_LAUNCH_CHECK("lx_lora_down");
   return LX_OK;
 }

@@ -192,12 +192,13 @@ class DiTEngine:
 
     # ------------------------------------------------------------------------------------------ building blocks
     def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
-        D = self.cfg.inner_dim
+        row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
+        segs = []
         for s, L in self._streams():
             mods = self.cmods if s == "cond" else self.mods
             b0 = base_by_stream[s]
-            ops.ln_modulate(self.rows(self.X, s), mods[:, b0 + shift_off:], mods[:, b0 + scale_off:], self.rows(self.XN, s),
-                            rows_per_batch=L, mod_ld=mods.stride(0))
+            segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
+        ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0))
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
@@ -244,7 +245,7 @@ class DiTEngine:
         cfg = self.cfg
         D, H, B = cfg.inner_dim, cfg.num_attention_heads, self.B
         Y = self.Y
-        seg_row0, seg_len, seg_vt0 = [], [], []
+        seg_row0, seg_len, seg_vt0, qsegs = [], [], [], []
         off = 0
         streams = self._streams()
         bias = [[0.0] * 3 for _ in range(3)]
@@ -260,10 +261,9 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            ops.qkv_prep(Y, q_col=2 * D, k_col=0, v_col=D, row0=row0, n_rows=B * L, rows_per_batch=L, H=H,
-                         wq=wq_txt if s == "txt" else wq, wk=wk_txt if s == "txt" else wk, cos=cos, sin=sin,
-                         VT=self.VT, vt_pos0=self.vt0[s])
+            qsegs.append((row0, L, self.vt0[s], wq_txt if s == "txt" else wq, wk_txt if s == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
+        ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                      seg_vt0=seg_vt0, bias=bias)
 

@@ -131,6 +131,28 @@ def qkv_prep(QKV, q_col, k_col, v_col, row0, n_rows, rows_per_batch, H, wq, wk, 
                           _p(cos), _p(sin), _p(VT), VT.shape[-1] if VT is not None else 0, vt_pos0, _stream()), "lx_qkv_prep")
 
 
+def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6) -> None:
+    """segs: list of (row0, n_rows, rows_per_batch, shift_tensor, scale_tensor); one launch."""
+    n = len(segs)
+    arr = (L.LnSeg * n)()
+    for i, (row0, n_rows, rpb, sh, sc) in enumerate(segs):
+        arr[i].row0, arr[i].n_rows, arr[i].rows_per_batch = row0, n_rows, rpb
+        arr[i].shift, arr[i].scale = sh.data_ptr(), sc.data_ptr()
+    check(lib.lx_ln_modulate_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, Y.data_ptr(), Y.stride(0), X.shape[1], eps, _stream()),
+          "lx_ln_modulate_segs")
+
+
+def qkv_prep_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, VT, eps=1e-6) -> None:
+    """segs: list of (row0, rows_per_batch, vt_pos0, wq, wk, cos, sin); one launch."""
+    n = len(segs)
+    arr = (L.QkvSeg * n)()
+    for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
+        arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, vt0
+        arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
+    check(lib.lx_qkv_prep_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, _p(VT),
+                               VT.shape[-1] if VT is not None else 0, _stream()), "lx_qkv_prep_segs")
+
+
 def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
     d = AttnDesc()
     d.Q, d.K, d.VT, d.O = Q.data_ptr(), K.data_ptr(), VT.data_ptr(), O.data_ptr()
