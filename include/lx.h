@@ -75,7 +75,7 @@ typedef struct lx_gemm_desc {
 
 #define LX_GEMM_MAX_GROUP 4
 /* One launch over `n` independent problems (the three token streams of a block share one launch so
- * that small-M streams still fill the chip).  K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0. */
+ * that small-M streams still fill the chip).  K % 64 == 0, N % 8 == 0, lda/ldw/ldc % 8 == 0. */
 int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
 
 /* lora_t[M, R] (fp32, ldt) = X[M,K] (bf16, ldx) . Adown[R,K]^T (bf16).  R <= 16.  (peft lora_A) */

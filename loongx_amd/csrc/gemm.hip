@@ -128,21 +128,105 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-  const int nkt = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
-    const char* sb = smem + buf * STAGE_BYTES;
+  // ---- main loop: software pipelined ------------------------------------------------------------------
+  // Fragment registers are double buffered (set A / set B alternate over the four 16-deep k steps of a K tile):
+  // the LDS reads of step s+1 are issued BEFORE the MFMAs of step s.  The single barrier of a K tile sits between
+  // steps 2 and 3, where every wave still holds 8 MFMAs of ready work: behind it the DMA of tile kt+2 is issued
+  // into the buffer tile kt just vacated and the first fragments of tile kt+1 are fetched under step 3's MFMAs.
+  auto load_frags = [&](const char* sb, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[MI]) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 128 + slot_off[ks]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 128 + slot_off[ks]);
+  };
+  auto mma_j = [&](int j, const bf16x8 (&wf)[2], const bf16x8 (&xf)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+  };
+  const int nkt = K / BK;
+  bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
+  stage(0, 0);
+  if (nkt > 1) stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  load_frags(smem, 0, wfA, xfA);
+  // One k step = [MI MFMAs] [6 LDS reads for the NEXT step] [MI MFMAs]; sched_barrier(0) pins that order.  The reads sit
+  // in the middle of an MFMA group so that the wait hipcc places in front of a group's first MFMA only ever covers
+  // reads issued a whole group earlier (it is conservative across the loop back-edge and would otherwise stall on
+  // the reads just issued).
+#define LX_STEP(CUR_W, CUR_X, NEXT_STMT)            \
+  mma_j(0, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_sched_barrier(0);                \
+  NEXT_STMT;                                        \
+  __builtin_amdgcn_sched_barrier(0);                \
+  mma_j(1, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+    const char* sbn = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    LX_STEP(wfA, xfA, load_frags(sb, 1, wfB, xfB))
+    LX_STEP(wfB, xfB, load_frags(sb, 2, wfA, xfA))
+    LX_STEP(wfA, xfA, load_frags(sb, 3, wfB, xfB))
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 (issued one K tile ago) has landed
+    __syncthreads();                                    // ... and every wave is done reading tile kt
+    if (kt + 2 < nkt) stage(kt + 2, kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA))
+  }
+#undef LX_STEP
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
+  const int epi = P.epilogue & 0xff;
+  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
+  const int mw0 = m0 + wm * (BM / 2);          // first row of this wave's tile
+  const int nw0 = n0 + wn * 64;                // first column of this wave's tile
+
+  // (1) LoRA up-projection as ONE extra MFMA k-step per 4 ranks. t and up are split into bf16 hi + lo parts and
+  //     the 16 k-slots carry the four cross terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy
+  //     (2^-16 relative) at the cost of 2*MI MFMAs, instead of a scalar epilogue loop.
+  if (P.lora_t != nullptr) {
+    const int R = P.lora_r;
+    const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+    for (int r0 = 0; r0 < R; r0 += 4) {
       bf16x8 wf[2], xf[MI];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 128 + slot_off[ks]);
+      for (int j = 0; j < 2; ++j) {
+        const int n = min(nw0 + j * 32 + l31, N - 1);
+        float u[4];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 128 + slot_off[ks]);
+        for (int e = 0; e < 4; ++e) u[e] = (r0 + e < R) ? P.lora_up[(size_t)n * R + r0 + e] : 0.f;
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint16_t h0 = f32_to_bf16(u[2 * e]), h1 = f32_to_bf16(u[2 * e + 1]);
+          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                            // slots 0-3: up_hi
+          w[2 + e] = pack_bf16x2(u[2 * e] - bf16_to_f32(h0), u[2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
+        }
+        wf[j] = __builtin_bit_cast(bf16x8, w);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = min(mw0 + i * 32 + l31, M - 1);
+        const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff + r0;
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (r0 + e < R) ? tp[e] : 0.f;
+        u32x2 h;
+        if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
+          h[0] = pack_bf16x2(t[0], t[1]);
+          h[1] = pack_bf16x2(t[2], t[3]);
+        } else {
+          float lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = t[e] - bf16_to_f32(f32_to_bf16(t[e]));
+          h[0] = pack_bf16x2(lo[0], lo[1]);
+          h[1] = pack_bf16x2(lo[2], lo[3]);
+        }
+        u32x4 x = {h[0], h[1], h[0], h[1]};
+        xf[i] = __builtin_bit_cast(bf16x8, x);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -151,76 +235,77 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------
-  // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
-  const int epi = P.epilogue & 0xff;
-  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
-  const int nbase = n0 + wn * 64 + 4 * lhi;
-  const bool has_lora = P.lora_t != nullptr;
-  const int R = P.lora_r;
-  int toff = 0;
-  if (has_lora) toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
-
+  // (2) transpose each 32x64 accumulator block through a wave-private LDS patch so that every global access of
+  //     the epilogue (bias, gate, residual read-modify-write, stores) is a coalesced 16-B-per-lane row access.
+  __syncthreads();                                   // every wave is done with the operand tiles
+  constexpr int EP_LD = 68;                          // fp32 row stride of the patch (64 + 4 pad)
+  float* patch = (float*)smem + wave * (32 * EP_LD);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 32 + l31;
-    if (m >= M) continue;
-    const int b = m / P.rows_per_batch;
-    float tv[16];
-    if (has_lora) {
-      const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff;
-      for (int r = 0; r < R; ++r) tv[r] = tp[r];
-    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const int nb = nbase + j * 32 + rq * 8;
-        if (nb >= N) continue;
-        float v[4];
+        f32x4 v = {acc[j][i][rq * 4], acc[j][i][rq * 4 + 1], acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
+        *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int mb = mw0 + i * 32;
+    if (epi == LX_EPI_STORE_BF16) {
+      const int c8 = (lane & 7) * 8, n = nw0 + c8;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = acc[j][i][rq * 4 + c];
-        if (P.bias) {
-          const f32x4 bv = *(const f32x4*)(P.bias + nb);
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + (lane >> 3), m = mb + row;
+        f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
+        f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
+        if (m < M && n < N) {
+          if (P.bias) {
+            const f32x4 b0 = *(const f32x4*)(P.bias + n), b1 = *(const f32x4*)(P.bias + n + 4);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] += bv[c];
-        }
-        if (has_lora) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float* up = P.lora_up + (size_t)(nb + c) * R;
-            float s = 0.f;
-            for (int r = 0; r < R; ++r) s += tv[r] * up[r];
-            v[c] += s;
+            for (int c = 0; c < 4; ++c) { v0[c] += b0[c]; v1[c] += b1[c]; }
           }
-        }
-        if (do_gelu && nb >= P.gelu_col_start) {
+          if (do_gelu && n >= P.gelu_col_start) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
-        }
-        if (epi == LX_EPI_STORE_BF16) {
-          u32x2 o;
-          o[0] = pack_bf16x2(v[0], v[1]);
-          o[1] = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)((uint16_t*)P.C + (size_t)m * P.ldc + nb) = o;
-        } else if (epi == LX_EPI_STORE_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + nb) = o;
-        } else {  // LX_EPI_RESID_F32
-          float* cp = (float*)P.C + (size_t)m * P.ldc + nb;
-          f32x4 o = *(const f32x4*)cp;
-          if (P.gate) {
-            const f32x4 gv = *(const f32x4*)(P.gate + (size_t)b * P.gate_ld + nb);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] += v[c];
+            for (int c = 0; c < 4; ++c) { v0[c] = gelu_tanh(v0[c]); v1[c] = gelu_tanh(v1[c]); }
           }
-          *(f32x4*)cp = o;
+          u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + n) = o;
+        }
+      }
+    } else {
+      const int c4 = (lane & 15) * 4, n = nw0 + c4;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 4 + (lane >> 4), m = mb + row;
+        f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
+        if (m < M && n < N) {
+          if (P.bias) {
+            const f32x4 bv = *(const f32x4*)(P.bias + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += bv[c];
+          }
+          if (do_gelu && n >= P.gelu_col_start) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+          }
+          float* cp = (float*)P.C + (size_t)m * P.ldc + n;
+          if (epi == LX_EPI_RESID_F32) {
+            f32x4 o = *(const f32x4*)cp;
+            if (P.gate) {
+              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)(m / P.rows_per_batch) * P.gate_ld + n);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] += v[c];
+            }
+            v = o;
+          }
+          *(f32x4*)cp = v;
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -241,10 +326,10 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
     LX_CHECK_ARG(p.A && p.W && p.C, "lx_gemm_bf16[%d]: NULL operand", i);
     LX_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "lx_gemm_bf16[%d]: bad shape M=%d N=%d K=%d", i, p.M, p.N, p.K);
     LX_CHECK_ARG(p.K % BK == 0, "lx_gemm_bf16[%d]: K=%d must be a multiple of %d", i, p.K, BK);
-    LX_CHECK_ARG(p.N % 4 == 0, "lx_gemm_bf16[%d]: N=%d must be a multiple of 4", i, p.N);
+    LX_CHECK_ARG(p.N % 8 == 0, "lx_gemm_bf16[%d]: N=%d must be a multiple of 8", i, p.N);
     LX_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.lda >= p.K && p.ldw >= p.K, "lx_gemm_bf16[%d]: lda/ldw must be >= K and multiples of 8", i);
     LX_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "lx_gemm_bf16[%d]: operands must be 16-byte aligned", i);
-    LX_CHECK_ARG(p.ldc % 4 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 4", i, p.ldc);
+    LX_CHECK_ARG(p.ldc % 8 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 4", i, p.ldc);
     const int epi = p.epilogue & 0xff;
     LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && epi <= LX_EPI_RESID_F32, "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
     LX_CHECK_ARG(p.rows_per_batch > 0, "lx_gemm_bf16[%d]: rows_per_batch must be > 0", i);
