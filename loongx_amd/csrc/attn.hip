@@ -36,7 +36,7 @@ struct AttnArgs {
   int qt_start[4];   // prefix of 128-row query tiles per segment
 };
 
-__global__ __launch_bounds__(NTHREADS) void lx_attn_kernel(const AttnArgs args) {
+__global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs args) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
   const lx_attn_desc& D = args.d;
   const int tid = threadIdx.x;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_attn_kernel(const AttnArgs args) 
     const int klen = D.seg_len[sk];
     const int kbase = kt * KVBLK + 4 * lhi;
     if (kt * KVBLK + KVBLK > klen) {   // ragged last tile of the segment: mask keys past its end
+      __builtin_amdgcn_sched_barrier(0);   // keep this a (wave-uniform) branch: if-converted it costs 64 VALU on every tile
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     LX_STEP(wfA, xfA, load_frags(sb, 3, wfB, xfB))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 (issued one K tile ago) has landed
     __syncthreads();                                    // ... and every wave is done reading tile kt
-    if (kt + 2 < nkt) stage(kt + 2, kt & 1);
+    if (kt + 2 < nkt && !(P.epilogue & 0x1000)) stage(kt + 2, kt & 1);   // 0x1000: debug, skip in-loop DMA
     __builtin_amdgcn_sched_barrier(0);
     LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA))
   }

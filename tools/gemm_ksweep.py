@@ -10,6 +10,7 @@ for K in (64, 512, 1024, 2048, 3072, 6144, 12288):
     W = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     d = ops.gemm_desc(A, W, C)
+    d.epilogue |= int(os.environ.get('EPI_OR', '0'), 0)
     for _ in range(6):
         ops.gemm([d])
     torch.cuda.synchronize()
