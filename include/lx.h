@@ -71,6 +71,8 @@ typedef struct lx_gemm_desc {
   int32_t lora_r, lora_ldt, lora_mod_cols, lora_toff_max;
   int32_t epilogue;
   int32_t gelu_col_start;
+  int32_t lora_nsplit;       /* lora_t is the sum of this many K-split partial slabs (0/1 = a single slab) ... */
+  int32_t lora_split_stride; /* ... spaced this many floats apart (as written by lx_lora_down) */
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4
@@ -78,8 +80,11 @@ typedef struct lx_gemm_desc {
  * that small-M streams still fill the chip).  K % 64 == 0, N % 8 == 0, lda/ldw/ldc % 8 == 0. */
 int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
 
-/* lora_t[M, R] (fp32, ldt) = X[M,K] (bf16, ldx) . Adown[R,K]^T (bf16).  R <= 16.  (peft lora_A) */
-int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, void* stream);
+/* LoRA down-projection (peft lora_A): T_s[M, R] (fp32, ldt) = X[M, K_s] (bf16, ldx) . Adown[R, K_s]^T (bf16), R <= 16,
+ * for n_split contiguous K slices s (n_split = 1: the whole K); slab s is written at T + s*split_stride. Splitting K
+ * spreads a tall-skinny product over the whole chip without atomics; the consumer (lx_gemm_bf16) adds the slabs. */
+int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                 int split_stride, void* stream);
 
 /* Skinny linear for M <= 16 rows (AdaLayerNorm modulation linears, time/text embedders:
  * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound.

@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32),
                 ("rows_per_batch", C.c_int32), ("gate_ld", C.c_int32),
                 ("lora_r", C.c_int32), ("lora_ldt", C.c_int32), ("lora_mod_cols", C.c_int32),
-                ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32)]
+                ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32),
+                ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -55,7 +56,7 @@ _SIGS = {
     "lx_last_error": (C.c_char_p, []),
     "lx_device_arch": (C.c_int, [C.c_char_p, _Z]),
     "lx_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _I, _P]),
-    "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
     "lx_rope_table": (C.c_int, [_P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),

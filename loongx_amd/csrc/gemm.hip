@@ -37,6 +37,149 @@ struct GemmArgs {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
+template <int BM, int MI>
+__device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int wave,
+                                              int wm, int wn, int lane, int l31, int lhi) {
+  const int M = P.M, N = P.N;
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
+  const int epi = P.epilogue & 0xff;
+  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
+  const int mw0 = m0 + wm * (BM / 2);          // first row of this wave's tile
+  const int nw0 = n0 + wn * 64;                // first column of this wave's tile
+
+  // (1) LoRA up-projection as ONE extra MFMA k-step per 4 ranks. t and up are split into bf16 hi + lo parts and
+  //     the 16 k-slots carry the four cross terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy
+  //     (2^-16 relative) at the cost of 2*MI MFMAs, instead of a scalar epilogue loop.
+  if (P.lora_t != nullptr) {
+    const int R = P.lora_r;
+    const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+    for (int r0 = 0; r0 < R; r0 += 4) {
+      bf16x8 wf[2], xf[MI];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = min(nw0 + j * 32 + l31, N - 1);
+        float u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (r0 + e < R) ? P.lora_up[(size_t)n * R + r0 + e] : 0.f;
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint16_t h0 = f32_to_bf16(u[2 * e]), h1 = f32_to_bf16(u[2 * e + 1]);
+          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                            // slots 0-3: up_hi
+          w[2 + e] = pack_bf16x2(u[2 * e] - bf16_to_f32(h0), u[2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
+        }
+        wf[j] = __builtin_bit_cast(bf16x8, w);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = min(mw0 + i * 32 + l31, M - 1);
+        const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff + r0;
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (r0 + e < R) ? tp[e] : 0.f;
+        for (int sp = 1; sp < P.lora_nsplit; ++sp) {        // K-split partial slabs from lx_lora_down
+          const float* tq = tp + (size_t)sp * P.lora_split_stride;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] += (r0 + e < R) ? tq[e] : 0.f;
+        }
+        u32x2 h;
+        if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
+          h[0] = pack_bf16x2(t[0], t[1]);
+          h[1] = pack_bf16x2(t[2], t[3]);
+        } else {
+          float lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = t[e] - bf16_to_f32(f32_to_bf16(t[e]));
+          h[0] = pack_bf16x2(lo[0], lo[1]);
+          h[1] = pack_bf16x2(lo[2], lo[3]);
+        }
+        u32x4 x = {h[0], h[1], h[0], h[1]};
+        xf[i] = __builtin_bit_cast(bf16x8, x);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // (2) transpose each 32x64 accumulator block through a wave-private LDS patch so that every global access of
+  //     the epilogue (bias, gate, residual read-modify-write, stores) is a coalesced 16-B-per-lane row access.
+  __syncthreads();                                   // every wave is done with the operand tiles
+  constexpr int EP_LD = 68;                          // fp32 row stride of the patch (64 + 4 pad)
+  float* patch = (float*)smem + wave * (32 * EP_LD);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v = {acc[j][i][rq * 4], acc[j][i][rq * 4 + 1], acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
+        *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int mb = mw0 + i * 32;
+    if (epi == LX_EPI_STORE_BF16) {
+      const int c8 = (lane & 7) * 8, n = nw0 + c8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + (lane >> 3), m = mb + row;
+        f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
+        f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
+        if (m < M && n < N) {
+          if (P.bias) {
+            const f32x4 b0 = *(const f32x4*)(P.bias + n), b1 = *(const f32x4*)(P.bias + n + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v0[c] += b0[c]; v1[c] += b1[c]; }
+          }
+          if (do_gelu && n >= P.gelu_col_start) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v0[c] = gelu_tanh(v0[c]); v1[c] = gelu_tanh(v1[c]); }
+          }
+          u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + n) = o;
+        }
+      }
+    } else {
+      const int c4 = (lane & 15) * 4, n = nw0 + c4;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 4 + (lane >> 4), m = mb + row;
+        f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
+        if (m < M && n < N) {
+          if (P.bias) {
+            const f32x4 bv = *(const f32x4*)(P.bias + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += bv[c];
+          }
+          if (do_gelu && n >= P.gelu_col_start) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+          }
+          float* cp = (float*)P.C + (size_t)m * P.ldc + n;
+          if (epi == LX_EPI_RESID_F32) {
+            f32x4 o = *(const f32x4*)cp;
+            if (P.gate) {
+              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)(m / P.rows_per_batch) * P.gate_ld + n);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] += v[c];
+            }
+            v = o;
+          }
+          *(f32x4*)cp = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int BM>
 __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) {
   constexpr int MI = BM / 64;               // 32-row m-blocks per wave
@@ -145,6 +288,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
       acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
   };
   const int nkt = K / BK;
+  const bool split = (P.epilogue & 0x2000) == 0;     // 0x2000: debug, disable the DMA role split
   bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
   stage(0, 0);
   if (nkt > 1) stage(1, 1);
@@ -170,143 +314,169 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     LX_STEP(wfA, xfA, load_frags(sb, 3, wfB, xfB))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 (issued one K tile ago) has landed
     __syncthreads();                                    // ... and every wave is done reading tile kt
-    if (kt + 2 < nkt && !(P.epilogue & 0x1000)) stage(kt + 2, kt & 1);   // 0x1000: debug, skip in-loop DMA
+    // Role split: waves w and w+4 share a SIMD. The lower half issues its 8 DMA pieces right behind the barrier while
+    // its SIMD partner runs MFMAs; the upper half runs step 3 first and issues its pieces afterwards. (Issuing from
+    // both at once leaves the matrix pipe idle for the ~1000 cycles the LDS-DMA issue costs.)
+    const bool dma = kt + 2 < nkt && !(P.epilogue & 0x1000);   // 0x1000: debug, skip in-loop DMA
+    if (dma && (wm == 0 || !split)) stage(kt + 2, kt & 1);
     __builtin_amdgcn_sched_barrier(0);
     LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA))
+    if (dma && wm == 1 && split) stage(kt + 2, kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #undef LX_STEP
 
-  // ---- epilogue ----------------------------------------------------------------------------------
-  // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
-  const int epi = P.epilogue & 0xff;
-  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
-  const int mw0 = m0 + wm * (BM / 2);          // first row of this wave's tile
-  const int nw0 = n0 + wn * 64;                // first column of this wave's tile
+  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, wave, wm, wn, lane, l31, lhi);
+}
 
-  // (1) LoRA up-projection as ONE extra MFMA k-step per 4 ranks. t and up are split into bf16 hi + lo parts and
-  //     the 16 k-slots carry the four cross terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy
-  //     (2^-16 relative) at the cost of 2*MI MFMAs, instead of a scalar epilogue loop.
-  if (P.lora_t != nullptr) {
-    const int R = P.lora_r;
-    const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
-    for (int r0 = 0; r0 < R; r0 += 4) {
-      bf16x8 wf[2], xf[MI];
+// ---------------------------------------------------------------------------------------------------------------
+// v2 main loop: BK = 32, FOUR LDS stages. Three K tiles are in flight while one is consumed (96 KiB of DMA per CU
+// instead of 64 at BM=256), tracked with a counted `s_waitcnt vmcnt` and a raw s_barrier so outstanding DMA is never
+// drained. Motivation (measured): with 2 stages the loop ran 1.85 us per 64-deep K tile against 1.34 us with the DMA
+// disabled -- L2/HBM->LDS latency, not MFMA or LDS bandwidth, was the limiter.
+// LDS rows are 64 B; the 16-B slot index is XORed with (row>>2)&3 (conflict-free for the ds_read_b128 lane groups).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel_v2(const GemmArgs args) {
+  constexpr int MI = BM / 64;
+  constexpr int BK2 = 32;
+  constexpr int NST = 4;
+  constexpr int A_BYTES = BM * BK2 * 2;
+  constexpr int W_BYTES = BN * BK2 * 2;
+  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int AJ = BM / 128;                // global_load_lds per wave per stage for A (16 rows of 64 B each)
+  constexpr int LOADS = AJ + 2;               // ... plus 2 for W
+  static_assert(NST * STAGE_BYTES >= 8 * 32 * 68 * 4, "epilogue patch must fit");
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int total = args.tile_start[args.n];
+  int lid;
+  {
+    const int pid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, inx = pid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  }
+  int g = 0;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = min(nw0 + j * 32 + l31, N - 1);
-        float u[4];
+  for (int i = 1; i < LX_GEMM_MAX_GROUP; ++i)
+    if (i < args.n && lid >= args.tile_start[i]) g = i;
+  const lx_gemm_desc& P = args.p[g];
+  const int local = lid - args.tile_start[g];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  int tm, tn;
+  {
+    const int gs = GROUP_M * tiles_n;
+    const int gi = local / gs, in_g = local - gi * gs;
+    const int first_m = gi * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = P.M, N = P.N, K = P.K;
+
+  const __bf16* asrc[AJ];
+  const __bf16* wsrc[2];
+  {
+    const int rsub = lane >> 2, pslot = lane & 3;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = (r0 + e < R) ? P.lora_up[(size_t)n * R + r0 + e] : 0.f;
-        u32x4 w;
+    for (int j = 0; j < AJ; ++j) {
+      const int row = (j * 8 + wave) * 16 + rsub;
+      const int lslot = pslot ^ ((row >> 2) & 3);
+      asrc[j] = (const __bf16*)P.A + (size_t)min(m0 + row, M - 1) * P.lda + lslot * 8;
+    }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint16_t h0 = f32_to_bf16(u[2 * e]), h1 = f32_to_bf16(u[2 * e + 1]);
-          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                            // slots 0-3: up_hi
-          w[2 + e] = pack_bf16x2(u[2 * e] - bf16_to_f32(h0), u[2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
-        }
-        wf[j] = __builtin_bit_cast(bf16x8, w);
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = min(mw0 + i * 32 + l31, M - 1);
-        const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff + r0;
-        float t[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (r0 + e < R) ? tp[e] : 0.f;
-        u32x2 h;
-        if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
-          h[0] = pack_bf16x2(t[0], t[1]);
-          h[1] = pack_bf16x2(t[2], t[3]);
-        } else {
-          float lo[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) lo[e] = t[e] - bf16_to_f32(f32_to_bf16(t[e]));
-          h[0] = pack_bf16x2(lo[0], lo[1]);
-          h[1] = pack_bf16x2(lo[2], lo[3]);
-        }
-        u32x4 x = {h[0], h[1], h[0], h[1]};
-        xf[i] = __builtin_bit_cast(bf16x8, x);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      const int row = (j * 8 + wave) * 16 + rsub;
+      const int lslot = pslot ^ ((row >> 2) & 3);
+      wsrc[j] = (const __bf16*)P.W + (size_t)min(n0 + row, N - 1) * P.ldw + lslot * 8;
     }
   }
-
-  // (2) transpose each 32x64 accumulator block through a wave-private LDS patch so that every global access of
-  //     the epilogue (bias, gate, residual read-modify-write, stores) is a coalesced 16-B-per-lane row access.
-  __syncthreads();                                   // every wave is done with the operand tiles
-  constexpr int EP_LD = 68;                          // fp32 row stride of the patch (64 + 4 pad)
-  float* patch = (float*)smem + wave * (32 * EP_LD);
+  const int nkt = K / BK2;
+  // Every wave issues exactly LOADS DMA instructions per call, so vmcnt arithmetic is uniform; tiles past the end of K
+  // re-read the last tile into a stage nobody consumes any more.
+  auto stage = [&](int kt) {
+    char* base = smem + (kt & (NST - 1)) * STAGE_BYTES;
+    const int k0 = min(kt, nkt - 1) * BK2;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+    for (int j = 0; j < AJ; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + k0), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  const int sw = (l31 >> 2) & 3;
+  int slot_off[2];
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        f32x4 v = {acc[j][i][rq * 4], acc[j][i][rq * 4 + 1], acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
-        *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
-      }
-    __builtin_amdgcn_wave_barrier();
-    const int mb = mw0 + i * 32;
-    if (epi == LX_EPI_STORE_BF16) {
-      const int c8 = (lane & 7) * 8, n = nw0 + c8;
+  for (int ks = 0; ks < 2; ++ks) slot_off[ks] = ((ks * 2 + lhi) ^ sw) * 16;
+  const int a_row_off = (wm * (BM / 2) + l31) * 64;
+  const int w_row_off = A_BYTES + (wn * 64 + l31) * 64;
+
+  f32x16 acc[2][MI];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = t * 8 + (lane >> 3), m = mb + row;
-        f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
-        f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
-        if (m < M && n < N) {
-          if (P.bias) {
-            const f32x4 b0 = *(const f32x4*)(P.bias + n), b1 = *(const f32x4*)(P.bias + n + 4);
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] += b0[c]; v1[c] += b1[c]; }
-          }
-          if (do_gelu && n >= P.gelu_col_start) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] = gelu_tanh(v0[c]); v1[c] = gelu_tanh(v1[c]); }
-          }
-          u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + n) = o;
-        }
-      }
-    } else {
-      const int c4 = (lane & 15) * 4, n = nw0 + c4;
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  auto load_frags = [&](const char* sb, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[MI]) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = t * 4 + (lane >> 4), m = mb + row;
-        f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
-        if (m < M && n < N) {
-          if (P.bias) {
-            const f32x4 bv = *(const f32x4*)(P.bias + n);
+    for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 64 + slot_off[ks]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += bv[c];
-          }
-          if (do_gelu && n >= P.gelu_col_start) {
+    for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 64 + slot_off[ks]);
+  };
+  auto mma_j = [&](int j, const bf16x8 (&wf)[2], const bf16x8 (&xf)[MI]) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
-          }
-          float* cp = (float*)P.C + (size_t)m * P.ldc + n;
-          if (epi == LX_EPI_RESID_F32) {
-            f32x4 o = *(const f32x4*)cp;
-            if (P.gate) {
-              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)(m / P.rows_per_batch) * P.gate_ld + n);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] += v[c];
-            }
-            v = o;
-          }
-          *(f32x4*)cp = v;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < MI; ++i)
+      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+  };
+
+  bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
+  stage(0);
+  stage(1);
+  stage(2);
+  stage(3);
+  // tile 0 landed <=> at most 3*LOADS of my DMA instructions outstanding
+  if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  load_frags(smem, 0, wfA, xfA);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* sb = smem + (kt & (NST - 1)) * STAGE_BYTES;
+    const char* sbn = smem + ((kt + 1) & (NST - 1)) * STAGE_BYTES;
+    // k-step 0 (set A), prefetching step 1 into set B
+    mma_j(0, wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(sb, 1, wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_j(1, wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    // tile kt+1 must have landed (tiles kt+2 and kt+3 stay in flight: 2*LOADS outstanding allowed), my reads of tile kt
+    // (both k-steps are in registers now) must be done, then everyone agrees.
+    if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 4);                                    // into the stage tile kt just vacated: 3 tiles (96 KiB) in flight
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (set B), prefetching step 0 of tile kt+1 into set A
+    mma_j(0, wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_j(1, wfB, xfB);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-reads before LDS is reused by the epilogue
+  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, wave, wm, wn, lane, l31, lhi);
 }
 
 int env_int(const char* name, int dflt) {
@@ -351,10 +521,14 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
   }
   for (int i = n; i <= LX_GEMM_MAX_GROUP; ++i) args.tile_start[i] = t;
   hipStream_t s = (hipStream_t)stream;
-  if (bm == 256)
-    hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, args);
-  else
-    hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, args);
+  const int ver = env_int("LX_GEMM_V", 1);
+  if (ver == 2) {
+    if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel_v2<256>, dim3(t), dim3(NTHREADS), 0, s, args);
+    else hipLaunchKernelGGL(lx_gemm_kernel_v2<128>, dim3(t), dim3(NTHREADS), 0, s, args);
+  } else {
+    if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, args);
+    else hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, args);
+  }
   LX_LAUNCH_CHECK("lx_gemm_bf16");
   return LX_OK;
 }

@@ -220,15 +220,18 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
 // operand (rows = r), X the "B" operand (cols = m): each lane ends with 4 consecutive r of one row m.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ A,
-                                                             float* __restrict__ T, int ldt, int M, int K, int R) {
+                                                             float* __restrict__ T, int ldt, int M, int K, int R, int Ks,
+                                                             int split_stride) {
   __shared__ f32x4 red[8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
+  const int kbeg = blockIdx.y * Ks, kend = min(K, kbeg + Ks);
+  T += (size_t)blockIdx.y * split_stride;
   const int l15 = lane & 15, kq = lane >> 4;
   const uint16_t* xp = X + (size_t)min(m0 + l15, M - 1) * ldx + kq * 8;
   const uint16_t* ap = A + (size_t)min(l15, R - 1) * K + kq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = wave * 32; k < K; k += 8 * 32) {
+  for (int k = kbeg + wave * 32; k < kend; k += 8 * 32) {
     const bf16x8 af = *(const bf16x8*)(ap + k);
     const bf16x8 xf = *(const bf16x8*)(xp + k);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, acc, 0, 0, 0);
@@ -428,13 +431,17 @@ extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_c
   return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_batches, H, eps, VT, vt_ld, stream);
 }
 
-extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, void* stream) {
+extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                            int split_stride, void* stream) {
   LX_CHECK_ARG(X && Adown && T && M > 0, "lx_lora_down: NULL operand");
   LX_CHECK_ARG(R >= 1 && R <= 16, "lx_lora_down: R=%d must be in [1,16]", R);
   LX_CHECK_ARG(K % 32 == 0 && ldx % 8 == 0 && ldt >= R, "lx_lora_down: K %% 32, ldx %% 8 and ldt >= R required (K=%d)", K);
   LX_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Adown & 15) == 0 && ((uintptr_t)T & 15) == 0, "lx_lora_down: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)X, ldx,
-                     (const uint16_t*)Adown, T, ldt, M, K, R);
+  LX_CHECK_ARG(n_split >= 1 && n_split <= 16 && (n_split == 1 || split_stride >= (M - 1) * ldt + R) && split_stride % 4 == 0,
+               "lx_lora_down: bad n_split=%d / split_stride=%d", n_split, split_stride);
+  const int Ks = ((K / 32 + n_split - 1) / n_split) * 32;
+  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)X, ldx,
+                     (const uint16_t*)Adown, T, ldt, M, K, R, Ks, split_stride);
   LX_LAUNCH_CHECK("lx_lora_down");
   return LX_OK;
 }

@@ -40,6 +40,9 @@ class DiTEngine:
             raise ValueError("the gfx950 attention kernel is specialised for head_dim 128 (FLUX.1)")
         self.shape = None
         self.cond_ready = False
+        self.graph = None
+        import os
+        self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
         self.model_config: Dict = {}
         self.c_factor: Optional[float] = None
 
@@ -59,7 +62,9 @@ class DiTEngine:
         self.Y = torch.zeros(M, 7 * D, dtype=bf16, device=dev)
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
-        self.TL = torch.zeros(M, 16, dtype=f32, device=dev)
+        self.TL_SPLIT = 4                                          # K-split slabs of the LoRA down-projection
+        self.TLs = torch.zeros(self.TL_SPLIT, M, 16, dtype=f32, device=dev)
+        self.TL = self.TLs[0]
         self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
         self.out = torch.zeros(B * N, cfg.in_channels, dtype=f32, device=dev)
         self.temb = torch.zeros(B, D, dtype=f32, device=dev)
@@ -74,6 +79,9 @@ class DiTEngine:
         self.tmod = torch.zeros(B, max(nb * cfg.lora_r, 4), dtype=f32, device=dev)
         self.X_txt_init = torch.zeros(max(B * T, 1), D, dtype=f32, device=dev)
         self.X_cond_init = torch.zeros(max(B * C, 1), D, dtype=f32, device=dev)
+        self.g_lat = torch.zeros(B, N, cfg.in_channels, dtype=f32, device=dev)
+        self.g_t = torch.zeros(B, dtype=f32, device=dev)
+        self.graph = None
         self.shape = (B, T, N, C)
         self.cond_ready = False
 
@@ -188,6 +196,7 @@ class DiTEngine:
             self._time_text_embed(ct, self.cond_temb, self.temb_base)
             self._compute_mods(self.cond_temb, self.cmods, lora=True)
         self.attn_bias = self._attn_bias()
+        self.graph = None            # the captured step bakes in this conditioning's code path (LoRA rows, bias table)
         self.cond_ready = True
 
     # ------------------------------------------------------------------------------------------ building blocks
@@ -214,7 +223,7 @@ class DiTEngine:
             return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
-        ops.lora_down(A[r0:r0 + n], lo.down, t)
+        ops.lora_down(A[r0:r0 + n], lo.down, t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
         return lo, r0
 
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
@@ -237,7 +246,7 @@ class DiTEngine:
                 row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
                 if row0 >= lr0:
                     kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up, lora_mod_cols=lora_mod_cols,
-                              lora_toff_max=lora_toff_max)
+                              lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, w.t[name + ".w"], c, **kw))
         ops.gemm(probs)
 
@@ -283,7 +292,8 @@ class DiTEngine:
         if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
             lo = w.lora.get(p + ".out")
             a = self.rows(Ya, "cond")
-            kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up) if lo is not None else {}
+            kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up, lora_nsplit=self.TL_SPLIT,
+                      lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
             ops.gemm([ops.gemm_desc(a, w.t[p + ".out.w"], self.rows(self.X, "img"), bias=w.t[p + ".out.b"], epilogue=LX_EPI_RESID_F32,
                                     rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)])
         self._ln(base, 3 * D, 4 * D)                                                       # norm2 + (scale_mlp, shift_mlp)
@@ -333,16 +343,35 @@ class DiTEngine:
                                 epilogue=LX_EPI_STORE_F32)])
         return self.out.view(self.B, self.N, cfg.in_channels)
 
-    def forward(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
-        """latents fp32 [B,N,in_channels], timestep [B] in 0..1 -> velocity fp32 [B,N,in_channels] (engine-owned buffer)."""
-        if not self.cond_ready:
-            raise RuntimeError("call set_conditioning() before forward()")
+    def _forward_eager(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
         self.embed_step_inputs(latents, timestep)
         for i in range(self.cfg.num_layers):
             self.double_block(i)
         for j in range(self.cfg.num_single_layers):
             self.single_block(j)
         return self.final_layer()
+
+    def forward(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """latents fp32 [B,N,in_channels], timestep [B] in 0..1 -> velocity fp32 [B,N,in_channels] (engine-owned buffer).
+
+        The ~600 kernel launches of a step are captured ONCE per conditioning into a HIP graph (all of them are enqueued
+        on torch's current stream through the C ABI, so stream capture sees them) and replayed for the remaining steps:
+        the launch-bound gaps between the short kernels disappear.  LX_GRAPH=0 disables capture."""
+        if not self.cond_ready:
+            raise RuntimeError("call set_conditioning() before forward()")
+        if not self.use_graph or ops.TIMER is not None:
+            return self._forward_eager(latents, timestep)
+        self.g_lat.copy_(latents.reshape(self.g_lat.shape))
+        self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
+        if self.graph is None:
+            self._forward_eager(self.g_lat, self.g_t)            # warm-up outside capture (lazy module loads, allocator)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward_eager(self.g_lat, self.g_t)
+            self.graph = g
+        self.graph.replay()
+        return self.out.view(self.B, self.N, self.cfg.in_channels)
 
     # ------------------------------------------------------------------------------------------ block-level entry points
     # (used by the reference-API mirrors in block.py: same arithmetic as forward(), driven one block at a time)
@@ -379,6 +408,7 @@ class DiTEngine:
     def configure(self, B, T, N, C, model_config=None, c_factor=None, rope_main=None, rope_cond=None) -> None:
         """Shape + config + RoPE tables without the prompt/condition embedders (block-level use)."""
         self.setup(B, T, N, C)
+        self.graph = None
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))

@@ -32,7 +32,7 @@ def _req(t: torch.Tensor, dtype, name: str):
 
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
               gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
-              gelu_col_start=0, M=None, N=None, K=None) -> GemmDesc:
+              gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0) -> GemmDesc:
     """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome)."""
     _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
     d = GemmDesc()
@@ -49,6 +49,7 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
     if lora_t is not None:
         d.lora_r, d.lora_ldt = lora_up.shape[1], lora_t.stride(0)
     d.lora_mod_cols, d.lora_toff_max = lora_mod_cols, lora_toff_max
+    d.lora_nsplit, d.lora_split_stride = lora_nsplit, lora_split_stride
     d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
     want = torch.bfloat16 if (epilogue & 0xff) == LX_EPI_STORE_BF16 else torch.float32
     _req(C_, want, "C")
@@ -90,10 +91,11 @@ def gemm(problems: Sequence[GemmDesc]) -> None:
     check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
 
 
-def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor) -> None:
+def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor, n_split: int = 1, split_stride: int = 0) -> None:
+    """T (slab 0) [M,R] fp32; with n_split > 1 slab s lives split_stride floats further (same row stride)."""
     _req(X, torch.bfloat16, "X"); _req(Adown, torch.bfloat16, "Adown"); _req(T, torch.float32, "T")
     check(lib.lx_lora_down(X.data_ptr(), X.stride(0), Adown.data_ptr(), T.data_ptr(), T.stride(0), X.shape[0], X.shape[1],
-                           Adown.shape[0], _stream()), "lx_lora_down")
+                           Adown.shape[0], n_split, split_stride, _stream()), "lx_lora_down")
 
 
 def linear_skinny(X, W, bias, Y, act_in=0, act_out=0, accumulate=False) -> None:

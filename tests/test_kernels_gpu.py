@@ -126,6 +126,23 @@ def test_gemm_lora_module_offsets(ops):
     assert relerr(Cc.cpu(), ref.cpu()) < 2e-5
 
 
+def test_lora_down_ksplit_slabs(ops):
+    """K-split partial slabs: the GEMM epilogue must add them up to the unsplit result."""
+    M, K, r, N = 300, 1024, 4, 256
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    Ad = rnd(r, K, seed=3, scale=0.1, dtype=torch.bfloat16)
+    Bu = rnd(N, r, seed=4, scale=0.2)
+    slabs = torch.full((4, M, 16), float("nan"), device=DEV)
+    ops.lora_down(A, Ad, slabs[0, :, :r], n_split=4, split_stride=slabs.stride(0))
+    t = A.float() @ Ad.float().T
+    assert relerr(slabs[:, :, :r].sum(0).cpu(), t.cpu()) < 1e-5
+    Cc = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, epilogue=ops.LX_EPI_STORE_F32, lora_t=slabs[0, :, :r], lora_up=Bu, lora_nsplit=4,
+                            lora_split_stride=slabs.stride(0))])
+    assert relerr(Cc.cpu(), (A.float() @ W.float().T + t @ Bu.T).cpu()) < 2e-5
+
+
 def test_gemm_rejects_bad_k(ops):
     A = rnd(64, 96, dtype=torch.bfloat16)
     W = rnd(64, 96, dtype=torch.bfloat16)
