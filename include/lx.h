@@ -54,7 +54,9 @@ enum {
   LX_EPI_STORE_BF16 = 0, /* C(bf16)  = act(acc + bias)                      */
   LX_EPI_STORE_F32 = 1,  /* C(fp32)  = acc + bias                           */
   LX_EPI_RESID_F32 = 2,  /* C(fp32) += gate[m / rows_per_batch, n] * (acc + bias)   (gate NULL => 1) */
-  LX_EPI_GELU = 0x100    /* OR-able flag: GELU(tanh) on columns n >= gelu_col_start */
+  LX_EPI_GELU = 0x100,   /* OR-able flag: GELU(tanh) on columns n >= gelu_col_start */
+  LX_W_TILED = 0x200     /* OR-able flag: W is pre-tiled (see lx_tile_weight_layout): [N/256][K/64] blocks of 256x64,
+                            each stored as the swizzled LDS image the kernel consumes; needs N % 256 == 0, ldw == K */
 };
 
 typedef struct lx_gemm_desc {

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (import order is load-bearing)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
-LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU = 0, 1, 2, 0x100
+LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED = 0, 1, 2, 0x100, 0x200
 LX_GEMM_MAX_GROUP = 4
 
 

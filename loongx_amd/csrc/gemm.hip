@@ -28,9 +28,12 @@ constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int GROUP_M = 4;
 
+constexpr int MAX_SUB = 2 * LX_GEMM_MAX_GROUP;   // a problem may be split into a 256-row-tile part and a 128-row-tile tail
+
 struct GemmArgs {
-  lx_gemm_desc p[LX_GEMM_MAX_GROUP];
-  int tile_start[LX_GEMM_MAX_GROUP + 1];
+  lx_gemm_desc p[MAX_SUB];
+  int tile_start[MAX_SUB + 1];
+  int m_base[MAX_SUB];       // row of the original problem at which this (sub)problem starts (for the gate batch index)
   int n;
 };
 
@@ -39,8 +42,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
 template <int BM, int MI>
-__device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int wave,
-                                              int wm, int wn, int lane, int l31, int lhi) {
+__device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
+                                              int wave, int wm, int wn, int lane, int l31, int lhi) {
   const int M = P.M, N = P.N;
   // ---- epilogue ----------------------------------------------------------------------------------
   // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
@@ -163,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
           if (epi == LX_EPI_RESID_F32) {
             f32x4 o = *(const f32x4*)cp;
             if (P.gate) {
-              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)(m / P.rows_per_batch) * P.gate_ld + n);
+              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + n);
 #pragma unroll
               for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
             } else {
@@ -205,9 +208,10 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   }
   int g = 0;
 #pragma unroll
-  for (int i = 1; i < LX_GEMM_MAX_GROUP; ++i)
+  for (int i = 1; i < MAX_SUB; ++i)
     if (i < args.n && lid >= args.tile_start[i]) g = i;
   const lx_gemm_desc& P = args.p[g];
+  const int m_base = args.m_base[g];
   const int local = lid - args.tile_start[g];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   }
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = P.M, N = P.N, K = P.K;
+  const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
 
   // ---- per-lane source pointers for the global->LDS stage ----------------------------------------
   // one global_load_lds moves 1 KiB per wave = 8 tile rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
@@ -236,23 +241,32 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
       const int gm_ = min(m0 + row, M - 1);
       asrc[j] = (const __bf16*)P.A + (size_t)gm_ * P.lda + lslot * 8;
     }
+    // W: either nn.Linear row-major [N,K], or (LX_W_TILED) pre-tiled at load time into the LDS image itself:
+    // [N/256][K/64] blocks of 32 KiB, rows of 128 B with the XOR swizzle already applied, so a stage is ONE
+    // contiguous 32 KiB read (DRAM-page / TLB friendly when the weights stream cold from HBM) copied verbatim.
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = (j * 8 + wave) * 8 + rsub;
-      const int lslot = pslot ^ ((row >> 1) & 7);
-      const int gn_ = min(n0 + row, N - 1);
-      wsrc[j] = (const __bf16*)P.W + (size_t)gn_ * P.ldw + lslot * 8;
+      if (w_tiled) {
+        wsrc[j] = (const __bf16*)P.W + ((size_t)tn * (K / BK)) * (BN * BK) + ((j * 8 + wave) * 512 + lane * 8);
+      } else {
+        const int row = (j * 8 + wave) * 8 + rsub;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        const int gn_ = min(n0 + row, N - 1);
+        wsrc[j] = (const __bf16*)P.W + (size_t)gn_ * P.ldw + lslot * 8;
+      }
     }
   }
+  const int w_kstride = w_tiled ? BN * BK : BK;       // elements between consecutive K tiles of the W operand
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE_BYTES;
     const int k0 = kt * BK;
 #pragma unroll
     for (int j = 0; j < MI; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + k0), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+    const size_t wk = (size_t)kt * w_kstride;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + wk), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
   };
 
   // ---- fragment read offsets -----------------------------------------------------------------------
@@ -288,7 +302,6 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
       acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
   };
   const int nkt = K / BK;
-  const bool split = (P.epilogue & 0x2000) == 0;     // 0x2000: debug, disable the DMA role split
   bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
   stage(0, 0);
   if (nkt > 1) stage(1, 1);
@@ -300,11 +313,15 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   // reads issued a whole group earlier (it is conservative across the loop back-edge and would otherwise stall on
   // the reads just issued).
 #define LX_STEP(CUR_W, CUR_X, NEXT_STMT)            \
+  __builtin_amdgcn_s_setprio(1);                    \
   mma_j(0, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_s_setprio(0);                    \
   __builtin_amdgcn_sched_barrier(0);                \
   NEXT_STMT;                                        \
   __builtin_amdgcn_sched_barrier(0);                \
+  __builtin_amdgcn_s_setprio(1);                    \
   mma_j(1, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_s_setprio(0);                    \
   __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const char* sb = smem + (kt & 1) * STAGE_BYTES;
@@ -316,167 +333,17 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     __syncthreads();                                    // ... and every wave is done reading tile kt
     // Role split: waves w and w+4 share a SIMD. The lower half issues its 8 DMA pieces right behind the barrier while
     // its SIMD partner runs MFMAs; the upper half runs step 3 first and issues its pieces afterwards. (Issuing from
-    // both at once leaves the matrix pipe idle for the ~1000 cycles the LDS-DMA issue costs.)
-    const bool dma = kt + 2 < nkt && !(P.epilogue & 0x1000);   // 0x1000: debug, skip in-loop DMA
-    if (dma && (wm == 0 || !split)) stage(kt + 2, kt & 1);
+    // both at once leaves the matrix pipe idle while the LDS-DMA pieces issue: measured +5 %.)
+    const bool dma = kt + 2 < nkt;
+    if (dma && wm == 0) stage(kt + 2, kt & 1);
     __builtin_amdgcn_sched_barrier(0);
     LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA))
-    if (dma && wm == 1 && split) stage(kt + 2, kt & 1);
+    if (dma && wm == 1) stage(kt + 2, kt & 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef LX_STEP
 
-  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, wave, wm, wn, lane, l31, lhi);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// v2 main loop: BK = 32, FOUR LDS stages. Three K tiles are in flight while one is consumed (96 KiB of DMA per CU
-// instead of 64 at BM=256), tracked with a counted `s_waitcnt vmcnt` and a raw s_barrier so outstanding DMA is never
-// drained. Motivation (measured): with 2 stages the loop ran 1.85 us per 64-deep K tile against 1.34 us with the DMA
-// disabled -- L2/HBM->LDS latency, not MFMA or LDS bandwidth, was the limiter.
-// LDS rows are 64 B; the 16-B slot index is XORed with (row>>2)&3 (conflict-free for the ds_read_b128 lane groups).
-// ---------------------------------------------------------------------------------------------------------------
-template <int BM>
-__global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel_v2(const GemmArgs args) {
-  constexpr int MI = BM / 64;
-  constexpr int BK2 = 32;
-  constexpr int NST = 4;
-  constexpr int A_BYTES = BM * BK2 * 2;
-  constexpr int W_BYTES = BN * BK2 * 2;
-  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int AJ = BM / 128;                // global_load_lds per wave per stage for A (16 rows of 64 B each)
-  constexpr int LOADS = AJ + 2;               // ... plus 2 for W
-  static_assert(NST * STAGE_BYTES >= 8 * 32 * 68 * 4, "epilogue patch must fit");
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE_BYTES];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int total = args.tile_start[args.n];
-  int lid;
-  {
-    const int pid = blockIdx.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = pid & 7, inx = pid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
-  }
-  int g = 0;
-#pragma unroll
-  for (int i = 1; i < LX_GEMM_MAX_GROUP; ++i)
-    if (i < args.n && lid >= args.tile_start[i]) g = i;
-  const lx_gemm_desc& P = args.p[g];
-  const int local = lid - args.tile_start[g];
-  const int tiles_m = (P.M + BM - 1) / BM;
-  const int tiles_n = (P.N + BN - 1) / BN;
-  int tm, tn;
-  {
-    const int gs = GROUP_M * tiles_n;
-    const int gi = local / gs, in_g = local - gi * gs;
-    const int first_m = gi * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    tm = first_m + in_g % gm;
-    tn = in_g / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int M = P.M, N = P.N, K = P.K;
-
-  const __bf16* asrc[AJ];
-  const __bf16* wsrc[2];
-  {
-    const int rsub = lane >> 2, pslot = lane & 3;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int row = (j * 8 + wave) * 16 + rsub;
-      const int lslot = pslot ^ ((row >> 2) & 3);
-      asrc[j] = (const __bf16*)P.A + (size_t)min(m0 + row, M - 1) * P.lda + lslot * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = (j * 8 + wave) * 16 + rsub;
-      const int lslot = pslot ^ ((row >> 2) & 3);
-      wsrc[j] = (const __bf16*)P.W + (size_t)min(n0 + row, N - 1) * P.ldw + lslot * 8;
-    }
-  }
-  const int nkt = K / BK2;
-  // Every wave issues exactly LOADS DMA instructions per call, so vmcnt arithmetic is uniform; tiles past the end of K
-  // re-read the last tile into a stage nobody consumes any more.
-  auto stage = [&](int kt) {
-    char* base = smem + (kt & (NST - 1)) * STAGE_BYTES;
-    const int k0 = min(kt, nkt - 1) * BK2;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + k0), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
-  };
-
-  const int sw = (l31 >> 2) & 3;
-  int slot_off[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) slot_off[ks] = ((ks * 2 + lhi) ^ sw) * 16;
-  const int a_row_off = (wm * (BM / 2) + l31) * 64;
-  const int w_row_off = A_BYTES + (wn * 64 + l31) * 64;
-
-  f32x16 acc[2][MI];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  auto load_frags = [&](const char* sb, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[MI]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 64 + slot_off[ks]);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 64 + slot_off[ks]);
-  };
-  auto mma_j = [&](int j, const bf16x8 (&wf)[2], const bf16x8 (&xf)[MI]) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
-  };
-
-  bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
-  stage(0);
-  stage(1);
-  stage(2);
-  stage(3);
-  // tile 0 landed <=> at most 3*LOADS of my DMA instructions outstanding
-  if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  load_frags(smem, 0, wfA, xfA);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* sb = smem + (kt & (NST - 1)) * STAGE_BYTES;
-    const char* sbn = smem + ((kt + 1) & (NST - 1)) * STAGE_BYTES;
-    // k-step 0 (set A), prefetching step 1 into set B
-    mma_j(0, wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags(sb, 1, wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_j(1, wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
-    // tile kt+1 must have landed (tiles kt+2 and kt+3 stay in flight: 2*LOADS outstanding allowed), my reads of tile kt
-    // (both k-steps are in registers now) must be done, then everyone agrees.
-    if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 4);                                    // into the stage tile kt just vacated: 3 tiles (96 KiB) in flight
-    __builtin_amdgcn_sched_barrier(0);
-    // k-step 1 (set B), prefetching step 0 of tile kt+1 into set A
-    mma_j(0, wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_j(1, wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-reads before LDS is reused by the epilogue
-  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, wave, wm, wn, lane, l31, lhi);
+  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
 }
 
 int env_int(const char* name, int dflt) {
@@ -486,11 +353,45 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+// ---- launch planning ---------------------------------------------------------------------------------------------
+// One workgroup per CU, so a launch runs in "rounds" of 256 tiles. Per-round cost model calibrated on MI355X with
+// rocprofv3 kernel durations over a K sweep (tools/gemm_ksweep.py): fixed (launch + prologue + epilogue burst) plus a
+// per-64-deep-K-tile slope at full occupancy.
+static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
+
+static long tiles_of(const lx_gemm_desc& p, int bm) { return (long)((p.M + bm - 1) / bm) * ((p.N + BN - 1) / BN); }
+
+static lx_gemm_desc sub_rows(const lx_gemm_desc& p, int r0, int rows) {   // rows [r0, r0+rows) of a problem
+  lx_gemm_desc q = p;
+  q.A = (const uint16_t*)p.A + (size_t)r0 * p.lda;
+  const int epi = p.epilogue & 0xff;
+  q.C = epi == LX_EPI_STORE_BF16 ? (void*)((uint16_t*)p.C + (size_t)r0 * p.ldc) : (void*)((float*)p.C + (size_t)r0 * p.ldc);
+  if (p.lora_t) q.lora_t = p.lora_t + (size_t)r0 * p.lora_ldt;
+  q.M = rows;
+  return q;
+}
+
+static int launch_plan(const GemmArgs& a, int bm, hipStream_t s) {
+  if (a.n == 0) return LX_OK;
+  const int t = a.tile_start[a.n];
+  if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, a);
+  LX_LAUNCH_CHECK("lx_gemm_bf16");
+  return LX_OK;
+}
+
+static void plan_add(GemmArgs& a, const lx_gemm_desc& p, int m_base, int bm) {
+  a.p[a.n] = p;
+  a.m_base[a.n] = m_base;
+  a.tile_start[a.n + 1] = a.tile_start[a.n] + (int)tiles_of(p, bm);
+  ++a.n;
+  for (int i = a.n + 1; i <= MAX_SUB; ++i) a.tile_start[i] = a.tile_start[a.n];
+}
+
 extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
   LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
-  GemmArgs args;
-  args.n = n;
-  long tiles256 = 0;
+  long t256 = 0, t128 = 0;
+  int kmax = 0;
   for (int i = 0; i < n; ++i) {
     const lx_gemm_desc& p = problems[i];
     LX_CHECK_ARG(p.A && p.W && p.C, "lx_gemm_bf16[%d]: NULL operand", i);
@@ -499,36 +400,67 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
     LX_CHECK_ARG(p.N % 8 == 0, "lx_gemm_bf16[%d]: N=%d must be a multiple of 8", i, p.N);
     LX_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.lda >= p.K && p.ldw >= p.K, "lx_gemm_bf16[%d]: lda/ldw must be >= K and multiples of 8", i);
     LX_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "lx_gemm_bf16[%d]: operands must be 16-byte aligned", i);
-    LX_CHECK_ARG(p.ldc % 8 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 4", i, p.ldc);
+    LX_CHECK_ARG(p.ldc % 8 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 8", i, p.ldc);
     const int epi = p.epilogue & 0xff;
     LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && epi <= LX_EPI_RESID_F32, "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
     LX_CHECK_ARG(p.rows_per_batch > 0, "lx_gemm_bf16[%d]: rows_per_batch must be > 0", i);
+    if (p.epilogue & LX_W_TILED) LX_CHECK_ARG(p.N % BN == 0 && p.ldw == p.K, "lx_gemm_bf16[%d]: LX_W_TILED needs N %% 256 == 0 and ldw == K", i);
     if (p.gate) LX_CHECK_ARG(p.gate_ld >= p.N && p.gate_ld % 4 == 0, "lx_gemm_bf16[%d]: gate_ld=%d", i, p.gate_ld);
     if (p.lora_t) {
       LX_CHECK_ARG(p.lora_up && p.lora_r >= 1 && p.lora_r <= 16, "lx_gemm_bf16[%d]: LoRA needs lora_up and 1 <= r <= 16", i);
       LX_CHECK_ARG(p.lora_mod_cols <= 0 || p.lora_mod_cols % BN == 0, "lx_gemm_bf16[%d]: lora_mod_cols must be a multiple of %d", i, BN);
     }
     if (p.bias) LX_CHECK_ARG(((uintptr_t)p.bias & 15) == 0, "lx_gemm_bf16[%d]: bias must be 16-byte aligned", i);
-    args.p[i] = p;
-    tiles256 += (long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    t256 += tiles_of(p, 256);
+    t128 += tiles_of(p, 128);
+    kmax = p.K > kmax ? p.K : kmax;
   }
-  int bm = env_int("LX_GEMM_BM", 0);
-  if (bm != 128 && bm != 256) bm = (tiles256 < 208) ? 128 : 256;  // < ~0.8 of 256 CUs: halve the tile to fill the chip
-  int t = 0;
-  for (int i = 0; i < n; ++i) {
-    args.tile_start[i] = t;
-    t += ((problems[i].M + bm - 1) / bm) * ((problems[i].N + BN - 1) / BN);
-  }
-  for (int i = n; i <= LX_GEMM_MAX_GROUP; ++i) args.tile_start[i] = t;
   hipStream_t s = (hipStream_t)stream;
-  const int ver = env_int("LX_GEMM_V", 1);
-  if (ver == 2) {
-    if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel_v2<256>, dim3(t), dim3(NTHREADS), 0, s, args);
-    else hipLaunchKernelGGL(lx_gemm_kernel_v2<128>, dim3(t), dim3(NTHREADS), 0, s, args);
-  } else {
-    if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, args);
-    else hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, args);
+  const int NCU = 256;
+  const int forced = env_int("LX_GEMM_BM", 0);      // 256 | 128 | 0 = plan
+  // candidate schedules: all 256-row tiles, all 128-row tiles, or full rounds of 256-row tiles + a 128-row-tile tail
+  const double c_a = (double)((t256 + NCU - 1) / NCU) * round_us(256, kmax);
+  const double c_b = (double)((t128 + NCU - 1) / NCU) * round_us(128, kmax);
+  GemmArgs big, tail;
+  big.n = tail.n = 0;
+  big.tile_start[0] = tail.tile_start[0] = 0;
+  for (int i = 1; i <= MAX_SUB; ++i) big.tile_start[i] = tail.tile_start[i] = 0;
+  double c_c = 1e30;
+  const long full = (t256 / NCU) * NCU;
+  if (forced == 0 && full > 0 && t256 > full) {
+    // peel 256-row tile-rows off the ends of the problems (last problem first) until the big launch fits in full rounds
+    long remain = t256;
+    int keep_rows[LX_GEMM_MAX_GROUP];
+    for (int i = 0; i < n; ++i) keep_rows[i] = problems[i].M;
+    for (int i = n - 1; i >= 0 && remain > full; --i) {
+      const int tn = (problems[i].N + BN - 1) / BN;
+      while (remain > full && keep_rows[i] > 0) {
+        const int last_rows = keep_rows[i] % 256 ? keep_rows[i] % 256 : 256;
+        keep_rows[i] -= last_rows;
+        remain -= tn;
+      }
+    }
+    long tail_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+      if (keep_rows[i] > 0) plan_add(big, sub_rows(problems[i], 0, keep_rows[i]), 0, 256);
+      if (keep_rows[i] < problems[i].M) {
+        const lx_gemm_desc q = sub_rows(problems[i], keep_rows[i], problems[i].M - keep_rows[i]);
+        plan_add(tail, q, keep_rows[i], 128);
+        tail_tiles += tiles_of(q, 128);
+      }
+    }
+    c_c = (double)((remain + NCU - 1) / NCU) * round_us(256, kmax) + (double)((tail_tiles + NCU - 1) / NCU) * round_us(128, kmax) + 2.0;
   }
-  LX_LAUNCH_CHECK("lx_gemm_bf16");
-  return LX_OK;
+  int choice = forced == 256 ? 0 : forced == 128 ? 1 : (c_c < c_a && c_c < c_b) ? 2 : (c_b < c_a ? 1 : 0);
+  if (choice == 2) {
+    const int rc = launch_plan(big, 256, s);
+    if (rc != LX_OK) return rc;
+    return launch_plan(tail, 128, s);
+  }
+  GemmArgs all;
+  all.n = 0;
+  all.tile_start[0] = 0;
+  for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+  for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, choice == 0 ? 256 : 128);
+  return launch_plan(all, choice == 0 ? 256 : 128, s);
 }

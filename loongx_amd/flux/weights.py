@@ -20,10 +20,24 @@ Fused layout (D = heads*128, r = LoRA rank; all GEMM weights bf16 [out, in], bia
 from __future__ import annotations
 
 import re
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
+
+_GEMM_WEIGHTS = re.compile(r"^(d\d+\.(qkv|qkv_txt|out|out_txt|ff1|ff1_txt|ff2|ff2_txt)|s\d+\.(fused|out)|x_embedder|context_embedder)$")
+
+
+def _maybe_tile(name: str, w: torch.Tensor) -> torch.Tensor:
+    """GEMM-consumed weights are stored pre-tiled (ops.tile_weight: the kernel's LDS image, one contiguous 32 KiB block
+    per K tile) so they stream from HBM with DRAM-page locality. LX_TILE_W=0 keeps nn.Linear row-major."""
+    if os.environ.get("LX_TILE_W", "1") == "0" or not _GEMM_WEIGHTS.match(name):
+        return w
+    if w.shape[0] % 256 or w.shape[1] % 64:
+        return w
+    from ..ops import tile_weight
+    return tile_weight(w)
 
 
 @dataclass
@@ -132,7 +146,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
         return Lora(down, up)
 
     def put(name, w_names, out_sizes):
-        pw.t[name + ".w"] = W(w_names)
+        pw.t[name + ".w"] = _maybe_tile(name, W(w_names))
         pw.t[name + ".b"] = Bv(w_names, out_sizes)
         l = Lr(w_names)
         if l is not None:
@@ -195,7 +209,7 @@ def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02,
         return out
 
     def put(name, n_out, n_in, n_lora_mod=0):
-        pw.t[name + ".w"] = rn(n_out, n_in)
+        pw.t[name + ".w"] = _maybe_tile(name, rn(n_out, n_in))
         pw.t[name + ".b"] = torch.zeros(n_out, dtype=torch.float32, device=device)
         if lora and n_lora_mod:
             pw.lora[name] = Lora(rn(n_lora_mod * r, n_in), rn(n_out, r, dtype=torch.float32))

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, AttnDesc, GemmDesc, check, lib)
+from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_W_TILED, AttnDesc, GemmDesc, check, lib)
 
 
 def _stream() -> int:
@@ -28,6 +28,21 @@ def _req(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_cuda:
         raise ValueError(f"{name}: must live on the GPU (the hot path has no CPU fallback)")
+
+
+def tile_weight(W: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N,K] bf16 (N % 256 == 0, K % 64 == 0) -> the pre-tiled layout LX_W_TILED expects, same shape/bytes:
+    [N/256][K/64] blocks of 256 rows x 64 cols; inside a block row r, the 16-B chunk c sits at position c ^ ((r>>1)&7)
+    (the LDS swizzle of gemm.hip), so the kernel's global->LDS DMA copies a block verbatim. Pure layout plumbing."""
+    N, K = W.shape
+    assert N % 256 == 0 and K % 64 == 0 and W.dtype == torch.bfloat16
+    t = W.reshape(N // 256, 256, K // 64, 8, 8).permute(0, 2, 1, 3, 4)            # [nb, kb, row, chunk, 8]
+    r = torch.arange(256, device=W.device)
+    src = torch.arange(8, device=W.device)[None, :] ^ ((r >> 1) & 7)[:, None]    # position p holds chunk p ^ f(r)
+    t = t[:, :, r[:, None], src]                                                  # gather chunks per row
+    out = t.contiguous().reshape(N, K)
+    out.lx_tiled = True
+    return out
 
 
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
@@ -50,6 +65,8 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         d.lora_r, d.lora_ldt = lora_up.shape[1], lora_t.stride(0)
     d.lora_mod_cols, d.lora_toff_max = lora_mod_cols, lora_toff_max
     d.lora_nsplit, d.lora_split_stride = lora_nsplit, lora_split_stride
+    if getattr(W, "lx_tiled", False):
+        epilogue |= LX_W_TILED
     d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
     want = torch.bfloat16 if (epilogue & 0xff) == LX_EPI_STORE_BF16 else torch.float32
     _req(C_, want, "C")

@@ -126,6 +126,47 @@ def test_gemm_lora_module_offsets(ops):
     assert relerr(Cc.cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("bm", [256, 128])
+def test_gemm_pretiled_weight(ops, bm, monkeypatch):
+    """LX_W_TILED: the load-time tiled/swizzled weight image must give bit-identical results to the row-major weight."""
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    M, N, K = 700, 768, 320
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3)
+    C1 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    C2 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, C1, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    Wt = ops.tile_weight(W)
+    assert Wt.shape == W.shape and not torch.equal(Wt, W)
+    ops.gemm([ops.gemm_desc(A, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    assert torch.equal(C1, C2)
+    assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
+
+
+def test_gemm_planner_mixed_tail(ops, monkeypatch):
+    """No LX_GEMM_BM override: 280 tiles of 256x256 -> the planner runs full rounds of 256-row tiles plus a 128-row-tile
+    tail launch. Gate batch index, LoRA rows and residual must stay right across the split."""
+    monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    M1, M2, N, K, r = 1536, 1024, 7168, 128, 4
+    A = rnd(M1 + M2, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3, scale=0.1)
+    X = rnd(M1 + M2, N, seed=4)
+    X0 = X.clone()
+    g1, g2 = rnd(3, N, seed=5), rnd(4, N, seed=6)            # 3 batches of 512 rows, 4 batches of 256 rows
+    Ad = rnd(r, K, seed=7, scale=0.1, dtype=torch.bfloat16)
+    Bu = rnd(N, r, seed=8, scale=0.1)
+    Tl = torch.empty(M2, r, dtype=torch.float32, device=DEV)
+    ops.lora_down(A[M1:], Ad, Tl)
+    ops.gemm([ops.gemm_desc(A[:M1], W, X[:M1], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g1, rows_per_batch=512),
+              ops.gemm_desc(A[M1:], W, X[M1:], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g2, rows_per_batch=256, lora_t=Tl, lora_up=Bu)])
+    y = A.float() @ W.float().T + bias
+    y[M1:] += (A[M1:].float() @ Ad.float().T) @ Bu.T
+    ref = X0 + y * torch.cat([g1.repeat_interleave(512, 0), g2.repeat_interleave(256, 0)])
+    assert relerr(X.cpu(), ref.cpu()) < 2e-5
+
+
 def test_lora_down_ksplit_slabs(ops):
     """K-split partial slabs: the GEMM epilogue must add them up to the unsplit result."""
     M, K, r, N = 300, 1024, 4, 256
