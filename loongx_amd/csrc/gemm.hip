@@ -189,7 +189,20 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+  // LDS rings. The activation operand A is L2/MALL-hot (just written by the previous kernel); the weight operand W streams
+  // cold from HBM and needs more lead (measured: long-K GEMMs lose 21-23 % with a single K tile of DMA in flight).
+  //   BM=128: A ring 3 x 16 KiB + W ring 3 x 32 KiB = 144 KiB: two K tiles of lead (long-K ff.net.2 / proj_out GEMMs:
+  //           cold-weight penalty 21-23 % -> 0).
+  //   BM=256: 2 x (32 + 32) KiB. A 3-deep W ring (160 KiB total) was measured: no gain at K=3072 (in-box A/B 43.6 vs
+  //           43.2 ms per step), so the wide-N GEMMs keep two stages.
+  // In-flight DMA is tracked with counted s_waitcnt vmcnt + a raw s_barrier (a __syncthreads() would drain it).
+  constexpr int NSA = BM == 128 ? 3 : 2;
+  constexpr int NSW = BM == 128 ? 3 : 2;
+  constexpr int W_BASE = NSA * A_BYTES;
+  constexpr int WAIT_STEADY = BM == 128 ? MI + 4 : (NSW == 3 ? 4 : 0);   // DMA instructions allowed in flight across the K-tile barrier
+  static_assert(W_BASE + NSW * W_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(W_BASE + NSW * W_BYTES >= 8 * 32 * 68 * 4, "epilogue patch must fit");
+  __shared__ __attribute__((aligned(1024))) char smem[W_BASE + NSW * W_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -257,16 +270,19 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     }
   }
   const int w_kstride = w_tiled ? BN * BK : BK;       // elements between consecutive K tiles of the W operand
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * STAGE_BYTES;
+  auto stage_a = [&](int kt, int slot) {
+    char* base = smem + slot * A_BYTES;
     const int k0 = kt * BK;
 #pragma unroll
     for (int j = 0; j < MI; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + k0), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+  auto stage_w = [&](int kt, int slot) {
+    char* base = smem + W_BASE + slot * W_BYTES;
     const size_t wk = (size_t)kt * w_kstride;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + wk), (lptr_t)(base + A_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + wk), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
   };
 
   // ---- fragment read offsets -----------------------------------------------------------------------
@@ -275,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) slot_off[ks] = ((ks * 2 + lhi) ^ sw) * 16;
   const int a_row_off = (wm * (BM / 2) + l31) * 128;
-  const int w_row_off = A_BYTES + (wn * 64 + l31) * 128;
+  const int w_row_off = (wn * 64 + l31) * 128;
 
   f32x16 acc[2][MI];
 #pragma unroll
@@ -290,11 +306,13 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   // the LDS reads of step s+1 are issued BEFORE the MFMAs of step s.  The single barrier of a K tile sits between
   // steps 2 and 3, where every wave still holds 8 MFMAs of ready work: behind it the DMA of tile kt+2 is issued
   // into the buffer tile kt just vacated and the first fragments of tile kt+1 are fetched under step 3's MFMAs.
-  auto load_frags = [&](const char* sb, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[MI]) {
+  auto load_frags = [&](int sa, int sw_, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[MI]) {
+    const char* pa = smem + sa * A_BYTES + a_row_off + slot_off[ks];
+    const char* pw = smem + W_BASE + sw_ * W_BYTES + w_row_off + slot_off[ks];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(sb + w_row_off + j * 32 * 128 + slot_off[ks]);
+    for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(pw + j * 32 * 128);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * 128 + slot_off[ks]);
+    for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(pa + i * 32 * 128);
   };
   auto mma_j = [&](int j, const bf16x8 (&wf)[2], const bf16x8 (&xf)[MI]) {
 #pragma unroll
@@ -303,11 +321,21 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   };
   const int nkt = K / BK;
   bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
-  stage(0, 0);
-  if (nkt > 1) stage(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // prologue: A tiles 0..NSA-1 and W tiles 0..NSW-1 in (A0 W0 A1 W1 [A2] W2) order; wait only for tile 0
+  {
+    stage_a(0, 0);
+    stage_w(0, 0);
+    if (nkt > 1) { stage_a(1, 1); stage_w(1, 1); }
+    if (nkt > 2) { if constexpr (NSA > 2) stage_a(2, 2); if constexpr (NSW > 2) stage_w(2, 2); }
+    if (nkt > 2 && NSW > 2) {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // BM=128: A1 W1 A2 W2 / BM=256: A1 W1 W2 may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    static_assert((BM == 128 && 2 * (MI + 4) == 12) || (BM == 256 && MI + 4 + 4 == 12), "prologue wait count");
+  }
   __syncthreads();
-  load_frags(smem, 0, wfA, xfA);
+  load_frags(0, 0, 0, wfA, xfA);
   // One k step = [MI MFMAs] [6 LDS reads for the NEXT step] [MI MFMAs]; sched_barrier(0) pins that order.  The reads sit
   // in the middle of an MFMA group so that the wait hipcc places in front of a group's first MFMA only ever covers
   // reads issued a whole group earlier (it is conservative across the loop back-edge and would otherwise stall on
@@ -323,23 +351,41 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   mma_j(1, CUR_W, CUR_X);                           \
   __builtin_amdgcn_s_setprio(0);                    \
   __builtin_amdgcn_sched_barrier(0);
+  int ca = 0, cw = 0;                                  // ring slots of tile kt
   for (int kt = 0; kt < nkt; ++kt) {
-    const char* sb = smem + (kt & 1) * STAGE_BYTES;
-    const char* sbn = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    LX_STEP(wfA, xfA, load_frags(sb, 1, wfB, xfB))
-    LX_STEP(wfB, xfB, load_frags(sb, 2, wfA, xfA))
-    LX_STEP(wfA, xfA, load_frags(sb, 3, wfB, xfB))
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 (issued one K tile ago) has landed
-    __syncthreads();                                    // ... and every wave is done reading tile kt
-    // Role split: waves w and w+4 share a SIMD. The lower half issues its 8 DMA pieces right behind the barrier while
+    const int na = ca + 1 == NSA ? 0 : ca + 1;
+    const int nw = cw + 1 == NSW ? 0 : cw + 1;
+    LX_STEP(wfA, xfA, load_frags(ca, cw, 1, wfB, xfB))
+    LX_STEP(wfB, xfB, load_frags(ca, cw, 2, wfA, xfA))
+    LX_STEP(wfA, xfA, load_frags(ca, cw, 3, wfB, xfB))
+    // Tile kt+1 (A and W) must have landed: everything older than the last WAIT_STEADY DMA instructions this wave issued
+    // (= the W [and A] pieces of tile kt+2) is then complete. My LDS reads of tile kt are done (both k-steps are in
+    // registers). Then the raw barrier makes that true for every wave.
+    if (kt + 2 < nkt && WAIT_STEADY > 0) {
+      if constexpr (WAIT_STEADY == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // Role split: waves w and w+4 share a SIMD. The lower half issues its DMA pieces right behind the barrier while
     // its SIMD partner runs MFMAs; the upper half runs step 3 first and issues its pieces afterwards. (Issuing from
-    // both at once leaves the matrix pipe idle while the LDS-DMA pieces issue: measured +5 %.)
-    const bool dma = kt + 2 < nkt;
-    if (dma && wm == 0) stage(kt + 2, kt & 1);
+    // both at once leaves the matrix pipe idle while the LDS-DMA pieces issue: measured +5 %.)  A goes first, W second:
+    // the counted wait above relies on that order.
+    if (wm == 0) {
+      if (kt + NSA < nkt) stage_a(kt + NSA, ca);       // into the slots tile kt just vacated
+      if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(sbn, 0, wfA, xfA))
-    if (dma && wm == 1) stage(kt + 2, kt & 1);
+    LX_STEP(wfB, xfB, if (kt + 1 < nkt) load_frags(na, nw, 0, wfA, xfA))
+    if (wm == 1) {
+      if (kt + NSA < nkt) stage_a(kt + NSA, ca);
+      if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    ca = na;
+    cw = nw;
   }
 #undef LX_STEP
 

@@ -41,6 +41,8 @@ class DiTEngine:
         self.shape = None
         self.cond_ready = False
         self.graph = None
+        self.graph_key = None
+        self._warmed = False
         import os
         self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
         self.model_config: Dict = {}
@@ -79,6 +81,9 @@ class DiTEngine:
         self.tmod = torch.zeros(B, max(nb * cfg.lora_r, 4), dtype=f32, device=dev)
         self.X_txt_init = torch.zeros(max(B * T, 1), D, dtype=f32, device=dev)
         self.X_cond_init = torch.zeros(max(B * C, 1), D, dtype=f32, device=dev)
+        rd = sum(cfg.axes_dims_rope)
+        self.rope_main = torch.zeros(2, T + N, rd, dtype=f32, device=dev)
+        self.rope_cond = torch.zeros(2, max(C, 1), rd, dtype=f32, device=dev)
         self.g_lat = torch.zeros(B, N, cfg.in_channels, dtype=f32, device=dev)
         self.g_t = torch.zeros(B, dtype=f32, device=dev)
         self.graph = None
@@ -176,9 +181,11 @@ class DiTEngine:
                                     lora_t=tl, lora_up=lo.up if lo is not None else None)])
         # RoPE tables: [text; image] and condition (transformer.py:130-134)
         ids = torch.cat([txt_ids.to(dev, f32).reshape(-1, 3), img_ids.to(dev, f32).reshape(-1, 3)], 0)
-        self.cos_main, self.sin_main = ops.rope_table(ids, cfg.axes_dims_rope)
+        # tables live in persistent buffers: the captured step graph holds their addresses
+        self.cos_main, self.sin_main = ops.rope_table(ids, cfg.axes_dims_rope, out=(self.rope_main[0], self.rope_main[1]))
         if C:
-            self.cos_cond, self.sin_cond = ops.rope_table(condition_ids.to(dev, f32).reshape(-1, 3), cfg.axes_dims_rope)
+            self.cos_cond, self.sin_cond = ops.rope_table(condition_ids.to(dev, f32).reshape(-1, 3), cfg.axes_dims_rope,
+                                                          out=(self.rope_cond[0], self.rope_cond[1]))
         # temb_base = text_embedder(pooled) [+ guidance_embedder(sinusoid(1000 g))]
         pooled = pooled.to(device=dev, dtype=f32).contiguous()
         self._lin_skinny(pooled, "tte.text_embedder.linear_1", self.thid, act_out=1)
@@ -196,7 +203,6 @@ class DiTEngine:
             self._time_text_embed(ct, self.cond_temb, self.temb_base)
             self._compute_mods(self.cond_temb, self.cmods, lora=True)
         self.attn_bias = self._attn_bias()
-        self.graph = None            # the captured step bakes in this conditioning's code path (LoRA rows, bias table)
         self.cond_ready = True
 
     # ------------------------------------------------------------------------------------------ building blocks
@@ -363,13 +369,18 @@ class DiTEngine:
             return self._forward_eager(latents, timestep)
         self.g_lat.copy_(latents.reshape(self.g_lat.shape))
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
-        if self.graph is None:
-            self._forward_eager(self.g_lat, self.g_t)            # warm-up outside capture (lazy module loads, allocator)
-            torch.cuda.synchronize(self.device)
+        # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
+        # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor)
+        if self.graph is None or self.graph_key != key:
+            if not self._warmed:                                  # lazy code-object loads must not happen inside capture
+                self._forward_eager(self.g_lat, self.g_t)
+                torch.cuda.synchronize(self.device)
+                self._warmed = True
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._forward_eager(self.g_lat, self.g_t)
-            self.graph = g
+            self.graph, self.graph_key = g, key
         self.graph.replay()
         return self.out.view(self.B, self.N, self.cfg.in_channels)
 

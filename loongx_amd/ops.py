@@ -126,13 +126,17 @@ def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> None:
     check(lib.lx_timestep_embed(t.data_ptr(), out.data_ptr(), out.shape[0], out.shape[1], _stream()), "lx_timestep_embed")
 
 
-def rope_table(ids: torch.Tensor, axes=(16, 56, 56), theta: float = 10000.0):
-    """ids fp32 [L,3] on the GPU -> (cos, sin) fp32 [L, sum(axes)]."""
+def rope_table(ids: torch.Tensor, axes=(16, 56, 56), theta: float = 10000.0, out=None):
+    """ids fp32 [L,3] on the GPU -> (cos, sin) fp32 [L, sum(axes)] (written into `out=(cos, sin)` when given)."""
     _req(ids, torch.float32, "ids")
     ids = ids.contiguous()
     Lq, tot = ids.shape[0], sum(axes)
-    cos = torch.empty(Lq, tot, dtype=torch.float32, device=ids.device)
-    sin = torch.empty_like(cos)
+    if out is None:
+        cos = torch.empty(Lq, tot, dtype=torch.float32, device=ids.device)
+        sin = torch.empty_like(cos)
+    else:
+        cos, sin = out
+        assert cos.shape == (Lq, tot) and sin.shape == (Lq, tot) and cos.is_contiguous() and sin.is_contiguous()
     check(lib.lx_rope_table(ids.data_ptr(), Lq, axes[0], axes[1], axes[2], float(theta), cos.data_ptr(), sin.data_ptr(), _stream()), "lx_rope_table")
     return cos, sin
 
