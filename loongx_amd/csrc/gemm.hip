@@ -28,6 +28,11 @@ constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int GROUP_M = 4;
 
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
 constexpr int MAX_SUB = 2 * LX_GEMM_MAX_GROUP;   // a problem may be split into a 256-row-tile part and a 128-row-tile tail
 
 struct GemmArgs {
@@ -390,11 +395,6 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
 #undef LX_STEP
 
   gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
-}
-
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
 }
 
 }  // namespace
