@@ -1,0 +1,17 @@
+import torch, math
+from loongx_amd import ops
+dev="cuda"; B,H=1,24; lens=(512,1024,1024); D=H*128
+M=B*sum(lens)
+buf=torch.randn(M,3*D,device=dev).to(torch.bfloat16)
+row0=[0,B*512,B*1536]; vt0=[0,512,1536]
+VT=torch.zeros(B,H,128,2560,dtype=torch.bfloat16,device=dev)
+ops.qkv_prep_segs(buf,2*D,0,D,[(row0[i],lens[i],vt0[i],None,None,None,None) for i in range(3)],B,H,VT)
+def run(): ops.attn_fwd(buf,buf,VT,buf,q_col=2*D,k_col=0,o_col=2*D,B=B,H=H,seg_row0=row0,seg_len=list(lens),seg_vt0=vt0)
+for _ in range(5): run()
+torch.cuda.synchronize()
+s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(50): run()
+e.record(); torch.cuda.synchronize()
+us=s.elapsed_time(e)*1e3/50
+S=sum(lens); print(f"attn {us:.1f} us  {4*B*H*S*S*128/us/1e6:.0f} TF")
