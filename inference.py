@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 
 def get_config():
     path = os.environ.get("XFL_CONFIG")
-    if path is None:
+    if not path:
         return {"dtype": "bfloat16", "model": {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}}
     with open(path, "r") as f:
         return yaml.safe_load(f)
