@@ -21,6 +21,10 @@
 //    ordered in 4-tile-tall column groups so co-resident tiles share A / W panels in that L2.
 #include "common.h"
 
+#ifndef LX_ACC_AGPR
+#define LX_ACC_AGPR 0
+#endif
+
 namespace {
 
 constexpr int BN = 256;
@@ -321,8 +325,12 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   };
   auto mma_j = [&](int j, const bf16x8 (&wf)[2], const bf16x8 (&xf)[MI]) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    for (int i = 0; i < MI; ++i) {
+      // Accumulators live in AGPRs ("a" constraint; hipcc's own choice is arch VGPRs). Measured (tools/ubench/agpr_rate):
+      // with LDS-DMA running on the CU, a K tile of MFMAs costs 1.36 us with AGPR accumulators vs 1.74 us with VGPR ones.
+      if (LX_ACC_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wf[j]), "v"(xf[i]));
+      else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
   };
   const int nkt = K / BK;
   bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
@@ -393,6 +401,8 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
     cw = nw;
   }
 #undef LX_STEP
+  // the inline-asm MFMAs are opaque to the hazard recogniser: cover MFMA write -> v_accvgpr_read by hand (18 wait states)
+  if (LX_ACC_AGPR) asm volatile("s_nop 15\n s_nop 7" ::: "memory");
 
   gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
 }

@@ -16,13 +16,3 @@ for mode in (1, 2, 3, 4, 5, 6, 7):
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / 20
     print(f"mode {mode} {names[mode]:22s}: {us:7.1f} us/launch  {us/iters:6.3f} us per K-tile  (DMA {64*1024/(us/iters)/1e3:6.1f} GB/s per CU)" if mode & 1 else f"mode {mode} {names[mode]:22s}: {us:7.1f} us/launch  {us/iters:6.3f} us per K-tile")
-ws = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ws_rate.so"))
-ws.run_ws.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
-for _ in range(3): ws.run_ws(A.data_ptr(), W.data_ptr(), out.data_ptr(), 256, iters, a_stride, w_stride, torch.cuda.current_stream().cuda_stream)
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(20): ws.run_ws(A.data_ptr(), W.data_ptr(), out.data_ptr(), 256, iters, a_stride, w_stride, torch.cuda.current_stream().cuda_stream)
-e.record(); torch.cuda.synchronize()
-us = s.elapsed_time(e) * 1e3 / 20
-print(f"mode WS 8 compute (ds_read+MFMA) + 4 loader waves: {us:7.1f} us/launch  {us/iters:6.3f} us per K-tile")
