@@ -88,8 +88,10 @@ int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
 int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
                  int split_stride, void* stream);
 
-/* Skinny linear for M <= 16 rows (AdaLayerNorm modulation linears, time/text embedders:
- * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound.
+/* Skinny linear for a few rows (AdaLayerNorm modulation linears, time/text embedders:
+ * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound; rows are processed four at a
+ * time against the same weight rows, independently (M rows give bit-identical results to M one-row calls), so the
+ * modulations of a whole sigma schedule can be evaluated in one weight pass (M = steps x batch).
  * Y[M,N] fp32 (=|+=) act_out(act_in(X[M,K] fp32) . W[N,K]^T (bf16) + bias).  act: 0 none, 1 SiLU. */
 int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy,
                      int M, int N, int K, int act_in, int act_out, int accumulate, void* stream);

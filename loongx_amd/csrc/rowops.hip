@@ -449,7 +449,7 @@ extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T,
 extern "C" int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy, int M, int N,
                                 int K, int act_in, int act_out, int accumulate, void* stream) {
   LX_CHECK_ARG(X && W && Y, "lx_linear_skinny: NULL operand");
-  LX_CHECK_ARG(M >= 1 && M <= 16, "lx_linear_skinny: M=%d must be in [1,16]", M);
+  LX_CHECK_ARG(M >= 1 && M <= 65536, "lx_linear_skinny: M=%d must be in [1,65536]", M);
   LX_CHECK_ARG(K % 8 == 0 && ldw % 8 == 0 && ldx % 4 == 0, "lx_linear_skinny: K %% 8, ldw %% 8, ldx %% 4 required (K=%d)", K);
   const dim3 grid((N + 15) / 16), block(256);
   hipLaunchKernelGGL(linear_skinny_kernel, grid, block, 0, (hipStream_t)stream, X, ldx, (const uint16_t*)W, ldw, bias, Y, ldy, M, N,

@@ -40,8 +40,8 @@ class DiTEngine:
             raise ValueError("the gfx950 attention kernel is specialised for head_dim 128 (FLUX.1)")
         self.shape = None
         self.cond_ready = False
-        self.graph = None
-        self.graph_key = None
+        self.sched = None
+        self.graphs: Dict = {}
         self._warmed = False
         import os
         self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
@@ -86,7 +86,7 @@ class DiTEngine:
         self.rope_cond = torch.zeros(2, max(C, 1), rd, dtype=f32, device=dev)
         self.g_lat = torch.zeros(B, N, cfg.in_channels, dtype=f32, device=dev)
         self.g_t = torch.zeros(B, dtype=f32, device=dev)
-        self.graph = None
+        self.graphs = {}
         self.shape = (B, T, N, C)
         self.cond_ready = False
 
@@ -120,15 +120,42 @@ class DiTEngine:
         if lora and "mod.lora_down" in w.t:
             cfg, r, D = self.cfg, self.cfg.lora_r, self.cfg.inner_dim
             nb = cfg.num_layers + cfg.num_single_layers
-            tm = self.tmod[:, : nb * r]
+            rows = temb.shape[0]
+            tm = self.tmod[:, : nb * r] if rows == self.B else torch.zeros(rows, nb * r, dtype=torch.float32, device=self.device)
             ops.linear_skinny(temb, w.t["mod.lora_down"], None, tm, act_in=1)
             for idx in range(nb):
                 if idx < cfg.num_layers:
                     base, width = cfg.mod_base_double(idx), 6 * D
                 else:
                     base, width = cfg.mod_base_single(idx - cfg.num_layers), 3 * D
-                ops.linear_f32(tm[:, idx * r:], w.t[f"mod.lora_up.{idx}"], None, out[:, base:], M=self.B, N=width, K=r,
+                ops.linear_f32(tm[:, idx * r:], w.t[f"mod.lora_up.{idx}"], None, out[:, base:], M=rows, N=width, K=r,
                                ldx=tm.stride(0), ldy=out.stride(0), accumulate=True)
+
+    def prepare_schedule(self, t_sched) -> None:
+        """Timestep embedding and every image/text modulation vector for ALL steps of a schedule in one weight pass.
+
+        The modulation Linears hold 6.5 GB of weights (FLUX.1-dev) and see one row per sample and step; evaluated step by
+        step they re-stream those weights from HBM 28 times per image. Rows are independent in the weight-streaming kernel, so
+        the batched result is bit-identical to the per-step one. `t_sched`: 1-D, the values later passed as `timestep`
+        (0..1). Needs set_conditioning() first (temb_base) and is invalidated by it."""
+        if not self.cond_ready:
+            raise RuntimeError("call set_conditioning() before prepare_schedule()")
+        cfg, dev, f32 = self.cfg, self.device, torch.float32
+        t = torch.as_tensor(t_sched, dtype=f32, device=dev).reshape(-1)
+        n, B, D = t.numel(), self.B, cfg.inner_dim
+        if n * B * cfg.n_mod * 4 > (8 << 30):        # keep the table bounded; the per-step path handles the rest
+            self.sched = None
+            return
+        t1000 = torch.mul(t, 1000.0).repeat_interleave(B).contiguous()          # row = step * B + sample
+        tproj = torch.empty(n * B, 256, dtype=f32, device=dev)
+        thid = torch.empty(n * B, D, dtype=f32, device=dev)
+        temb_all = self.temb_base.repeat(n, 1).contiguous()
+        ops.timestep_embed(t1000, tproj)
+        self._lin_skinny(tproj, "tte.timestep_embedder.linear_1", thid, act_out=1)
+        self._lin_skinny(thid, "tte.timestep_embedder.linear_2", temb_all, accumulate=True)
+        mods_all = torch.empty(n * B, cfg.n_mod, dtype=f32, device=dev)
+        self._compute_mods(temb_all, mods_all, lora=self.latent_lora)
+        self.sched = (tuple(float(v) for v in t.tolist()), mods_all.view(n, B, cfg.n_mod))
 
     def _attn_bias(self) -> Dict[str, Dict[str, float]]:
         """block.py:106-128 as a (query stream, key stream) table: 0, log(c_factor) or -inf."""
@@ -204,6 +231,7 @@ class DiTEngine:
             self._compute_mods(self.cond_temb, self.cmods, lora=True)
         self.attn_bias = self._attn_bias()
         self.cond_ready = True
+        self.sched = None
 
     # ------------------------------------------------------------------------------------------ building blocks
     def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
@@ -321,7 +349,7 @@ class DiTEngine:
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate)
 
     # ------------------------------------------------------------------------------------------ one step
-    def embed_step_inputs(self, latents: torch.Tensor, timestep: torch.Tensor) -> None:
+    def embed_step_inputs(self, latents: torch.Tensor, timestep: torch.Tensor, mods_ready: bool = False) -> None:
         """x_embedder(latents), reset text/condition rows, temb(t) and every image/text modulation vector."""
         w, cfg = self.w, self.cfg
         ops.convert(self.lat16, latents.reshape(self.B * self.N, -1).contiguous())
@@ -335,6 +363,8 @@ class DiTEngine:
         self.rows(self.X, "txt").copy_(self.X_txt_init)
         if self.C:
             self.rows(self.X, "cond").copy_(self.X_cond_init)
+        if mods_ready:                      # self.mods already holds this step's row of the prepare_schedule() table
+            return
         torch.mul(timestep.to(device=self.device, dtype=torch.float32), 1000.0, out=self.t1000)
         self._time_text_embed(self.t1000, self.temb, self.temb_base)
         self._compute_mods(self.temb, self.mods, lora=self.latent_lora)
@@ -349,39 +379,50 @@ class DiTEngine:
                                 epilogue=LX_EPI_STORE_F32)])
         return self.out.view(self.B, self.N, cfg.in_channels)
 
-    def _forward_eager(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
-        self.embed_step_inputs(latents, timestep)
+    def _forward_eager(self, latents: torch.Tensor, timestep: torch.Tensor, mods_ready: bool = False) -> torch.Tensor:
+        self.embed_step_inputs(latents, timestep, mods_ready)
         for i in range(self.cfg.num_layers):
             self.double_block(i)
         for j in range(self.cfg.num_single_layers):
             self.single_block(j)
         return self.final_layer()
 
-    def forward(self, latents: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+    def forward(self, latents: torch.Tensor, timestep: torch.Tensor, step_index: Optional[int] = None) -> torch.Tensor:
         """latents fp32 [B,N,in_channels], timestep [B] in 0..1 -> velocity fp32 [B,N,in_channels] (engine-owned buffer).
 
         The ~600 kernel launches of a step are captured ONCE per conditioning into a HIP graph (all of them are enqueued
         on torch's current stream through the C ABI, so stream capture sees them) and replayed for the remaining steps:
-        the launch-bound gaps between the short kernels disappear.  LX_GRAPH=0 disables capture."""
+        the launch-bound gaps between the short kernels disappear.  LX_GRAPH=0 disables capture.
+
+        `step_index`: position of `timestep` in the schedule given to prepare_schedule(); the step then takes its
+        modulation vectors from that table instead of re-streaming the modulation weights."""
         if not self.cond_ready:
             raise RuntimeError("call set_conditioning() before forward()")
+        pre = step_index is not None and self.sched is not None
+        if pre:
+            if not 0 <= step_index < len(self.sched[0]):
+                raise IndexError(f"step_index {step_index} outside the prepared schedule of {len(self.sched[0])} steps")
+            self.mods.copy_(self.sched[1][step_index])
         if not self.use_graph or ops.TIMER is not None:
-            return self._forward_eager(latents, timestep)
+            return self._forward_eager(latents, timestep, pre)
         self.g_lat.copy_(latents.reshape(self.g_lat.shape))
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor)
-        if self.graph is None or self.graph_key != key:
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre)
+        g = self.graphs.get(key)
+        if g is None:
             if not self._warmed:                                  # lazy code-object loads must not happen inside capture
-                self._forward_eager(self.g_lat, self.g_t)
+                self._forward_eager(self.g_lat, self.g_t, False)
                 torch.cuda.synchronize(self.device)
                 self._warmed = True
+            if len(self.graphs) >= 4:
+                self.graphs.clear()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._forward_eager(self.g_lat, self.g_t)
-            self.graph, self.graph_key = g, key
-        self.graph.replay()
+                self._forward_eager(self.g_lat, self.g_t, pre)
+            self.graphs[key] = g
+        g.replay()
         return self.out.view(self.B, self.N, self.cfg.in_channels)
 
     # ------------------------------------------------------------------------------------------ block-level entry points
@@ -419,7 +460,7 @@ class DiTEngine:
     def configure(self, B, T, N, C, model_config=None, c_factor=None, rope_main=None, rope_cond=None) -> None:
         """Shape + config + RoPE tables without the prompt/condition embedders (block-level use)."""
         self.setup(B, T, N, C)
-        self.graph = None
+        self.graphs = {}
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))

@@ -160,6 +160,8 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
     pooled_prompt_embeds = pooled_prompt_embeds.contiguous()
 
     # ---- denoise loop (generate.py:313-369) ------------------------------------------------------------------
+    # the whole schedule is known here: hand it to the engine so the AdaLN modulation weights stream once per image
+    sched_ts = (timesteps.to(latents.dtype) / 1000).tolist()
     with self.progress_bar(total=num_inference_steps) as progress_bar:
         for i, t in enumerate(timesteps):
             if self.interrupt:
@@ -172,7 +174,7 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
                 condition_type_ids=condition_type_ids if use_condition else None,
                 hidden_states=latents, timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled_prompt_embeds,
                 encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
-                joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False)[0]
+                joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, lx_schedule=(i, sched_ts))[0]
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if callback_on_step_end is not None:
                 callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}

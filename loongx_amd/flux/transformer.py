@@ -103,7 +103,15 @@ def tranformer_forward(transformer: LxFluxTransformer, condition_latents: torch.
                              condition_latents if use_condition else None, condition_ids if use_condition else None,
                              c_t=float(c_t), model_config=mc, c_factor=transformer.c_factor)
         transformer._cond_key = key
-    out = eng.forward(hidden_states.to(device=eng.device, dtype=torch.float32), timestep.to(eng.device))
+    # Extension (the reference swallows unknown kwargs): lx_schedule=(i, timesteps) tells the engine that `timestep` is entry
+    # i of a known schedule (same units as `timestep`), so all steps' modulation vectors come from one weight pass.
+    step_index = None
+    sched = params.get("lx_schedule")
+    if sched is not None:
+        step_index, ts = int(sched[0]), tuple(float(v) for v in sched[1])
+        if eng.sched is None or eng.sched[0] != ts:
+            eng.prepare_schedule(torch.tensor(ts, dtype=torch.float32))
+    out = eng.forward(hidden_states.to(device=eng.device, dtype=torch.float32), timestep.to(eng.device), step_index=step_index)
     out = out.to(hidden_states.dtype) if hidden_states.dtype != torch.float32 else out.clone()
     if not return_dict:
         return (out,)

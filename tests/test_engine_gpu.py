@@ -73,3 +73,31 @@ def test_forward_is_deterministic(G):
     eng = _engine(tiny_transformer())
     a, b = _run(eng, G), _run(eng, G)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
+def test_prepared_schedule_is_bit_identical(G, mc):
+    """prepare_schedule(): all steps' modulation vectors from one weight pass == the per-step evaluation, bit for bit
+    (rows are independent in lx_linear_skinny), for graph replay and eager, with and without LoRA on the image stream."""
+    d = "cuda"
+    eng = _engine(tiny_transformer())
+    ts = [1.0, 0.8731, 0.5, 0.25, 0.0357]
+    B = G["in_latents"].shape[0]
+    per_step = []
+    for t in ts:
+        tt = torch.full((B,), t, device=d)
+        _run(eng, G, model_config=mc)                                 # (re)conditioning drops any prepared schedule
+        assert eng.sched is None
+        per_step.append(eng.forward(G["in_latents"].to(d), tt).clone())
+    _run(eng, G, model_config=mc)
+    eng.prepare_schedule(torch.tensor(ts))
+    for i, t in enumerate(ts):
+        tt = torch.full((B,), t, device=d)
+        got = eng.forward(G["in_latents"].to(d), tt, step_index=i)
+        assert torch.equal(got, per_step[i]), f"step {i}"
+    with pytest.raises(IndexError):
+        eng.forward(G["in_latents"].to(d), tt, step_index=len(ts))
+    # conditioning change invalidates the table: step_index is then ignored and the per-step path runs
+    _run(eng, G, model_config=mc)
+    got = eng.forward(G["in_latents"].to(d), torch.full((B,), ts[2], device=d), step_index=2)
+    assert torch.equal(got, per_step[2])
