@@ -6,7 +6,8 @@
 // pair (0, log(c_factor), or -inf for the union_cond_attn=False / independent_condition masks), so the
 // [S,S] mask tensor is never materialised.
 //
-// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); lane = query row):
+// Structure (one workgroup = NW waves = 32*NW query rows of one (batch, head); lane = query row; NW = 8 by default: one
+// K/V tile staged per 256 query rows halves the LDS-DMA pieces per flop against NW = 4):
 //   S^T[key, q] = K_tile . Q^T      v_mfma_f32_32x32x16_bf16, K fragments from LDS, Q resident in VGPRs
 //   online softmax in registers     each lane owns 32 scores of ITS query row; the other 32 sit in lane^32
 //   O^T[d, q]  += V^T_tile . P^T    P fragments are 8 consecutive accumulator registers (no shuffles):
@@ -21,9 +22,7 @@
 namespace {
 
 constexpr int DH = 128;
-constexpr int QBLK = 128;
 constexpr int KVBLK = 64;
-constexpr int NTHREADS = 256;
 constexpr int K_BYTES = KVBLK * DH * 2;   // 16 KiB
 constexpr int V_BYTES = DH * KVBLK * 2;   // 16 KiB
 constexpr int STAGE_BYTES = K_BYTES + V_BYTES;
@@ -33,10 +32,19 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct AttnArgs {
   lx_attn_desc d;
-  int qt_start[4];   // prefix of 128-row query tiles per segment
+  int qt_start[4];   // prefix of (32*NW)-row query tiles per segment
 };
 
-__global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs args) {
+// LX_ATTN_DEFER: rescale threshold in log2 units for the deferred running-max update (0 = always rescale).
+// While no row of the wave sees its tile maximum grow past the max in use by more than this, the stale max keeps being
+// used (P <= 2^thr), so the 64 accumulator multiplies and the l rescale are skipped; O and l carry the same factor, the
+// final O / l is unchanged.
+constexpr float DEFER_THR = 8.0f;
+
+template <int NW, bool DEFER>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const AttnArgs args) {
+  constexpr int QBLK = NW * 32;
+  constexpr int PIECES = 16 / NW;     // 1-KiB LDS-DMA pieces per wave per operand tile
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
   const lx_attn_desc& D = args.d;
   const int tid = threadIdx.x;
@@ -84,21 +92,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
     const size_t krow0 = (size_t)D.seg_row0[sk] + (size_t)b * klen;
     // K: one instruction = 4 key rows of 256 B; lane -> (row = lane>>4, slot = lane&15)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = (j * 4 + wave) * 4 + (lane >> 4);
+    for (int j = 0; j < PIECES; ++j) {
+      const int key = (j * NW + wave) * 4 + (lane >> 4);
       const int lslot = (lane & 15) ^ (key & 15);
       const int kin = min(kt * KVBLK + key, klen - 1);
       const __bf16* src = Kbase + (krow0 + kin) * D.ldk + lslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (j * NW + wave) * 1024), 16, 0, 0);
     }
     // V^T: one instruction = 8 d rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
     const int vpos = D.seg_vt0[sk] + kt * KVBLK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int drow = (j * 4 + wave) * 8 + (lane >> 3);
+    for (int j = 0; j < PIECES; ++j) {
+      const int drow = (j * NW + wave) * 8 + (lane >> 3);
       const int lslot = (lane & 7) ^ ((drow >> 1) & 7);
       const __bf16* src = Vbase + (size_t)drow * D.vt_ld + vpos + lslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + K_BYTES + (j * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + K_BYTES + (j * NW + wave) * 1024), 16, 0, 0);
     }
   };
   // iteration over (key segment, key tile), skipping fully masked segment pairs
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -139,6 +148,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- online softmax (log2 domain) ------------------------------------------------------------
     const float bl = D.bias[sq][sk] * 1.4426950408889634f;
     const int klen = D.seg_len[sk];
@@ -153,15 +163,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
           if (key >= klen) sacc[kb][r] = -1e30f;
         }
     }
-    float tmax = sacc[0][0];
+    float tmax = fmaxf(sacc[0][0], sacc[0][1]);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
+      for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax * c2 + bl);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    const float off = bl - m_new;
+    const float t_new = tmax * c2 + bl;
+    bool rescale = true;
+    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;    // wave-uniform
+    if (rescale) {
+      const float m_new = fmaxf(m_run, t_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    const float off = bl - m_run;
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -171,12 +192,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
         sacc[kb][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    l_run += psum;
     // ---- P fragments: step s uses accumulator registers [8*(s&1), +8) of sacc[s>>1] -------------
     bf16x8 pf[4];
 #pragma unroll
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
       pf[s] = __builtin_bit_cast(bf16x8, w);
     }
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -196,12 +213,324 @@ __global__ __launch_bounds__(NTHREADS, 2) void lx_attn_kernel(const AttnArgs arg
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     sk = nsk;
     kt = nkt;
     buf ^= 1;
   }
 
   // ---- epilogue: O[q, d] = O^T / l ; lane holds d = db*32 + 8*(r>>2) + 4*lhi + (r&3) --------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_valid) {
+    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 o;
+        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        *(u32x2*)(op + db * 32 + rq * 8) = o;
+      }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (default): one instruction stream per wave that interleaves matrix and vector work.
+//
+// Measured on gfx950 (tools/ubench/coexec): an MFMA stream on one wave and a VALU stream on the wave sharing its SIMD do
+// NOT overlap -- their times add (651 + 1405 -> 1921 us), whatever s_setprio says. In lx_attn_kernel both waves of a
+// SIMD alternate QK -> softmax -> PV, so a KV tile costs (2 x 1024 MFMA + 2 x ~1100 VALU) cycles per SIMD: 5300 measured,
+// MfmaUtil 43 %. Skewing the two waves by a phase (tried: X = {PV, QK} / Y = {softmax} with an odd s_barrier) changes
+// nothing for the same reason. What does overlap is a wave's OWN vector instructions issued in the shadow of its own
+// MFMAs. So every iteration t runs 32 "gaps", each = {wait for the operand, one MFMA, the ds_read for six gaps ahead,
+// a few VALU instructions}:
+//     matrix work : QK(t+1) (scores of the NEXT tile)  and  PV(t)
+//     vector work : softmax(t): row max (before gap 0, covering the first LDS round trip), then 32 one-value half-units
+//                   {fma, exp2, row-sum[, cvt_pk]}, about one per gap, placed so that P slice s (16 keys) is complete
+//                   just before PV slice s.
+// Scores live in two register sets that swap roles every iteration (the loop body is expanded twice). The last
+// iteration's QK works on a stale buffer and is discarded. One barrier per tile; K(t+2) and V(t+1) are staged (four 1-KiB
+// LDS-DMA pieces per wave, spread over gaps) into the slots K(t) / V(t-1) vacated in the previous iteration.
+constexpr int pipe_is_q(int g) { return g < 10 || g == 14 || g == 15 || g == 20 || g == 21 || g == 26 || g == 27; }
+constexpr int pipe_idx(int g) {   // index of the QK fragment (ks*2+kb) or PV fragment (s*4+db) consumed at gap g
+  return g < 10 ? g : g < 14 ? g - 10 : g < 16 ? g - 4 : g < 20 ? g - 12 : g < 22 ? g - 8 : g < 26 ? g - 14 : g < 28 ? g - 12 : g - 16;
+}
+constexpr int pipe_half(int g, int k) {   // k-th (0/1) softmax half-unit (slice*8 + value) issued behind gap g, or -1
+  // slice s must be complete before PV slice s starts (gaps 10, 16, 22, 28)
+  constexpr int at[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 19, 20, 21, 22, 22, 23, 23, 24, 25, 26, 27};
+  int seen = 0;
+  for (int j = 0; j < 32; ++j)
+    if (at[j] == g) { if (seen == k) return j; ++seen; }
+  return -1;
+}
+
+template <bool DEFER, bool ALT>
+__global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs args) {
+  constexpr int NW = 8, QBLK = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+  const lx_attn_desc& D = args.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool grp_b = wave >= 4;     // waves w and w+4 share a SIMD
+
+  const int BH = D.B * D.H;
+  const int bh = blockIdx.x % BH;
+  const int qt = blockIdx.x / BH;
+  const int b = bh / D.H, h = bh % D.H;
+  int sq = 0;
+#pragma unroll
+  for (int s = 1; s < 3; ++s)
+    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
+  // Descriptor fields are copied into scalars ONCE: indexing the kernarg arrays with the running segment index inside
+  // the tile loop costs a dependent s_load (~150 cycles each) and scalar loads would break the counted lgkmcnt below.
+  const int n_seg = D.n_seg;
+  const int len0 = D.seg_len[0], len1 = D.seg_len[1], len2 = D.seg_len[2];
+  const int row00 = D.seg_row0[0], row01 = D.seg_row0[1], row02 = D.seg_row0[2];
+  const int vt00 = D.seg_vt0[0], vt01 = D.seg_vt0[1], vt02 = D.seg_vt0[2];
+  const float bia0 = D.bias[sq][0], bia1 = D.bias[sq][1], bia2 = D.bias[sq][2];
+  auto pick = [](int s, auto x0, auto x1, auto x2) { return s == 0 ? x0 : (s == 1 ? x1 : x2); };
+  auto seg_len = [&](int s) { return pick(s, len0, len1, len2); };
+
+  const int q_len = seg_len(sq);
+  const int q_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 32 + l31;
+  const bool q_valid = q_in_seg < q_len;
+  const size_t q_row = (size_t)pick(sq, row00, row01, row02) + (size_t)b * q_len + min(q_in_seg, q_len - 1);
+
+  bf16x8 qf[8];
+  {
+    const __bf16* qp = (const __bf16*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  const float c2 = D.scale * 1.4426950408889634f;
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const __bf16* Kbase = (const __bf16*)D.K + D.k_col + h * DH;
+  const __bf16* Vbase = (const __bf16*)D.VT + (size_t)bh * DH * D.vt_ld;
+  const int ldk = D.ldk, vt_ld = D.vt_ld;
+  // One 1-KiB LDS-DMA piece: j = 0,1 K rows, j = 2,3 V^T rows (each wave moves four pieces per tile). Branch-free, so
+  // that the pieces can sit inside the MFMA stream without splitting it into basic blocks: source = wave-uniform tile
+  // origin (SGPR pair) + per-lane 32-bit byte offset. K rows are clamped to the tile's last valid key (ragged segment
+  // tails; a tile that does not exist is staged from row 0 of the previous one and never read).
+  const int k_key = wave * 4 + (lane >> 4);                                              // + 32 for the second piece
+  const uint32_t k_slot_off = (uint32_t)((((lane & 15) ^ (k_key & 15)) * 8) * 2);
+  const uint32_t v_lane_off = (uint32_t)(((wave * 8 + (lane >> 3)) * vt_ld + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) * 8)) * 2);
+  auto piece = [&](int j, int krow, int vpos, int nclamp, int slot) {
+    char* base = smem + slot * STAGE_BYTES;
+    if (j < 2) {
+      const char* org = (const char*)(Kbase + (size_t)krow * ldk);                                       // wave-uniform
+      const uint32_t off_ = (uint32_t)(min(k_key + j * 32, nclamp - 1) * ldk * 2) + k_slot_off;
+      __builtin_amdgcn_global_load_lds((gptr_t)(org + off_), (lptr_t)(base + (j * NW + wave) * 1024), 16, 0, 0);
+    } else {
+      const int jj = j - 2;
+      const char* org = (const char*)(Vbase + (size_t)(jj * NW * 8) * vt_ld + vpos);                     // wave-uniform
+      __builtin_amdgcn_global_load_lds((gptr_t)(org + v_lane_off), (lptr_t)(base + K_BYTES + (jj * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+  // Wave-uniform KV-tile descriptors. `gen` walks (segment, tile) over the segments this query segment may attend to; the
+  // common step is three scalar adds, a segment switch is a rare branch. Each iteration needs the descriptors of tiles t
+  // (softmax: bias, valid keys), t+1 (V staging) and t+2 (K staging): they are handed down a three-deep FIFO.
+  struct Tile { int krow, vpos, nvalid, nclamp; float bl; };   // first key row, first V^T column, keys in the tile (0 = none),
+                                                               // row clamp for staging (>= 1 always), bias*log2e
+  int g_seg = -1, g_left = 0;                               // generator state: segment, keys of it not yet handed out
+  Tile g_cur = {0, 0, 0, 1, 0.f};
+  auto gen_next = [&]() {
+    if (g_left > 0) {
+      g_cur.krow += KVBLK; g_cur.vpos += KVBLK;
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      do { ++g_seg; } while (g_seg < n_seg && !(pick(g_seg, bia0, bia1, bia2) > -1e37f));
+      if (g_seg >= n_seg) { g_cur.nvalid = 0; g_cur.nclamp = 1; g_left = 0; return; }   // krow / vpos stay on the last real tile
+      g_left = seg_len(g_seg);
+      g_cur.krow = pick(g_seg, row00, row01, row02) + b * g_left;
+      g_cur.vpos = pick(g_seg, vt00, vt01, vt02);
+      g_cur.bl = pick(g_seg, bia0, bia1, bia2) * 1.4426950408889634f;
+    }
+    g_cur.nvalid = min(g_left, KVBLK);
+    g_cur.nclamp = g_cur.nvalid;
+    g_left -= g_cur.nvalid;
+  };
+  gen_next();
+  Tile t0 = g_cur;                  // tile t: being soft-maxed and multiplied into O
+  gen_next();
+  Tile t1 = g_cur;                  // tile t+1: its scores are being computed, its V staged
+  gen_next();
+  Tile t2 = g_cur;                  // tile t+2: its K is being staged
+
+  // K: 16-B slot ((2ks + lhi) ^ (key & 15)), V^T: slot ((2s + lhi) ^ ((d >> 1) & 7)). The tiles are 1 KiB aligned and
+  // 2ks / 2s only touch bits the row offset leaves clear, so address(ks) = address(0) ^ (ks * 32): two address registers.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t kaddr0 = lds0 + l31 * 256 + ((lhi ^ (l31 & 15)) * 16);
+  const uint32_t vaddr0 = lds0 + K_BYTES + l31 * 128 + ((lhi ^ ((l31 >> 1) & 7)) * 16);
+
+  constexpr int LOOK = 5;           // fragments in flight ahead of the MFMA that consumes them (<= 6)
+  bf16x8 ring[LOOK];
+  u32x4 pfw[4];
+  f32x16 sA[2], sB[2];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float off = 0.f, p_even = 0.f;
+  uint32_t bq = 0, bv = 0;          // LDS byte offsets of the K buffer read by QK and the V buffer read by PV
+
+#define LX_FENCE() asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define LX_BARRIER() LX_FENCE(); __builtin_amdgcn_s_barrier(); LX_FENCE()
+#define LX_DSR(dst, addr, offs) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offs))
+#define LX_WAITL(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
+  // read of the fragment consumed at gap j (gaps >= last do not exist); QONLY: prologue stream of the 16 K fragments
+#define LX_RD(j, last, QONLY)                                                                                          \
+  if ((j) < (last)) {                                                                                                  \
+    if ((QONLY) || pipe_is_q(j)) {                                                                                     \
+      constexpr int f_ = (QONLY) ? (j) : pipe_idx(j);                                                                  \
+      const uint32_t a_ = (kaddr0 + bq) ^ ((f_ >> 1) * 32);                                                            \
+      LX_DSR(ring[(j) % LOOK], a_, (f_ & 1) * 8192);                                                                   \
+    } else {                                                                                                           \
+      constexpr int f_ = pipe_idx(j);                                                                                  \
+      const uint32_t a_ = (vaddr0 + bv) ^ ((f_ >> 2) * 32);                                                            \
+      LX_DSR(ring[(j) % LOOK], a_, (f_ & 3) * 4096);                                                                   \
+    }                                                                                                                  \
+  }                                                                                                                    \
+  __builtin_amdgcn_sched_barrier(0)
+#define LX_RDP(j, last, QONLY) LX_RD(j, (j) < LOOK ? (last) : 0, QONLY)   /* the LOOK reads that prime the ring */
+#define LX_MM(g, SC, SN, QONLY)                                                                                        \
+  if ((QONLY) || pipe_is_q(g)) {                                                                                       \
+    constexpr int f_ = (QONLY) ? (g) : pipe_idx(g);                                                                    \
+    SN[f_ & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(g) % LOOK], qf[f_ >> 1], f_ < 2 ? zero16 : SN[f_ & 1], 0, 0, 0); \
+  } else {                                                                                                             \
+    constexpr int f_ = pipe_idx(g);                                                                                    \
+    oacc[f_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(g) % LOOK], __builtin_bit_cast(bf16x8, pfw[f_ >> 2]), oacc[f_ & 3], 0, 0, 0); \
+  }                                                                                                                    \
+  __builtin_amdgcn_sched_barrier(0)
+  // softmax half-unit hu = slice*8 + value: one score -> one probability and the row sum; odd values also pack the bf16 pair.
+  // The empty asm keeps it in ITS gap (hipcc sinks the arithmetic to the first use otherwise).
+#define LX_HALF(hu, SC)                                                                                                \
+  {                                                                                                                    \
+    constexpr int s_ = (hu) >> 3, r_ = 8 * (s_ & 1) + ((hu) & 7);                                                      \
+    const float p_ = __builtin_amdgcn_exp2f(fmaf(SC[s_ >> 1][r_], c2, off));                                           \
+    l_run += p_;                                                                                                       \
+    if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even, p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]), "+v"(l_run)); } \
+    else { p_even = p_; asm volatile("" : "+v"(p_even), "+v"(l_run)); }                                                \
+  }
+#define LX_GAP(g, SC, SN)                                                                                              \
+  LX_WAITL((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1));                                                         \
+  LX_MM(g, SC, SN, false);                                                                                             \
+  LX_RD((g) + LOOK, 32, false);                                                                                        \
+  if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
+  if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }         \
+  if ((g) == 1) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                              \
+  if ((g) == 3) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                              \
+  if ((g) == 5) piece(2, 0, t1.vpos, 0, vs_slot);                                                                      \
+  if ((g) == 7) piece(3, 0, t1.vpos, 0, vs_slot);                                                                      \
+  __builtin_amdgcn_sched_barrier(0)
+#define LX_GAP4(g, SC, SN) LX_GAP(g, SC, SN); LX_GAP((g) + 1, SC, SN); LX_GAP((g) + 2, SC, SN); LX_GAP((g) + 3, SC, SN)
+
+  // One iteration: softmax(t) + PV(t) + QK(t+1).  SC = scores of tile t (complete), SN = scores of tile t+1 (written).
+#define LX_ITER(SC, SN)                                                                                                \
+  {                                                                                                                    \
+    const int ks_slot = t & 1, vs_slot = (t + 1) & 1;                                                                  \
+    bq = ((t + 1) & 1) * STAGE_BYTES;                                                                                  \
+    bv = (t & 1) * STAGE_BYTES;                                                                                        \
+    LX_WAITL(0);                                                                                                       \
+    LX_RDP(0, 32, false); LX_RDP(1, 32, false); LX_RDP(2, 32, false); LX_RDP(3, 32, false); LX_RDP(4, 32, false); LX_RDP(5, 32, false); \
+    /* ---- row max of tile t, under the first LDS round trip ---- */                                                  \
+    const float bl = t0.bl;                                                                                            \
+    if (t0.nvalid < KVBLK) {            /* ragged last tile of the segment: mask keys past its end */                  \
+      __builtin_amdgcn_sched_barrier(0); /* keeps this a wave-uniform branch: if-converted it is ~100 VALU on every tile */ \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {                \
+        const int key = 4 * lhi + kb * 32 + 8 * (r >> 2) + (r & 3);                                                    \
+        if (key >= t0.nvalid) SC[kb][r] = -1e30f;                                                                      \
+      }                                                                                                                \
+    }                                                                                                                  \
+    float tmax;                                                                                                        \
+    {   /* four independent v_max3 chains instead of one 16-deep dependent chain */                                    \
+      float m_[4];                                                                                                     \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                  \
+        const int kb = c >> 1, r0 = (c & 1) * 8;                                                                       \
+        m_[c] = __builtin_fmaxf(__builtin_fmaxf(SC[kb][r0], SC[kb][r0 + 1]), SC[kb][r0 + 2]);                          \
+        m_[c] = __builtin_fmaxf(__builtin_fmaxf(m_[c], SC[kb][r0 + 3]), SC[kb][r0 + 4]);                               \
+        m_[c] = __builtin_fmaxf(__builtin_fmaxf(m_[c], SC[kb][r0 + 5]), SC[kb][r0 + 6]);                               \
+        m_[c] = __builtin_fmaxf(m_[c], SC[kb][r0 + 7]);                                                                \
+      }                                                                                                                \
+      tmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m_[0], m_[1]), m_[2]), m_[3]);                            \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);   \
+      tmax = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                                  \
+    }                                                                                                                  \
+    const float t_new = tmax * c2 + bl;                                                                                \
+    bool rescale = true;                                                                                               \
+    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;                                  \
+    if (rescale) {                                                                                                     \
+      const float m_new = fmaxf(m_run, t_new);                                                                         \
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                       \
+      l_run *= alpha;                                                                                                  \
+      m_run = m_new;                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha; \
+    }                                                                                                                  \
+    off = bl - m_run;                                                                                                  \
+    asm volatile("" : "+v"(off));                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    LX_GAP4(0, SC, SN); LX_GAP4(4, SC, SN); LX_GAP4(8, SC, SN); LX_GAP4(12, SC, SN);                                   \
+    LX_GAP4(16, SC, SN); LX_GAP4(20, SC, SN); LX_GAP4(24, SC, SN); LX_GAP4(28, SC, SN);                                \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    LX_BARRIER();                                                                                                      \
+    t0 = t1; t1 = t2;                                                                                                  \
+    gen_next();                                                                                                        \
+    t2 = g_cur;                                                                                                        \
+    ++t;                                                                                                               \
+  }
+
+  int t = 0;
+  if (t0.nvalid > 0) {
+    piece(0, t0.krow, 0, t0.nclamp, 0); piece(1, t0.krow, 0, t0.nclamp, 0);
+    piece(2, 0, t0.vpos, 0, 0); piece(3, 0, t0.vpos, 0, 0);
+    piece(0, t1.krow, 0, t1.nclamp, 1); piece(1, t1.krow, 0, t1.nclamp, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LX_BARRIER();
+    // prologue: scores of tile 0
+    LX_WAITL(0);
+    LX_RDP(0, 16, true); LX_RDP(1, 16, true); LX_RDP(2, 16, true); LX_RDP(3, 16, true); LX_RDP(4, 16, true); LX_RDP(5, 16, true);
+#define LX_PG(g) LX_WAITL((15 - (g)) < (LOOK - 1) ? (15 - (g)) : (LOOK - 1)); LX_MM(g, sA, sA, true); LX_RD((g) + LOOK, 16, true)
+    LX_PG(0); LX_PG(1); LX_PG(2); LX_PG(3); LX_PG(4); LX_PG(5); LX_PG(6); LX_PG(7);
+    LX_PG(8); LX_PG(9); LX_PG(10); LX_PG(11); LX_PG(12); LX_PG(13); LX_PG(14); LX_PG(15);
+#undef LX_PG
+    // ALT: the two waves of a SIMD take turns. Waves 4-7 wait one barrier before each iteration, waves 0-3 one after it, so
+    // the hardware barrier (which only counts arrivals) pairs "A finished iteration t" with "B may start iteration t": one
+    // wave streams while its SIMD partner is parked in s_barrier and holds no pending MFMA (a pending MFMA blocks the VALU
+    // port for both). The staging rules are unchanged: K(t+2) / V(t+1) are issued inside iteration t, after every reader of
+    // K(t) / V(t-1) has passed the barrier that ended iteration t-1 for BOTH groups, and drained before the barrier that ends it.
+    while (true) {
+      if (ALT && grp_b) { LX_BARRIER(); }
+      LX_ITER(sA, sB);
+      if (ALT && !grp_b) { LX_BARRIER(); }
+      if (t0.nvalid == 0) break;
+      if (ALT && grp_b) { LX_BARRIER(); }
+      LX_ITER(sB, sA);
+      if (ALT && !grp_b) { LX_BARRIER(); }
+      if (t0.nvalid == 0) break;
+    }
+  }
+#undef LX_ITER
+#undef LX_GAP4
+#undef LX_GAP
+#undef LX_HALF
+#undef LX_MM
+#undef LX_RD
+#undef LX_RDP
+#undef LX_WAITL
+#undef LX_DSR
+#undef LX_BARRIER
+#undef LX_FENCE
+
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (q_valid) {
@@ -226,6 +555,12 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG(d->B >= 1 && d->H >= 1, "lx_attn_fwd: bad B/H");
   LX_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd: ldq/ldk %% 8, ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 8 == 0 && d->k_col % 8 == 0 && d->o_col % 4 == 0, "lx_attn_fwd: column offsets must be 16-byte aligned");
+  // variant: LX_ATTN_PIPE=0|1 (software-pipelined 8-wave kernel), LX_ATTN_NW=4|8 (plain kernel: waves per workgroup),
+  // LX_ATTN_DEFER=0|1 (deferred max rescale); defaults 1 / 8 / 1
+  static const bool piped = [] { const char* e = getenv("LX_ATTN_PIPE"); return e ? atoi(e) != 0 : true; }();
+  static const int nw = [] { const char* e = getenv("LX_ATTN_NW"); const int v = e ? atoi(e) : 8; return (v == 4 && !piped) ? 4 : 8; }();
+  static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
+  const int qblk = nw * 32;
   AttnArgs a;
   a.d = *d;
   int t = 0;
@@ -237,12 +572,25 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
       bool any = false;
       for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
       LX_CHECK_ARG(any, "lx_attn_fwd: query segment %d is masked from every key segment", s);
-      t += (d->seg_len[s] + QBLK - 1) / QBLK;
+      t += (d->seg_len[s] + qblk - 1) / qblk;
     }
   }
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
-  hipLaunchKernelGGL(lx_attn_kernel, dim3(grid), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  static const bool alt = [] { const char* e = getenv("LX_ATTN_ALT"); return e ? atoi(e) != 0 : false; }();
+  if (piped) {
+    if (defer && alt) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a);
+    else if (alt) hipLaunchKernelGGL((lx_attn_pipe_kernel<false, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false, false>), dim3(grid), dim3(512), 0, st, a);
+  } else if (nw == 8) {
+    if (defer) hipLaunchKernelGGL((lx_attn_kernel<8, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_kernel<8, false>), dim3(grid), dim3(512), 0, st, a);
+  } else {
+    if (defer) hipLaunchKernelGGL((lx_attn_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
+  }
   LX_LAUNCH_CHECK("lx_attn_fwd");
   return LX_OK;
 }

@@ -6,7 +6,8 @@ buf=torch.randn(M,3*D,device=dev).to(torch.bfloat16)
 row0=[0,B*512,B*1536]; vt0=[0,512,1536]
 VT=torch.zeros(B,H,128,2560,dtype=torch.bfloat16,device=dev)
 ops.qkv_prep_segs(buf,2*D,0,D,[(row0[i],lens[i],vt0[i],None,None,None,None) for i in range(3)],B,H,VT)
-def run(): ops.attn_fwd(buf,buf,VT,buf,q_col=2*D,k_col=0,o_col=2*D,B=B,H=H,seg_row0=row0,seg_len=list(lens),seg_vt0=vt0)
+obuf=torch.zeros(M,D,dtype=torch.bfloat16,device=dev)
+def run(): ops.attn_fwd(buf,buf,VT,obuf,q_col=2*D,k_col=0,o_col=0,B=B,H=H,seg_row0=row0,seg_len=list(lens),seg_vt0=vt0)
 for _ in range(5): run()
 torch.cuda.synchronize()
 s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
