@@ -326,16 +326,18 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const int k_key = wave * 4 + (lane >> 4);                                              // + 32 for the second piece
   const uint32_t k_slot_off = (uint32_t)((((lane & 15) ^ (k_key & 15)) * 8) * 2);
   const uint32_t v_lane_off = (uint32_t)(((wave * 8 + (lane >> 3)) * vt_ld + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) * 8)) * 2);
+  // (buffer addressing: the SRSRC is rebuilt from the wave-uniform origin with scalar instructions; in the GEMM loop this form
+  // measured 260 fewer stall cycles per 16 pieces than flat-global addresses)
   auto piece = [&](int j, int krow, int vpos, int nclamp, int slot) {
     char* base = smem + slot * STAGE_BYTES;
     if (j < 2) {
-      const char* org = (const char*)(Kbase + (size_t)krow * ldk);                                       // wave-uniform
+      const lx_rsrc_t rs = lx_make_rsrc(Kbase + (size_t)krow * ldk);                                     // wave-uniform
       const uint32_t off_ = (uint32_t)(min(k_key + j * 32, nclamp - 1) * ldk * 2) + k_slot_off;
-      __builtin_amdgcn_global_load_lds((gptr_t)(org + off_), (lptr_t)(base + (j * NW + wave) * 1024), 16, 0, 0);
+      lx_buf_to_lds(rs, (lptr_t)(base + (j * NW + wave) * 1024), off_, 0);
     } else {
       const int jj = j - 2;
-      const char* org = (const char*)(Vbase + (size_t)(jj * NW * 8) * vt_ld + vpos);                     // wave-uniform
-      __builtin_amdgcn_global_load_lds((gptr_t)(org + v_lane_off), (lptr_t)(base + K_BYTES + (jj * NW + wave) * 1024), 16, 0, 0);
+      const lx_rsrc_t rs = lx_make_rsrc(Vbase + (size_t)(jj * NW * 8) * vt_ld + vpos);                   // wave-uniform
+      lx_buf_to_lds(rs, (lptr_t)(base + K_BYTES + (jj * NW + wave) * 1024), v_lane_off, 0);
     }
   };
   // Wave-uniform KV-tile descriptors. `gen` walks (segment, tile) over the segments this query segment may attend to; the

@@ -37,6 +37,21 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_floa
 // converts (v_cvt_pk_bf16_f32) -- branch-free, NaN-safe. (A hand-rolled bit trick with a NaN branch compiles to
 // divergent exec-mask code per element and was 10x slower inside the attention loop.)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// Buffer-addressed LDS-DMA: 16 B per lane straight into LDS, source = SRSRC (wave-uniform origin) + per-lane byte offset +
+// scalar offset. Device pass only: the host pass of hipcc must still be able to emit the kernel stubs.
+typedef __attribute__((address_space(3))) void* lx_lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t lx_rsrc_t;
+__device__ __forceinline__ lx_rsrc_t lx_make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ void lx_buf_to_lds(lx_rsrc_t r, lx_lds_ptr_t l, uint32_t voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, 16, voff, soff, 0, 0);
+}
+#else
+typedef int lx_rsrc_t;
+__host__ __device__ inline lx_rsrc_t lx_make_rsrc(const void*) { return 0; }
+__host__ __device__ inline void lx_buf_to_lds(lx_rsrc_t, lx_lds_ptr_t, uint32_t, int) {}
+#endif
+
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   bf16x2 v = {(__bf16)lo, (__bf16)hi};

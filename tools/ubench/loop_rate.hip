@@ -8,6 +8,8 @@
 //               operands instead of zeros (DVFS: operand toggling costs power, power costs clock)
 //         bit12: DMA pieces spread one per MFMA group over the whole K tile (A pieces first, then W; vmcnt(4) at the barrier
 //                as a 3-deep W ring allows) instead of a burst of 8 per wave behind the barrier
+//         bit13: DMA source as wave-uniform base (SGPR pair) + per-lane 32-bit offset (global saddr form)
+//         bit14: DMA through buffer addressing (raw_buffer_load_lds: SRSRC + 32-bit voffset + soffset)
 //         bit6: fine interleave: one ds_read after each of the first six MFMAs of a k-step instead of a burst of six
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,17 +46,31 @@ __global__ __launch_bounds__(512) void kloop(const __bf16* A, const __bf16* W, f
     for (int j = 0; j < 4; ++j) wsrc[j] = W + ((size_t)tn * (K / BK)) * (BN * BK) + ((j * 8 + wave) * 512 + lane * 8);
   }
   bool force_stage = (FLAGS & 128) != 0;
+  // alternative addressing forms: 32-bit per-lane byte offsets relative to the (wave-uniform) operand base
+  uint32_t aoff32[MI], woff32[4];
+  for (int j = 0; j < MI; ++j) aoff32[j] = (uint32_t)((const char*)asrc[j] - (const char*)A);
+  for (int j = 0; j < 4; ++j) woff32[j] = (uint32_t)((const char*)wsrc[j] - (const char*)W);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
   auto stage_a = [&](int kt, int slot) {
     if (!DMA && !force_stage) return;
     char* base = smem + slot * A_BYTES;
 #pragma unroll
-    for (int j = 0; j < MI; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + kt * BK), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+    for (int j = 0; j < MI; ++j) {
+      if (FLAGS & 16384) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (j * 8 + wave) * 1024), 16, aoff32[j], kt * BK * 2, 0, 0);
+      else if (FLAGS & 8192) __builtin_amdgcn_global_load_lds((gptr_t)((const char*)A + kt * BK * 2 + aoff32[j]), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + kt * BK), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
   };
   auto stage_w = [&](int kt, int slot) {
     if (!DMA && !force_stage) return;
     char* base = smem + W_BASE + slot * W_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)kt * BN * BK), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      if (FLAGS & 16384) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(base + (j * 8 + wave) * 1024), 16, woff32[j], kt * BN * BK * 2, 0, 0);
+      else if (FLAGS & 8192) __builtin_amdgcn_global_load_lds((gptr_t)((const char*)W + (size_t)kt * BN * BK * 2 + woff32[j]), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)kt * BN * BK), (lptr_t)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
   };
   auto piece = [&](int p, int kt, int slot) {   // p 0..3: A pieces, 4..7: W pieces of K tile kt
     if (!DMA || kt >= nkt) return;
@@ -201,7 +217,7 @@ extern "C" int run_loop(int flags, const void* A, const void* W, float* out, int
   hipStream_t s = (hipStream_t)stream;
   switch (flags) {
     CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(6) CASE(2) CASE(4)
-    CASE(31) CASE(47) CASE(46) CASE(30) CASE(76) CASE(77) CASE(78) CASE(79) CASE(110) CASE(111) CASE(74) CASE(75) CASE(14+4096) CASE(10+4096) CASE(10+128+4096) CASE(8+128) CASE(9+128) CASE(10+128) CASE(11+128) CASE(12+0x100) CASE(12+0x300) CASE(12+0x500) CASE(12+0x800) CASE(12+0x800+0x300) CASE(12+0x800+0x500)
+    CASE(31) CASE(47) CASE(46) CASE(30) CASE(76) CASE(77) CASE(78) CASE(79) CASE(110) CASE(111) CASE(74) CASE(75) CASE(10+128+8192) CASE(10+128+16384) CASE(14+8192) CASE(14+16384) CASE(14+4096) CASE(10+4096) CASE(10+128+4096) CASE(8+128) CASE(9+128) CASE(10+128) CASE(11+128) CASE(12+0x100) CASE(12+0x300) CASE(12+0x500) CASE(12+0x800) CASE(12+0x800+0x300) CASE(12+0x800+0x500)
     default: return -1;
   }
   return (int)hipGetLastError();
