@@ -152,13 +152,13 @@ def main():
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             # HBM-side traffic per launch is not observable from inside the process: it comes from the committed rocprofv3
-            # PMC passes of this same workload (profiles/r01_pmc_*.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+            # PMC passes of this same workload (profiles/r01c_pmc_*.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
             # launch-weighted mean over the GEMM launches of one step), or null if that summary is absent.
             traffic = None
             try:
                 import re
                 tot, n_l = 0.0, 0
-                for fn, key, mult in (("r01_pmc_FETCH.txt", "FETCH_SIZE", 2.0), ("r01_pmc_WRITE.txt", "WRITE_SIZE", 1.0)):
+                for fn, key, mult in (("r01c_pmc_FETCH.txt", "FETCH_SIZE", 2.0), ("r01c_pmc_WRITE.txt", "WRITE_SIZE", 1.0)):
                     n_l = 0
                     for line in open(os.path.join(ROOT, "profiles", fn)):
                         if "lx_gemm_kernel" in line:
@@ -169,12 +169,12 @@ def main():
                 traffic = None
             res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                               "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01_pmc_*.txt)",
+                               "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01c_pmc_*.txt)",
                                "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
                                "share_of_step_time": round(gm["ms"] / (elapsed_ms / a.steps), 3)}
             if at:
                 aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                res["roofline_attention"] = {"bound": "mfma", "kernel": "lx_attn_kernel", "achieved": round(aa, 1), "peak": PEAK_BF16_TFLOPS,
+                res["roofline_attention"] = {"bound": "mfma", "kernel": "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)", "achieved": round(aa, 1), "peak": PEAK_BF16_TFLOPS,
                                              "unit": "TFLOP/s", "frac": round(aa / PEAK_BF16_TFLOPS, 4), "launches": at["launches"],
                                              "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
                                              "share_of_step_time": round(at["ms"] / (elapsed_ms / a.steps), 3)}
