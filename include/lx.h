@@ -161,6 +161,22 @@ typedef struct lx_attn_desc {
 } lx_attn_desc;
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) attention path -- BASELINE configs[4] ("fp8 MFMA attention path"); opt-in, the bf16 path above is the
+ * default. lx_qkv_prep_fp8_segs does the arithmetic of lx_qkv_prep_segs (RMSNorm + RoPE in fp32, block.py:75-99) but
+ * leaves the bf16 buffer untouched and writes byte images instead:
+ *   Q8, K8 : [rows, ld8] e4m3, head h at byte column h*128, values multiplied by q_scale / k_scale;
+ *   VT8    : [B, H, 128, vt8_ld] e4m3, V * v_scale transposed per head, the 64 keys of every tile stored in the order
+ *            the 32x32x64 f8f6f4 MFMA's B operand wants (attn.hip, lx_attn_fp8_kernel).
+ * lx_attn_fwd_fp8 takes the same descriptor as lx_attn_fwd with Q / K / VT pointing at those images (ldq, ldk, q_col, k_col,
+ * vt_ld in bytes; O is bf16 as before) plus qk_descale = 1 / (q_scale * k_scale) and v_descale = 1 / v_scale.
+ * Softmax statistics and the output accumulators are fp32; P is rounded to e4m3.
+ * ------------------------------------------------------------------------------------------------ */
+int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                         int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                         float q_scale, float k_scale, float v_scale, void* stream);
+int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_descale, void* stream);
+
 /* x(fp32) += dsigma * v   (FlowMatchEulerDiscreteScheduler.step, generate.py:349); v is bf16 or fp32 */
 int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream);
 /* dst(fp32)[i] = src(fp32|bf16)[i] ; dst(bf16) = src(fp32) : layout plumbing between streams */

@@ -65,6 +65,8 @@ _SIGS = {
     "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
+    "lx_qkv_prep_fp8_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _P, _I, _P, _I, _F, _F, _F, _P]),
+    "lx_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnDesc), _F, _F, _P]),
     "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),
     "lx_convert": (C.c_int, [_P, _I, _P, _I, _Z, _P]),
     "lx_s4_scan": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

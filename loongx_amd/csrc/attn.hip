@@ -549,6 +549,201 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) attention: BASELINE configs[4] names an "fp8 MFMA attention path". Q, K and V^T come as byte images written
+// by lx_qkv_prep_fp8_segs; both products run on v_mfma_f32_32x32x64_f8f6f4 (64-deep, twice the bf16 rate): a 64-key tile is
+// 4 MFMAs for S^T = K.Q^T (two key blocks x two 64-wide halves of d) and 4 for O^T += V^T.P^T (four d blocks, the whole tile
+// as the k dimension) instead of 16 + 16. Softmax, running max / sum and the O accumulators stay fp32; P is rounded to e4m3
+// (values <= 2^DEFER_THR = 256 < 448). Operand convention of the f8f6f4 MFMA (checked on hardware, tools/ubench/fp8_mfma):
+// lane (row = lane % 32, g = lane / 32) supplies 32 bytes, and byte p of group g is the same k index on both operands. So the
+// K / Q fragments simply take d = half*64 + g*32 + p, the P fragment is the lane's own 32 probabilities in register order
+// (p = kb*16 + r), and the V^T image stores its keys in exactly that order (qkv_prep_fp8_kernel, vt8_key()).
+// Structure: the plain 8-wave kernel (two waves per SIMD); stage = 8 KiB K (64 keys x 128 B, slot ^= (key>>1)&7) + 8 KiB V^T
+// (128 d x 64 B, slot ^= (d>>2)&3), double buffered, one 1-KiB LDS-DMA piece per wave and operand.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+constexpr int K8_BYTES = KVBLK * DH;        // 8 KiB
+constexpr int V8_BYTES = DH * KVBLK;        // 8 KiB
+constexpr int STAGE8_BYTES = K8_BYTES + V8_BYTES;
+
+template <bool DEFER>
+__global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args, float qk_descale, float v_descale) {
+  constexpr int QBLK = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE8_BYTES];
+  const lx_attn_desc& D = args.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int BH = D.B * D.H;
+  const int bh = blockIdx.x % BH;
+  const int qt = blockIdx.x / BH;
+  const int b = bh / D.H, h = bh % D.H;
+  int sq = 0;
+#pragma unroll
+  for (int s = 1; s < 3; ++s)
+    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
+  const int q_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 32 + l31;
+  const int q_len = D.seg_len[sq];
+  const bool q_valid = q_in_seg < q_len;
+  const size_t q_row = (size_t)D.seg_row0[sq] + (size_t)b * q_len + min(q_in_seg, q_len - 1);
+
+  // Q fragments: lane (q = l31, g = lhi) holds d = half*64 + g*32 .. +32 for half = 0, 1
+  i32x8 qf[2];
+  {
+    const uint8_t* qp = (const uint8_t*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 32;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const u32x4 lo = *(const u32x4*)(qp + hf * 64), hi = *(const u32x4*)(qp + hf * 64 + 16);
+      qf[hf] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    }
+  }
+  const float c2 = D.scale * qk_descale * 1.4426950408889634f;
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const uint8_t* Kbase = (const uint8_t*)D.K + D.k_col + h * DH;
+  const uint8_t* Vbase = (const uint8_t*)D.VT + (size_t)bh * DH * D.vt_ld;
+  auto stage = [&](int sk, int kt, int buf) {
+    char* base = smem + buf * STAGE8_BYTES;
+    const int klen = D.seg_len[sk];
+    const size_t krow0 = (size_t)D.seg_row0[sk] + (size_t)b * klen;
+    {  // K: this wave's piece = 8 key rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
+      const int key = wave * 8 + (lane >> 3);
+      const int lslot = (lane & 7) ^ ((key >> 1) & 7);
+      const int kin = min(kt * KVBLK + key, klen - 1);
+      const uint8_t* src = Kbase + (krow0 + kin) * D.ldk + lslot * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + wave * 1024), 16, 0, 0);
+    }
+    {  // V^T: this wave's piece = 16 d rows of 64 B; lane -> (row = lane>>2, slot = lane&3)
+      const int drow = wave * 16 + (lane >> 2);
+      const int lslot = (lane & 3) ^ ((drow >> 2) & 3);
+      const uint8_t* src = Vbase + (size_t)drow * D.vt_ld + D.seg_vt0[sk] + kt * KVBLK + lslot * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + K8_BYTES + wave * 1024), 16, 0, 0);
+    }
+  };
+  auto seg_ok = [&](int s) { return D.bias[sq][s] > -1e37f; };
+  auto advance = [&](int& sk, int& kt) {
+    ++kt;
+    while (sk < D.n_seg && (kt * KVBLK >= D.seg_len[sk] || !seg_ok(sk))) { ++sk; kt = 0; }
+  };
+  int sk = 0, kt = -1;
+  advance(sk, kt);
+
+  const int ksw = (l31 >> 1) & 7;     // K rows (128 B): slot ^= (key >> 1) & 7
+  const int vsw = (l31 >> 2) & 3;     // V^T rows (64 B): slot ^= (d >> 2) & 3   (rows db*32 + l31: (row >> 2) & 3 == (l31 >> 2) & 3)
+  auto frag = [&](const char* p0, int slot_a, int sw) {   // 32 bytes = 16-B slots slot_a, slot_a + 1 (slot_a even) of one row
+    const u32x4 lo = *(const u32x4*)(p0 + ((slot_a ^ sw) * 16)), hi = *(const u32x4*)(p0 + (((slot_a + 1) ^ sw) * 16));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  if (sk < D.n_seg) stage(sk, kt, 0);
+  int buf = 0;
+  while (sk < D.n_seg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int nsk = sk, nkt = kt;
+    advance(nsk, nkt);
+    if (nsk < D.n_seg) stage(nsk, nkt, buf ^ 1);
+    const char* sb = smem + buf * STAGE8_BYTES;
+
+    // ---- S^T = K . Q^T : sacc[kb][r] <-> key = kb*32 + 8*(r>>2) + 4*lhi + (r&3), query = l31 -------------------
+    f32x16 sacc[2];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const char* krow = sb + (kb * 32 + l31) * 128;
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(krow, 0 + lhi * 2, ksw), qf[0], z, 0, 0, 0, 0, 0, 0);
+      sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(krow, 4 + lhi * 2, ksw), qf[1], sacc[kb], 0, 0, 0, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- online softmax (log2 domain), as in the bf16 kernels ------------------------------------------------
+    const float bl = D.bias[sq][sk] * 1.4426950408889634f;
+    const int klen = D.seg_len[sk];
+    const int kbase = kt * KVBLK + 4 * lhi;
+    if (kt * KVBLK + KVBLK > klen) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kb * 32 + 8 * (r >> 2) + (r & 3);
+          if (key >= klen) sacc[kb][r] = -1e30f;
+        }
+    }
+    float tmax = fmaxf(sacc[0][0], sacc[0][1]);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float t_new = tmax * c2 + bl;
+    bool rescale = true;
+    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;
+    if (rescale) {
+      const float m_new = fmaxf(m_run, t_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    const float off = bl - m_run;
+    float psum = 0.f;
+    i32x8 pf;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float pv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          pv[c] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][rq * 4 + c], c2, off));
+          psum += pv[c];
+        }
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], w, true);
+        pf[kb * 4 + rq] = w;                          // byte p = kb*16 + r of this lane group's 32 k positions
+      }
+    l_run += psum;
+    // ---- O^T += V^T . P^T : one MFMA per 32-row d block, k = the tile's 64 keys ---------------------------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const char* vrow = sb + K8_BYTES + (db * 32 + l31) * 64;
+      oacc[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(vrow, lhi * 2, vsw), pf, oacc[db], 0, 0, 0, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    sk = nsk;
+    kt = nkt;
+    buf ^= 1;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
+  if (q_valid) {
+    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 o;
+        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        *(u32x2*)(op + db * 32 + rq * 8) = o;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
@@ -594,5 +789,35 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
     else hipLaunchKernelGGL((lx_attn_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
   }
   LX_LAUNCH_CHECK("lx_attn_fwd");
+  return LX_OK;
+}
+
+extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_descale, void* stream) {
+  LX_CHECK_ARG(d && d->Q && d->K && d->VT && d->O, "lx_attn_fwd_fp8: NULL operand");
+  LX_CHECK_ARG(d->n_seg >= 1 && d->n_seg <= 3, "lx_attn_fwd_fp8: n_seg=%d must be 1..3", d->n_seg);
+  LX_CHECK_ARG(d->B >= 1 && d->H >= 1, "lx_attn_fwd_fp8: bad B/H");
+  LX_CHECK_ARG(d->ldq % 16 == 0 && d->ldk % 16 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd_fp8: ldq/ldk %% 16 (bytes), ldo %% 4, vt_ld %% 64 required");
+  LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
+  LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
+  static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
+  AttnArgs a;
+  a.d = *d;
+  int t = 0;
+  for (int s = 0; s < 3; ++s) {
+    a.qt_start[s] = t;
+    if (s < d->n_seg) {
+      LX_CHECK_ARG(d->seg_len[s] >= 1, "lx_attn_fwd_fp8: empty segment %d", s);
+      LX_CHECK_ARG(d->seg_vt0[s] % 64 == 0, "lx_attn_fwd_fp8: seg_vt0 must be 64-aligned");
+      bool any = false;
+      for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
+      LX_CHECK_ARG(any, "lx_attn_fwd_fp8: query segment %d is masked from every key segment", s);
+      t += (d->seg_len[s] + 255) / 256;
+    }
+  }
+  a.qt_start[3] = t;
+  const int grid = t * d->B * d->H;
+  if (defer) hipLaunchKernelGGL((lx_attn_fp8_kernel<true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
+  else hipLaunchKernelGGL((lx_attn_fp8_kernel<false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
+  LX_LAUNCH_CHECK("lx_attn_fwd_fp8");
   return LX_OK;
 }

@@ -215,6 +215,113 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
 }
 
 // ------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) variant for the fp8 attention path (BASELINE configs[4]): the same RMSNorm + RoPE arithmetic in fp32,
+// but q and k go to separate byte images Q8 / K8 [rows, H*128] scaled by q_scale / k_scale, and V to a byte V^T image whose
+// 64 keys per tile are ordered for the 32x32x64 f8f6f4 MFMA's B operand: byte j = g*32 + p of a tile row holds key
+// (p>>4)*32 + 8*((p&15)>>2) + 4*g + (p&3), i.e. exactly the order in which lane group g of the attention kernel holds its 32
+// probabilities (lx_attn_fp8_kernel). The bf16 QKV buffer is left untouched.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(c), clamp_e4m3(d), w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ int vt8_key(int j) {   // byte position within a 64-key tile row -> key
+  const int g = j >> 5, p = j & 31;
+  return (p >> 4) * 32 + 8 * ((p & 15) >> 2) + 4 * g + (p & 3);
+}
+
+__global__ __launch_bounds__(256) void qkv_prep_fp8_kernel(const uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
+                                                           const QkvSegs segs, float eps, uint8_t* __restrict__ Q8,
+                                                           uint8_t* __restrict__ K8, int ld8, uint8_t* __restrict__ VT8, int vt_ld,
+                                                           int H, float q_scale, float k_scale, float v_scale) {
+  __shared__ uint16_t vt_s[64][128 + 8];
+  int sg = 0;
+  while (sg < segs.n - 1 && (int)blockIdx.x >= segs.tile0[sg + 1]) ++sg;
+  const int p0 = ((int)blockIdx.x - segs.tile0[sg]) * 64;
+  const int row0 = segs.row0[sg], rows_per_batch = segs.rows_per_batch[sg], vt_pos0 = segs.vt_pos0[sg];
+  const float* __restrict__ wq = segs.wq[sg];
+  const float* __restrict__ wk = segs.wk[sg];
+  const float* __restrict__ cos_tab = segs.cos_tab[sg];
+  const float* __restrict__ sin_tab = segs.sin_tab[sg];
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int sub = tid & 15;
+  const int rloc = tid >> 4;
+  const size_t rbase = (size_t)row0 + (size_t)b * rows_per_batch;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int p = p0 + pass * 16 + rloc;
+    const bool valid = p < rows_per_batch;
+    const size_t grow = rbase + (valid ? p : 0);
+    const uint16_t* rowp = QKV + grow * ld + h * 128 + sub * 8;
+    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (cos_tab && valid) {
+      const float* ct = cos_tab + (size_t)p * 128 + sub * 8;
+      const float* st = sin_tab + (size_t)p * 128 + sub * 8;
+      c0 = *(const f32x4*)ct; c1 = *(const f32x4*)(ct + 4);
+      s0 = *(const f32x4*)st; s1 = *(const f32x4*)(st + 4);
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {   // 0: q, 1: k
+      const float* wn = which ? wk : wq;
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (valid) raw = *(const u32x4*)(rowp + (which ? k_col : q_col));
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[2 * i] = __uint_as_float(raw[i] << 16);
+        x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+      }
+      if (wn) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+        const f32x4 w0 = *(const f32x4*)(wn + sub * 8), w1 = *(const f32x4*)(wn + sub * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = x[i] * r * w0[i]; x[4 + i] = x[4 + i] * r * w1[i]; }
+      }
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ce = i < 2 ? c0[2 * i] : c1[2 * i - 4], co = i < 2 ? c0[2 * i + 1] : c1[2 * i - 3];
+        const float se = i < 2 ? s0[2 * i] : s1[2 * i - 4], so = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
+        y[2 * i] = x[2 * i] * ce - x[2 * i + 1] * se;
+        y[2 * i + 1] = x[2 * i + 1] * co + x[2 * i] * so;
+      }
+      if (valid) {
+        const float sc = which ? k_scale : q_scale;
+        u32x2 o;
+        o[0] = pack_fp8x4(y[0] * sc, y[1] * sc, y[2] * sc, y[3] * sc);
+        o[1] = pack_fp8x4(y[4] * sc, y[5] * sc, y[6] * sc, y[7] * sc);
+        *(u32x2*)((which ? K8 : Q8) + grow * ld8 + h * 128 + sub * 8) = o;
+      }
+    }
+    u32x4 raw = {0u, 0u, 0u, 0u};
+    if (valid) raw = *(const u32x4*)(rowp + v_col);
+    *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = raw;
+  }
+  __syncthreads();
+  // V^T byte image: thread -> (d, 16 consecutive byte positions of the 64-key tile row)
+  uint8_t* vtb = VT8 + ((size_t)(b * H + h) * 128) * vt_ld + vt_pos0 + p0;
+  for (int item = tid; item < 128 * 4; item += 256) {
+    const int d = item >> 2, c = item & 3;
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = __uint_as_float((uint32_t)vt_s[vt8_key(c * 16 + i)][d] << 16) * v_scale;
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_fp8x4(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]);
+    *(u32x4*)(vtb + (size_t)d * vt_ld + c * 16) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // LoRA down-projection: T[M,R<=16] = X[M,K] . A[R,K]^T (bf16 in, fp32 out) on v_mfma_f32_16x16x32_bf16.
 // Workgroup = 8 waves = 16 rows; the waves split K eight ways and reduce through LDS. A is the MFMA "A"
 // operand (rows = r), X the "B" operand (cols = m): each lane ends with 4 consecutive r of one row m.
@@ -429,6 +536,33 @@ extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_c
     segs.wq[i] = seg[i].wq; segs.wk[i] = seg[i].wk; segs.cos_tab[i] = seg[i].cos_tab; segs.sin_tab[i] = seg[i].sin_tab;
   }
   return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_batches, H, eps, VT, vt_ld, stream);
+}
+
+extern "C" int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                                    int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                                    float q_scale, float k_scale, float v_scale, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_qkv_prep_fp8_segs: 1..3 segments");
+  LX_CHECK_ARG(QKV && Q8 && K8 && VT8 && n_batches > 0 && H > 0, "lx_qkv_prep_fp8_segs: bad arguments");
+  LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep_fp8_segs: ld and column offsets must be multiples of 8");
+  LX_CHECK_ARG(ld8 % 16 == 0 && vt8_ld % 64 == 0, "lx_qkv_prep_fp8_segs: ld8 %% 16 and vt8_ld %% 64 required");
+  LX_CHECK_ARG(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f, "lx_qkv_prep_fp8_segs: scales must be positive");
+  QkvSegs segs;
+  segs.n = n_seg;
+  int t = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.rows_per_batch[i] = seg[i].rows_per_batch; segs.vt_pos0[i] = seg[i].vt_pos0;
+    segs.wq[i] = seg[i].wq; segs.wk[i] = seg[i].wk; segs.cos_tab[i] = seg[i].cos_tab; segs.sin_tab[i] = seg[i].sin_tab;
+    LX_CHECK_ARG(segs.rows_per_batch[i] > 0, "lx_qkv_prep_fp8_segs: empty segment %d", i);
+    LX_CHECK_ARG((segs.cos_tab[i] == nullptr) == (segs.sin_tab[i] == nullptr), "lx_qkv_prep_fp8_segs: cos/sin tables must come together");
+    LX_CHECK_ARG(segs.vt_pos0[i] % 64 == 0, "lx_qkv_prep_fp8_segs: vt_pos0 must be a multiple of 64");
+    segs.tile0[i] = t;
+    t += (segs.rows_per_batch[i] + 63) / 64;
+  }
+  segs.tile0[n_seg] = t;
+  hipLaunchKernelGGL(qkv_prep_fp8_kernel, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QKV, ld, q_col, k_col,
+                     v_col, segs, eps, (uint8_t*)Q8, (uint8_t*)K8, ld8, (uint8_t*)VT8, vt8_ld, H, q_scale, k_scale, v_scale);
+  LX_LAUNCH_CHECK("lx_qkv_prep_fp8_segs");
+  return LX_OK;
 }
 
 extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,

@@ -64,6 +64,7 @@ class DiTEngine:
         self.Y = torch.zeros(M, 7 * D, dtype=bf16, device=dev)
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
+        self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
         self.TL_SPLIT = 4                                          # K-split slabs of the LoRA down-projection
         self.TLs = torch.zeros(self.TL_SPLIT, M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]
@@ -306,6 +307,18 @@ class DiTEngine:
                 off += L
             qsegs.append((row0, L, self.vt0[s], wq_txt if s == "txt" else wq, wk_txt if s == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
+        if self.model_config.get("attn_fp8", False):
+            # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
+            # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
+            if self.Q8 is None:
+                u8 = torch.uint8
+                self.Q8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
+                self.K8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
+                self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
+            ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8)
+            ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
+                             seg_vt0=seg_vt0, bias=bias)
+            return
         ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                      seg_vt0=seg_vt0, bias=bias)

@@ -176,7 +176,7 @@ def qkv_prep_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, VT, eps=1e-6) ->
                                VT.shape[-1] if VT is not None else 0, _stream()), "lx_qkv_prep_segs")
 
 
-def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale):
     d = AttnDesc()
     d.Q, d.K, d.VT, d.O = Q.data_ptr(), K.data_ptr(), VT.data_ptr(), O.data_ptr()
     d.ldq, d.ldk, d.ldo, d.vt_ld = Q.stride(0), K.stride(0), O.stride(0), VT.shape[-1]
@@ -187,6 +187,11 @@ def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_v
         for j in range(3):
             d.bias[i][j] = 0.0 if bias is None else float(bias[i][j])
     d.scale = (1.0 / math.sqrt(128.0)) if scale is None else scale
+    return d
+
+
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+    d = _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
     if TIMER is not None:
         S = sum(seg_len)
         s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
@@ -195,6 +200,36 @@ def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_v
         e.record()
         return
     check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
+
+
+# fp8 (e4m3) attention path: fixed operand scales. q and k are RMS-normalised (|x| <= sqrt(128) * |w|), so 16 keeps them inside
+# e4m3's normal range [2^-6, 448] with headroom; v is a raw projection output and is stored unscaled (clamped to +-448).
+FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE = 16.0, 16.0, 1.0
+
+
+def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8, eps=1e-6) -> None:
+    """segs as in qkv_prep_segs; Q8 / K8: uint8 [rows, H*128]; VT8: uint8 [B, H, 128, Spad]. The bf16 QKV buffer is not modified."""
+    n = len(segs)
+    arr = (L.QkvSeg * n)()
+    for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
+        arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, vt0
+        arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
+    check(lib.lx_qkv_prep_fp8_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, Q8.data_ptr(),
+                                   K8.data_ptr(), Q8.stride(0), VT8.data_ptr(), VT8.shape[-1], FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE,
+                                   _stream()), "lx_qkv_prep_fp8_segs")
+
+
+def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+    d = _attn_desc(Q8, K8, VT8, O, 0, 0, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
+    args = (C.byref(d), 1.0 / (FP8_Q_SCALE * FP8_K_SCALE), 1.0 / FP8_V_SCALE, _stream())
+    if TIMER is not None:
+        S = sum(seg_len)
+        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        s.record()
+        check(lib.lx_attn_fwd_fp8(*args), "lx_attn_fwd_fp8")
+        e.record()
+        return
+    check(lib.lx_attn_fwd_fp8(*args), "lx_attn_fwd_fp8")
 
 
 def euler_step(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> None:

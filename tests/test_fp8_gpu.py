@@ -1,0 +1,129 @@
+"""fp8 (e4m3) attention path (BASELINE configs[4]: "fp8 MFMA attention path") against fp32 references.
+
+Tolerance (stated here, fp8-specific): e4m3 keeps 3 mantissa bits, i.e. a relative rounding error uniform in +-2^-4 (3.6 % rms)
+per element. V and the probabilities P are each rounded once; on the RANDOM, uncorrelated V of these tests the output
+sum_j p_j v_j and its rounding noise both shrink like sqrt(sum p_j^2), so the relative L2 error is sqrt(2) * 3.6 % = 5.1 % plus
+the score perturbation from rounding q and k, independent of the sequence length: measured 4.5e-2 .. 5.4e-2 on every case
+(16 to 8704 keys). The asserts allow 7e-2; the bf16 path's bound on the same tests is 6e-3."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import relerr  # noqa: E402
+from tests.test_kernels_gpu import BIASES, DEV, _attn_reference, _qkv_buffer, _segments, ops, rnd  # noqa: E402,F401
+
+TOL_FP8 = 7e-2
+
+
+def _run_fp8(ops, buf, B, H, lens, bias, wq=None, wk=None, cos=None, sin=None):
+    D = H * 128
+    row0, vt0, vt_len = _segments(B, lens)
+    M = buf.shape[0]
+    Q8 = torch.zeros(M, D, dtype=torch.uint8, device=DEV)
+    K8 = torch.zeros(M, D, dtype=torch.uint8, device=DEV)
+    VT8 = torch.zeros(B, H, 128, vt_len, dtype=torch.uint8, device=DEV)
+    segs = [(row0[s], lens[s], vt0[s], wq, wk, cos[s] if cos else None, sin[s] if sin else None) for s in range(len(lens))]
+    before = buf.clone()
+    ops.qkv_prep_fp8_segs(buf, 2 * D, 0, D, segs, B, H, Q8, K8, VT8)
+    assert torch.equal(buf, before)                                  # the bf16 buffer is an input only
+    O = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=bias)
+    return O, (Q8, K8, VT8), (row0, vt0)
+
+
+@pytest.mark.parametrize("mode", list(BIASES))
+@pytest.mark.parametrize("lens", [(16, 16, 16), (64, 128, 200), (512, 1024, 1024)])
+def test_fp8_attention_segments(ops, lens, mode):
+    B, H = (1, 2) if lens[0] == 512 else (2, 3)
+    D = H * 128
+    buf = _qkv_buffer(B, lens, H, seed=5)
+    bias = BIASES[mode]
+    O, _, (row0, _) = _run_fp8(ops, buf, B, H, lens, bias)
+    ref, edges = _attn_reference(buf, B, H, lens, bias, 2 * D, 0, D)
+    got = O.float().cpu()
+    for s, Ls in enumerate(lens):
+        o = got[row0[s]: row0[s] + B * Ls].view(B, Ls, H, 128)
+        assert relerr(o, ref[:, edges[s]:edges[s + 1]]) < TOL_FP8, f"segment {s}"
+
+
+def test_fp8_images_hold_the_normalised_rotated_values(ops):
+    """Q8 / K8 = e4m3(16 * RoPE(RMSNorm(x) * w)); VT8 = e4m3(v) in the MFMA key order."""
+    from oracle.flux_modules import apply_rotary_emb, rope_tables
+    B, H, Ls = 2, 3, 70
+    D = H * 128
+    buf = _qkv_buffer(B, [Ls], H, seed=1)
+    wq, wk = 1 + 0.1 * rnd(128, seed=2), 1 + 0.1 * rnd(128, seed=3)
+    ids = torch.zeros(Ls, 3)
+    ids[:, 1] = torch.arange(Ls) // 8
+    ids[:, 2] = torch.arange(Ls) % 8 - 3
+    cos, sin = rope_tables(ids)
+    _, (Q8, K8, VT8), _ = _run_fp8(ops, buf, B, H, (Ls,), BIASES["none"], wq=wq, wk=wk, cos=[cos.to(DEV)], sin=[sin.to(DEV)])
+    o = buf.float().cpu().view(B, Ls, 3, H, 128)
+
+    def ref(x, w):
+        x = x.permute(0, 2, 1, 3)
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w.cpu()
+        return apply_rotary_emb(x, (cos, sin)).permute(0, 2, 1, 3)
+
+    q8 = Q8.view(torch.float8_e4m3fn).float().cpu().view(B, Ls, H, 128) / ops.FP8_Q_SCALE
+    k8 = K8.view(torch.float8_e4m3fn).float().cpu().view(B, Ls, H, 128) / ops.FP8_K_SCALE
+    assert relerr(q8, ref(o[:, :, 2], wq)) < 4e-2 and relerr(k8, ref(o[:, :, 0], wk)) < 4e-2       # one e4m3 rounding per element
+    # V^T image: byte j = g*32 + p of a 64-key tile row holds key (p>>4)*32 + 8*((p&15)>>2) + 4*g + (p&3)
+    j = torch.arange(64)
+    g, p = j >> 5, j & 31
+    key = (p >> 4) * 32 + 8 * ((p & 15) >> 2) + 4 * g + (p & 3)
+    v = torch.zeros(B, 128, H, 128)
+    v[:, :Ls] = o[:, :, 1]
+    slots = torch.cat([key, 64 + key])                                # two tiles cover the 70 keys (padded to 128)
+    expect = v[:, slots].permute(0, 2, 3, 1).to(torch.float8_e4m3fn).float()
+    assert torch.equal(VT8.view(torch.float8_e4m3fn).float().cpu(), expect)
+
+
+def test_fp8_attention_at_1024sq_sequence_length(ops):
+    lens, B, H = (512, 4096, 4096), 1, 2
+    D = H * 128
+    buf = _qkv_buffer(B, lens, H, seed=21)
+    O, _, (row0, _) = _run_fp8(ops, buf, B, H, lens, BIASES["cfactor"])
+    ref, edges = _attn_reference(buf, B, H, lens, BIASES["cfactor"], 2 * D, 0, D)
+    got = O.float().cpu()
+    for s, Ls in enumerate(lens):
+        assert relerr(got[row0[s]: row0[s] + B * Ls].view(B, Ls, H, 128), ref[:, edges[s]:edges[s + 1]]) < TOL_FP8, f"segment {s}"
+
+
+def test_engine_fp8_attention_vs_bf16_path_at_1024sq():
+    """configs[4] shape end to end through the engine (full width, 1 + 1 blocks, 512 + 4096 + 4096 tokens): the velocity with
+    model_config["attn_fp8"] stays within the fp8 tolerance of the bf16 path, is deterministic and batch-independent."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import flux_modules as fm
+    from loongx_amd.flux.engine import DiTEngine
+    from loongx_amd.flux.weights import FluxConfig, synthetic_weights
+    eng = DiTEngine(synthetic_weights(FluxConfig(num_layers=1, num_single_layers=1), "cuda", seed=0), "cuda")
+    hw, T = 64, 512
+    N = hw * hw
+    ids = fm.prepare_latent_image_ids(hw, hw).cuda()
+    cids = ids.clone()
+    cids[:, 2] -= hw
+    g = torch.Generator(device="cuda").manual_seed(23)
+    B = 2
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x = dict(lat=r(B, N, 64), cond=r(B, N, 64), pe=r(B, T, 4096) * 0.1, pooled=r(B, 768))
+
+    def fwd(sl, mc):
+        n = x["lat"][sl].shape[0]
+        eng.set_conditioning(x["pe"][sl], x["pooled"][sl], torch.full((n,), 3.5, device="cuda"), torch.zeros(T, 3, device="cuda"), ids,
+                             x["cond"][sl], cids, model_config=mc)
+        return eng.forward(x["lat"][sl], torch.full((n,), 0.7, device="cuda")).clone()
+
+    ref = fwd(slice(None), {})
+    v8 = fwd(slice(None), {"attn_fp8": True})
+    assert torch.isfinite(v8).all()
+    e = relerr(v8.cpu(), ref.cpu())
+    assert 1e-4 < e < TOL_FP8, e                                         # the fp8 path is live and within its tolerance
+    assert torch.equal(v8, fwd(slice(None), {"attn_fp8": True}))
+    for i in range(B):
+        assert torch.equal(fwd(slice(i, i + 1), {"attn_fp8": True})[0], v8[i])
+    assert torch.equal(ref, fwd(slice(None), {}))                        # switching back restores the bf16 path bit for bit

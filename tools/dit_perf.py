@@ -13,6 +13,7 @@ ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--hw", type=int, default=32)
 ap.add_argument("--layers", type=int, default=19)
 ap.add_argument("--single", type=int, default=38)
+ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) attention path")
 a = ap.parse_args()
 dev = "cuda"
 cfg = FluxConfig(num_layers=a.layers, num_single_layers=a.single)
@@ -33,7 +34,8 @@ ids[..., 2] = torch.arange(a.hw, device=dev)[None, :]
 img_ids = ids.reshape(-1, 3)
 cond_ids = img_ids.clone()
 cond_ids[:, 2] -= a.hw
-eng.set_conditioning(pe, pooled, torch.full((B,), 3.5, device=dev), torch.zeros(T, 3, device=dev), img_ids, cond, cond_ids)
+eng.set_conditioning(pe, pooled, torch.full((B,), 3.5, device=dev), torch.zeros(T, 3, device=dev), img_ids, cond, cond_ids,
+                     model_config={"attn_fp8": True} if a.fp8 else {})
 ts = torch.full((B,), 0.5, device=dev)
 for _ in range(2):
     v = eng.forward(lat, ts)
