@@ -103,6 +103,28 @@ class LxFluxPipeline:
     def to(self, *a, **k):
         return self
 
+    def load_lora_weights(self, path: str, weight_name: str = "pytorch_lora_weights.safetensors", lora_scale: float = 1.0, **kwargs):
+        """diffusers `FluxPipeline.load_lora_weights` for the transformer (model.py:472): `path` is the directory the
+        reference saves with `save_lora` (model.py:526-531) or the .safetensors file itself. Replaces the adapters of the
+        packed model in place and drops every cached graph / conditioning that baked the old ones in."""
+        import os
+        from .weights import install_lora
+        f = os.path.join(path, weight_name) if os.path.isdir(path) else path
+        if not os.path.isfile(f):
+            raise FileNotFoundError(f"no LoRA weights at {f}")
+        if f.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(f)
+        else:
+            sd = torch.load(f, map_location="cpu")
+        eng = self.transformer.engine
+        n = install_lora(eng.w, sd, lora_scale=lora_scale)
+        eng.graphs = {}
+        eng.cond_ready = False
+        eng.sched = None
+        self.transformer._cond_key = None
+        return n
+
     def set_adapters(self, *a, **k):
         """Adapters are baked into the packed weights (one LoRA per checkpoint, inference.py:114 default_lora=True)."""
 

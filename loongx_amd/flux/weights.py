@@ -197,6 +197,85 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
     return pw
 
 
+def lora_layout(cfg: FluxConfig):
+    """(fused name, [diffusers module names]) of every GEMM that may carry a LoRA adapter, and the per-block modulation
+    Linear names in packed order (mod.lora_down / mod.lora_up.<idx>) -- the same grouping pack_state_dict uses."""
+    fused, mods = [], []
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        fused += [(f"d{i}.qkv", [p + "attn.to_k", p + "attn.to_v", p + "attn.to_q"]),
+                  (f"d{i}.qkv_txt", [p + "attn.add_k_proj", p + "attn.add_v_proj", p + "attn.add_q_proj"]),
+                  (f"d{i}.out", [p + "attn.to_out.0"]), (f"d{i}.out_txt", [p + "attn.to_add_out"]),
+                  (f"d{i}.ff1", [p + "ff.net.0.proj"]), (f"d{i}.ff1_txt", [p + "ff_context.net.0.proj"]),
+                  (f"d{i}.ff2", [p + "ff.net.2"]), (f"d{i}.ff2_txt", [p + "ff_context.net.2"])]
+        mods.append(p + "norm1.linear")
+    for j in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{j}."
+        fused += [(f"s{j}.fused", [p + "attn.to_k", p + "attn.to_v", p + "attn.to_q", p + "proj_mlp"]), (f"s{j}.out", [p + "proj_out"])]
+        mods.append(p + "norm.linear")
+    fused += [("x_embedder", ["x_embedder"]), ("context_embedder", ["context_embedder"]), ("proj_out", ["proj_out"])]
+    return fused, mods
+
+
+def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale: float = 1.0, prefix: str = "transformer.") -> int:
+    """Install (replace) the LoRA adapters of an already packed model from a LoRA-only state dict -- the content of the
+    `pytorch_lora_weights.safetensors` the reference loads through `flux_pipe.load_lora_weights` (model.py:463-477):
+    keys `[transformer.]<module>.lora_A[.<adapter>].weight` / `lora_B...`, optional `<module>.alpha` (then the up matrix is
+    scaled by alpha / r, as diffusers / peft do). Returns the number of adapted Linear modules. Adapters that the fused GEMMs
+    evaluate together (q/k/v[/proj_mlp] of one block) must be given for all of them or none."""
+    sd = {}
+    for k, v in lora_sd.items():
+        if prefix and k.startswith(prefix):
+            k = k[len(prefix):]
+        sd[re.sub(r"\.lora_([AB])\.[^.]+\.weight$", r".lora_\1.weight", k)] = v
+    dev = pw.t["mod.w"].device
+    used = set()
+
+    def get(name):
+        a, b = sd.get(name + ".lora_A.weight"), sd.get(name + ".lora_B.weight")
+        if a is None or b is None:
+            return None
+        used.update((name + ".lora_A.weight", name + ".lora_B.weight"))
+        sc = lora_scale
+        if name + ".alpha" in sd:
+            used.add(name + ".alpha")
+            sc *= float(sd[name + ".alpha"]) / a.shape[0]
+        return a.float(), b.float() * sc
+
+    fused, mods = lora_layout(pw.cfg)
+    n = 0
+    new_lora = {}
+    for fname, names in fused:
+        parts = [get(m) for m in names]
+        if all(q is None for q in parts):
+            continue
+        if any(q is None for q in parts):
+            raise ValueError(f"LoRA adapters must cover all of {names} or none")
+        n += len(parts)
+        new_lora[fname] = Lora(torch.cat([q[0] for q in parts], 0).to(device=dev, dtype=torch.bfloat16).contiguous(),
+                               torch.cat([q[1] for q in parts], 0).to(device=dev, dtype=torch.float32).contiguous())
+    mparts = [get(m) for m in mods]
+    new_t = {}
+    if any(q is not None for q in mparts):
+        if any(q is None for q in mparts):
+            raise ValueError("LoRA must cover every norm1.linear / norm.linear or none")
+        n += len(mparts)
+        new_t["mod.lora_down"] = torch.cat([q[0] for q in mparts], 0).to(device=dev, dtype=torch.bfloat16).contiguous()
+        for idx, q in enumerate(mparts):
+            new_t[f"mod.lora_up.{idx}"] = q[1].to(dev).contiguous()
+    unknown = [k for k in sd if k not in used and ".lora_" in k]
+    if unknown:
+        raise KeyError(f"LoRA keys that match no module of this transformer: {unknown[:4]}{' ...' if len(unknown) > 4 else ''}")
+    if n == 0:
+        raise ValueError("no LoRA adapter found in the state dict")
+    pw.lora.clear()
+    pw.lora.update(new_lora)
+    for k in [k for k in pw.t if k.startswith("mod.lora_")]:
+        del pw.t[k]
+    pw.t.update(new_t)
+    return n
+
+
 def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True) -> PackedWeights:
     """Random weights of the fused layout generated on the GPU (full FLUX.1-dev scale = 23.8 GB bf16)."""
     g = torch.Generator(device=device).manual_seed(seed)

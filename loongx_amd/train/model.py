@@ -354,6 +354,11 @@ class OminiModel(CS3DGF):
         tr = LxFluxTransformer.synthetic(flux_config, device, seed)
         return cls(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device)
 
+    def load_lora(self, checkpoint_path: str):
+        """model.py:463-477: load LoRA weights from a checkpoint directory into the pipeline's transformer."""
+        self.flux_pipe.load_lora_weights(checkpoint_path)
+        return self
+
     def eval(self):
         return self
 

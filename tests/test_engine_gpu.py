@@ -101,3 +101,39 @@ def test_prepared_schedule_is_bit_identical(G, mc):
     _run(eng, G, model_config=mc)
     got = eng.forward(G["in_latents"].to(d), torch.full((B,), ts[2], device=d), step_index=2)
     assert torch.equal(got, per_step[2])
+
+
+def test_load_lora_from_safetensors(G, tmp_path):
+    """model.py:463-477 / inference.py:43-44: base weights first, then `load_lora(dir)` with a diffusers-format
+    `pytorch_lora_weights.safetensors` (`transformer.<module>.lora_A.weight`): the result must equal packing the PEFT-wrapped
+    state dict directly (bit for bit) and reproduce the reference golden; an unknown module name is an error."""
+    from safetensors.torch import save_file
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
+    tr = tiny_transformer()
+    sd = tr.state_dict()
+    base = {k.replace(".base_layer.", "."): v for k, v in sd.items() if ".lora_" not in k}
+    lora = {"transformer." + k.replace(".default.", "."): v.contiguous() for k, v in sd.items() if ".lora_" in k}
+    assert len(lora) == 50
+    save_file(lora, str(tmp_path / "pytorch_lora_weights.safetensors"))
+    c = tr.config
+    cfg = FluxConfig(num_layers=c.num_layers, num_single_layers=c.num_single_layers, num_attention_heads=c.num_attention_heads,
+                     attention_head_dim=c.attention_head_dim, in_channels=c.in_channels, joint_attention_dim=c.joint_attention_dim,
+                     pooled_projection_dim=c.pooled_projection_dim, guidance_embeds=c.guidance_embeds, axes_dims_rope=c.axes_dims_rope)
+    lxt = LxFluxTransformer.from_state_dict(base, cfg, "cuda")
+    pipe = LxFluxPipeline(lxt)
+    eng = lxt.engine
+    no_lora = _run(eng, G)
+    assert relerr(no_lora, G["fwd_cond"]) > 1e-3                      # adapters matter for the condition stream
+    assert pipe.load_lora_weights(str(tmp_path)) == 25
+    got = _run(eng, G)
+    assert relerr(got, G["fwd_cond"]) < TOL
+    assert torch.equal(got, _run(_engine(tr), G))                      # same tensors as packing the wrapped state dict
+    bad = dict(lora)
+    bad["transformer.transformer_blocks.9.attn.to_q.lora_A.weight"] = bad["transformer.x_embedder.lora_A.weight"].clone()
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(KeyError):
+        pipe.load_lora_weights(str(tmp_path / "bad.safetensors"))
+    with pytest.raises(FileNotFoundError):
+        pipe.load_lora_weights(str(tmp_path / "nowhere"))
