@@ -267,7 +267,7 @@ constexpr int pipe_half(int g, int k) {   // k-th (0/1) softmax half-unit (slice
   return -1;
 }
 
-template <bool DEFER, bool ALT>
+template <bool DEFER>
 __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs args) {
   constexpr int NW = 8, QBLK = 256;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
@@ -276,7 +276,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const bool grp_b = wave >= 4;     // waves w and w+4 share a SIMD
 
   const int BH = D.B * D.H;
   const int bh = blockIdx.x % BH;
@@ -505,19 +504,10 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     LX_PG(0); LX_PG(1); LX_PG(2); LX_PG(3); LX_PG(4); LX_PG(5); LX_PG(6); LX_PG(7);
     LX_PG(8); LX_PG(9); LX_PG(10); LX_PG(11); LX_PG(12); LX_PG(13); LX_PG(14); LX_PG(15);
 #undef LX_PG
-    // ALT: the two waves of a SIMD take turns. Waves 4-7 wait one barrier before each iteration, waves 0-3 one after it, so
-    // the hardware barrier (which only counts arrivals) pairs "A finished iteration t" with "B may start iteration t": one
-    // wave streams while its SIMD partner is parked in s_barrier and holds no pending MFMA (a pending MFMA blocks the VALU
-    // port for both). The staging rules are unchanged: K(t+2) / V(t+1) are issued inside iteration t, after every reader of
-    // K(t) / V(t-1) has passed the barrier that ended iteration t-1 for BOTH groups, and drained before the barrier that ends it.
     while (true) {
-      if (ALT && grp_b) { LX_BARRIER(); }
       LX_ITER(sA, sB);
-      if (ALT && !grp_b) { LX_BARRIER(); }
       if (t0.nvalid == 0) break;
-      if (ALT && grp_b) { LX_BARRIER(); }
       LX_ITER(sB, sA);
-      if (ALT && !grp_b) { LX_BARRIER(); }
       if (t0.nvalid == 0) break;
     }
   }
@@ -775,12 +765,9 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
   hipStream_t st = (hipStream_t)stream;
-  static const bool alt = [] { const char* e = getenv("LX_ATTN_ALT"); return e ? atoi(e) != 0 : false; }();
   if (piped) {
-    if (defer && alt) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a);
-    else if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a);
-    else if (alt) hipLaunchKernelGGL((lx_attn_pipe_kernel<false, true>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false, false>), dim3(grid), dim3(512), 0, st, a);
+    if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false>), dim3(grid), dim3(512), 0, st, a);
   } else if (nw == 8) {
     if (defer) hipLaunchKernelGGL((lx_attn_kernel<8, true>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((lx_attn_kernel<8, false>), dim3(grid), dim3(512), 0, st, a);

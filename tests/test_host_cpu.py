@@ -1,0 +1,63 @@
+"""CPU-only host logic: weight packing / LoRA installation (pure torch, no kernels) and the sigma schedule helpers."""
+import pytest
+import torch
+
+from tests.helpers import tiny_transformer
+
+
+def _cfg(tr):
+    from loongx_amd.flux.weights import FluxConfig
+    c = tr.config
+    return FluxConfig(num_layers=c.num_layers, num_single_layers=c.num_single_layers, num_attention_heads=c.num_attention_heads,
+                      attention_head_dim=c.attention_head_dim, in_channels=c.in_channels, joint_attention_dim=c.joint_attention_dim,
+                      pooled_projection_dim=c.pooled_projection_dim, guidance_embeds=c.guidance_embeds, axes_dims_rope=c.axes_dims_rope)
+
+
+def test_install_lora_equals_packing_the_wrapped_state_dict(monkeypatch):
+    """base weights + install_lora(diffusers-format LoRA dict) == pack_state_dict(PEFT-wrapped dict), tensor for tensor;
+    alpha keys rescale the up matrices by alpha / r; partial coverage of a fused q/k/v group and unknown modules are errors."""
+    monkeypatch.setenv("LX_TILE_W", "0")
+    from loongx_amd.flux.weights import install_lora, lora_layout, pack_state_dict
+    tr = tiny_transformer()
+    sd = tr.state_dict()
+    cfg = _cfg(tr)
+    want = pack_state_dict(sd, cfg, "cpu")
+    base = {k.replace(".base_layer.", "."): v for k, v in sd.items() if ".lora_" not in k}
+    lora = {"transformer." + k.replace(".default.", "."): v for k, v in sd.items() if ".lora_" in k}
+    pw = pack_state_dict(base, cfg, "cpu")
+    assert not pw.lora and "mod.lora_down" not in pw.t
+    assert install_lora(pw, lora) == 25
+    assert set(pw.lora) == set(want.lora)
+    for k in want.lora:
+        assert torch.equal(pw.lora[k].down, want.lora[k].down) and torch.equal(pw.lora[k].up, want.lora[k].up), k
+    for k in want.t:
+        assert torch.equal(pw.t[k], want.t[k]), k
+    assert set(pw.t) == set(want.t)
+    fused, mods = lora_layout(cfg)
+    assert len(mods) == cfg.num_layers + cfg.num_single_layers and fused[0][1][-1].endswith("attn.to_q")
+
+    with_alpha = dict(lora)
+    with_alpha["transformer.x_embedder.alpha"] = torch.tensor(2.0 * lora["transformer.x_embedder.lora_A.weight"].shape[0])
+    install_lora(pw, with_alpha)
+    assert torch.allclose(pw.lora["x_embedder"].up, 2.0 * want.lora["x_embedder"].up)
+
+    partial = {k: v for k, v in lora.items() if "transformer_blocks.0.attn.to_v" not in k or "single_" in k}
+    with pytest.raises(ValueError):
+        install_lora(pw, partial)
+    with pytest.raises(KeyError):
+        install_lora(pw, {**lora, "transformer.nope.lora_A.weight": torch.zeros(4, 8), "transformer.nope.lora_B.weight": torch.zeros(8, 4)})
+    with pytest.raises(ValueError):
+        install_lora(pw, {"transformer.x_embedder.weight": torch.zeros(2, 2)})
+
+
+def test_sigma_schedule_matches_oracle():
+    import numpy as np
+    from oracle import flux_modules as fm
+    from loongx_amd.flux.pipeline import FlowMatchEulerDiscreteScheduler, calculate_shift
+    for n, seq in ((28, 1024), (4, 4096), (50, 256)):
+        sig = np.linspace(1.0, 1 / n, n)
+        mu = calculate_shift(seq, 256, 4096, 0.5, 1.15)
+        assert mu == fm.calculate_shift(seq, 256, 4096, 0.5, 1.15)
+        a, b = FlowMatchEulerDiscreteScheduler(), fm.FlowMatchEulerDiscreteScheduler()
+        a.set_timesteps(sigmas=sig, mu=mu, device="cpu"); b.set_timesteps(sigmas=sig, mu=mu)
+        assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas)
