@@ -45,13 +45,13 @@ __global__ __launch_bounds__(512) void kloop(const __bf16* A, const __bf16* W, f
     }
     for (int j = 0; j < 4; ++j) wsrc[j] = W + ((size_t)tn * (K / BK)) * (BN * BK) + ((j * 8 + wave) * 512 + lane * 8);
   }
-  bool force_stage = (FLAGS & 128) != 0;
   // alternative addressing forms: 32-bit per-lane byte offsets relative to the (wave-uniform) operand base
   uint32_t aoff32[MI], woff32[4];
   for (int j = 0; j < MI; ++j) aoff32[j] = (uint32_t)((const char*)asrc[j] - (const char*)A);
   for (int j = 0; j < 4; ++j) woff32[j] = (uint32_t)((const char*)wsrc[j] - (const char*)W);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+  bool force_stage = (FLAGS & 128) != 0;
   auto stage_a = [&](int kt, int slot) {
     if (!DMA && !force_stage) return;
     char* base = smem + slot * A_BYTES;
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(512) void kloop(const __bf16* A, const __bf16* W, f
   };
   auto piece = [&](int p, int kt, int slot) {   // p 0..3: A pieces, 4..7: W pieces of K tile kt
     if (!DMA || kt >= nkt) return;
+    if (FLAGS & 16384) {
+      if (p < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + (slot & 1) * A_BYTES + (p * 8 + wave) * 1024), 16, aoff32[p], kt * BK * 2, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(smem + W_BASE + slot * W_BYTES + ((p - 4) * 8 + wave) * 1024), 16, woff32[p - 4], kt * BN * BK * 2, 0, 0);
+      return;
+    }
     if (p < 4) __builtin_amdgcn_global_load_lds((gptr_t)(asrc[p] + kt * BK), (lptr_t)(smem + (slot & 1) * A_BYTES + (p * 8 + wave) * 1024), 16, 0, 0);
     else __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[p - 4] + (size_t)kt * BN * BK), (lptr_t)(smem + W_BASE + slot * W_BYTES + ((p - 4) * 8 + wave) * 1024), 16, 0, 0);
   };
@@ -217,7 +222,7 @@ extern "C" int run_loop(int flags, const void* A, const void* W, float* out, int
   hipStream_t s = (hipStream_t)stream;
   switch (flags) {
     CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(6) CASE(2) CASE(4)
-    CASE(31) CASE(47) CASE(46) CASE(30) CASE(76) CASE(77) CASE(78) CASE(79) CASE(110) CASE(111) CASE(74) CASE(75) CASE(10+128+8192) CASE(10+128+16384) CASE(14+8192) CASE(14+16384) CASE(14+4096) CASE(10+4096) CASE(10+128+4096) CASE(8+128) CASE(9+128) CASE(10+128) CASE(11+128) CASE(12+0x100) CASE(12+0x300) CASE(12+0x500) CASE(12+0x800) CASE(12+0x800+0x300) CASE(12+0x800+0x500)
+    CASE(31) CASE(47) CASE(46) CASE(30) CASE(76) CASE(77) CASE(78) CASE(79) CASE(110) CASE(111) CASE(74) CASE(75) CASE(14+16384+4096) CASE(10+128+8192) CASE(10+128+16384) CASE(14+8192) CASE(14+16384) CASE(14+4096) CASE(10+4096) CASE(10+128+4096) CASE(8+128) CASE(9+128) CASE(10+128) CASE(11+128) CASE(12+0x100) CASE(12+0x300) CASE(12+0x500) CASE(12+0x800) CASE(12+0x800+0x300) CASE(12+0x800+0x500)
     default: return -1;
   }
   return (int)hipGetLastError();
