@@ -76,9 +76,10 @@ def test_forward_is_deterministic(G):
 
 
 @pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
-def test_prepared_schedule_is_bit_identical(G, mc):
-    """prepare_schedule(): all steps' modulation vectors from one weight pass == the per-step evaluation, bit for bit
-    (rows are independent in lx_linear_skinny), for graph replay and eager, with and without LoRA on the image stream."""
+def test_prepared_schedule_matches_per_step(G, mc):
+    """prepare_schedule(): all steps' modulation vectors from ONE pass over the modulation weights (MFMA GEMM on bf16 hi/lo
+    halves of silu(temb): fp32-class accuracy) against the per-step evaluation (weight-streaming GEMV on fp32 activations),
+    with and without LoRA on the image stream; the prepared path itself is deterministic."""
     d = "cuda"
     eng = _engine(tiny_transformer())
     ts = [1.0, 0.8731, 0.5, 0.25, 0.0357]
@@ -91,10 +92,17 @@ def test_prepared_schedule_is_bit_identical(G, mc):
         per_step.append(eng.forward(G["in_latents"].to(d), tt).clone())
     _run(eng, G, model_config=mc)
     eng.prepare_schedule(torch.tensor(ts))
+    for i, t in enumerate(ts):                                        # the table itself against the per-step kernels
+        eng.t1000.copy_(torch.full((B,), t * 1000.0, device=d))
+        eng._time_text_embed(eng.t1000, eng.temb, eng.temb_base)
+        eng._compute_mods(eng.temb, eng.mods, lora=eng.latent_lora)
+        assert relerr(eng.sched[1][i].cpu(), eng.mods.cpu()) < 1e-5, f"modulation table, step {i}"
     for i, t in enumerate(ts):
         tt = torch.full((B,), t, device=d)
-        got = eng.forward(G["in_latents"].to(d), tt, step_index=i)
-        assert torch.equal(got, per_step[i]), f"step {i}"
+        got = eng.forward(G["in_latents"].to(d), tt, step_index=i).clone()
+        # a 2.5e-6 difference in the modulations flips occasional bf16 roundings downstream: equal within bf16 noise
+        assert relerr(got.cpu(), per_step[i].cpu()) < 5e-3, f"step {i}"
+        assert torch.equal(got, eng.forward(G["in_latents"].to(d), tt, step_index=i))
     with pytest.raises(IndexError):
         eng.forward(G["in_latents"].to(d), tt, step_index=len(ts))
     # conditioning change invalidates the table: step_index is then ignored and the per-step path runs
