@@ -90,8 +90,9 @@ int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, i
 
 /* Skinny linear for a few rows (AdaLayerNorm modulation linears, time/text embedders:
  * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound; rows are processed four at a
- * time against the same weight rows, independently (M rows give bit-identical results to M one-row calls), so the
- * modulations of a whole sigma schedule can be evaluated in one weight pass (M = steps x batch).
+ * time against the same weight rows, independently (M rows give bit-identical results to M one-row calls). Meant for
+ * M <= 16: with more rows (e.g. the modulations of a whole sigma schedule, M = steps x batch) every wave re-loads all
+ * x rows and lx_gemm_bf16 on bf16 hi/lo halves of x is the better tool (DiTEngine.prepare_schedule).
  * Y[M,N] fp32 (=|+=) act_out(act_in(X[M,K] fp32) . W[N,K]^T (bf16) + bias).  act: 0 none, 1 SiLU. */
 int lx_linear_skinny(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy,
                      int M, int N, int K, int act_in, int act_out, int accumulate, void* stream);
