@@ -143,7 +143,8 @@ class DiTEngine:
         if not self.cond_ready:
             raise RuntimeError("call set_conditioning() before prepare_schedule()")
         cfg, dev, f32 = self.cfg, self.device, torch.float32
-        t = torch.as_tensor(t_sched, dtype=f32, device=dev).reshape(-1)
+        host = None if isinstance(t_sched, torch.Tensor) and t_sched.is_cuda else tuple(float(v) for v in torch.as_tensor(t_sched, dtype=f32).reshape(-1).tolist())
+        t = torch.as_tensor(t_sched, dtype=f32).reshape(-1).to(dev)
         n, B, D = t.numel(), self.B, cfg.inner_dim
         if n * B * cfg.n_mod * 4 > (4 << 30):        # keep the table (and its hi/lo twin) bounded; the per-step path handles the rest
             self.sched = None
@@ -168,7 +169,7 @@ class DiTEngine:
         mods_all += self.w.t["mod.b"]
         if self.latent_lora and "mod.lora_down" in self.w.t:
             self._compute_mods(temb_all, mods_all, lora=True, lora_only=True)
-        self.sched = (tuple(float(v) for v in t.tolist()), mods_all.view(n, B, cfg.n_mod))
+        self.sched = (host if host is not None else tuple(float(v) for v in t.tolist()), mods_all.view(n, B, cfg.n_mod))
 
     def _attn_bias(self) -> Dict[str, Dict[str, float]]:
         """block.py:106-128 as a (query stream, key stream) table: 0, log(c_factor) or -inf."""

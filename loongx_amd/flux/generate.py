@@ -161,7 +161,13 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
 
     # ---- denoise loop (generate.py:313-369) ------------------------------------------------------------------
     # the whole schedule is known here: hand it to the engine so the AdaLN modulation weights stream once per image
-    sched_ts = (timesteps.to(latents.dtype) / 1000).tolist()
+    # (host copy of the same fp32 values: a .tolist() on the device tensor would drain the stream here and keep the host from
+    #  preparing this image while the GPU is still busy with the previous one)
+    th = getattr(self.scheduler, "timesteps_host", None)
+    if th is not None and latents.dtype == torch.float32 and len(th) == len(timesteps):
+        sched_ts = (th / np.float32(1000)).tolist()
+    else:
+        sched_ts = (timesteps.to(latents.dtype) / 1000).tolist()
     with self.progress_bar(total=num_inference_steps) as progress_bar:
         for i, t in enumerate(timesteps):
             if self.interrupt:

@@ -53,7 +53,8 @@ class FlowMatchEulerDiscreteScheduler:
             sigmas = s * sigmas / (1 + (s - 1) * sigmas)
         sig = sigmas.astype(np.float32)
         self._sig_host = np.concatenate([sig, np.zeros(1, np.float32)])
-        self.timesteps = torch.from_numpy(sig * np.float32(self.config.num_train_timesteps)).to(device)
+        self.timesteps_host = sig * np.float32(self.config.num_train_timesteps)      # same fp32 values as self.timesteps, no device sync
+        self.timesteps = torch.from_numpy(self.timesteps_host).to(device)
         self.sigmas = torch.from_numpy(self._sig_host).to(device)
         self._step_index = 0
 
