@@ -192,8 +192,13 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   }
 }
 
+// One output tile. `pid` = index of this workgroup among the launch's tiles of height BM; `smem` = the workgroup's LDS buffer
+// (gemm_lds_bytes<BM>() bytes, 1 KiB aligned).
 template <int BM>
-__global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) {
+constexpr int gemm_lds_bytes() { return BM == 128 ? 3 * (128 * BK * 2) + 3 * (BN * BK * 2) : 2 * (256 * BK * 2) + 2 * (BN * BK * 2); }
+
+template <int BM>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, char* smem) {
   constexpr int MI = BM / 64;               // 32-row m-blocks per wave
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   constexpr int WAIT_STEADY = BM == 128 ? MI + 4 : (NSW == 3 ? 4 : 0);   // DMA instructions allowed in flight across the K-tile barrier
   static_assert(W_BASE + NSW * W_BYTES <= 160 * 1024, "LDS budget");
   static_assert(W_BASE + NSW * W_BYTES >= 8 * 32 * 68 * 4, "epilogue patch must fit");
-  __shared__ __attribute__((aligned(1024))) char smem[W_BASE + NSW * W_BYTES];
+  static_assert(W_BASE + NSW * W_BYTES == gemm_lds_bytes<BM>(), "gemm_lds_bytes out of sync with the ring layout");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -223,7 +228,6 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   const int total = args.tile_start[args.n];
   int lid;
   {
-    const int pid = blockIdx.x;
     const int q = total >> 3, r = total & 7;
     const int xcd = pid & 7, inx = pid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
@@ -408,6 +412,23 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
   gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
 }
 
+template <int BM>
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) {
+  __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<BM>()];
+  gemm_tile<BM>(args, blockIdx.x, smem);
+}
+
+// Mixed-height launch: `big` holds full rounds of 256-row tiles, `tail` the remaining rows as 128-row tiles, in ONE grid
+// [big tiles | padding to a multiple of 8 | tail tiles]. Launched one after the other, the tail (e.g. 168 tiles on 256 CUs) only
+// starts when the last big round has drained everywhere; in one grid a CU that finishes its last big tile picks up a tail tile
+// at once. The padding keeps blockIdx % 8 (the XCD a workgroup lands on) equal to pid % 8 for the tail's tile map.
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs big, const GemmArgs tail, const int n_big_pad) {
+  __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<128>() > gemm_lds_bytes<256>() ? gemm_lds_bytes<128>() : gemm_lds_bytes<256>()];
+  const int bid = blockIdx.x;
+  if (bid < big.tile_start[big.n]) gemm_tile<256>(big, bid, smem);
+  else if (bid >= n_big_pad) gemm_tile<128>(tail, bid - n_big_pad, smem);
+}
+
 }  // namespace
 
 // ---- launch planning ---------------------------------------------------------------------------------------------
@@ -510,6 +531,13 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
   }
   int choice = forced == 256 ? 0 : forced == 128 ? 1 : (c_c < c_a && c_c < c_b) ? 2 : (c_b < c_a ? 1 : 0);
   if (choice == 2) {
+    static const bool one_grid = env_int("LX_GEMM_MIXED_ONE_GRID", 1) != 0;
+    if (one_grid && big.n > 0 && tail.n > 0) {
+      const int n_big = big.tile_start[big.n], n_big_pad = (n_big + 7) & ~7;
+      hipLaunchKernelGGL(lx_gemm_mixed_kernel, dim3(n_big_pad + tail.tile_start[tail.n]), dim3(NTHREADS), 0, s, big, tail, n_big_pad);
+      LX_LAUNCH_CHECK("lx_gemm_bf16");
+      return LX_OK;
+    }
     const int rc = launch_plan(big, 256, s);
     if (rc != LX_OK) return rc;
     return launch_plan(tail, 128, s);
