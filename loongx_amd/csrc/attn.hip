@@ -254,13 +254,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const
 // Scores live in two register sets that swap roles every iteration (the loop body is expanded twice). The last
 // iteration's QK works on a stale buffer and is discarded. One barrier per tile; K(t+2) and V(t+1) are staged (four 1-KiB
 // LDS-DMA pieces per wave, spread over gaps) into the slots K(t) / V(t-1) vacated in the previous iteration.
-constexpr int pipe_is_q(int g) { return g < 10 || g == 14 || g == 15 || g == 20 || g == 21 || g == 26 || g == 27; }
+// Gap schedule of one iteration (32 gaps): the row max / rescale decision of tile t occupies the vector slots of gaps 0-3, the
+// 32 softmax half-units gaps 4-27 (slice s = halves 8s..8s+7), and PV slice s starts only after its slice is complete.
+//   MFMAs : gaps 0-13 QK fragments 0-13 | 14-17 PV slice 0 | 18-19 QK 14-15 | 20-23 PV 1 | 24-27 PV 2 | 28-31 PV 3
+constexpr int pipe_is_q(int g) { return g < 14 || g == 18 || g == 19; }
 constexpr int pipe_idx(int g) {   // index of the QK fragment (ks*2+kb) or PV fragment (s*4+db) consumed at gap g
-  return g < 10 ? g : g < 14 ? g - 10 : g < 16 ? g - 4 : g < 20 ? g - 12 : g < 22 ? g - 8 : g < 26 ? g - 14 : g < 28 ? g - 12 : g - 16;
+  return g < 14 ? g : g < 18 ? g - 14 : g < 20 ? g - 4 : g - 16;
 }
 constexpr int pipe_half(int g, int k) {   // k-th (0/1) softmax half-unit (slice*8 + value) issued behind gap g, or -1
-  // slice s must be complete before PV slice s starts (gaps 10, 16, 22, 28)
-  constexpr int at[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 19, 20, 21, 22, 22, 23, 23, 24, 25, 26, 27};
+  constexpr int at[32] = {4, 5, 6, 7, 8, 9, 10, 11, 10, 11, 12, 13, 14, 15, 16, 17, 16, 17, 18, 19, 20, 21, 22, 23, 20, 21, 22, 23, 24, 25, 26, 27};
   int seen = 0;
   for (int j = 0; j < 32; ++j)
     if (at[j] == g) { if (seen == k) return j; ++seen; }
@@ -380,7 +382,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   u32x4 pfw[4];
   f32x16 sA[2], sB[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float off = 0.f, p_even = 0.f;
+  float mx[4], t_new = 0.f;
+  float off = 0.f, p_even[2] = {0.f, 0.f};   // (slices s and s+1 overlap in time: one pending even value per slice parity)
   uint32_t bq = 0, bv = 0;          // LDS byte offsets of the K buffer read by QK and the V buffer read by PV
 
 #define LX_FENCE() asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
@@ -418,13 +421,49 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     constexpr int s_ = (hu) >> 3, r_ = 8 * (s_ & 1) + ((hu) & 7);                                                      \
     const float p_ = __builtin_amdgcn_exp2f(fmaf(SC[s_ >> 1][r_], c2, off));                                           \
     l_run += p_;                                                                                                       \
-    if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even, p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]), "+v"(l_run)); } \
-    else { p_even = p_; asm volatile("" : "+v"(p_even), "+v"(l_run)); }                                                \
+    if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even[s_ & 1], p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]), "+v"(l_run)); } \
+    else { p_even[s_ & 1] = p_; asm volatile("" : "+v"(p_even[s_ & 1]), "+v"(l_run)); }                                \
+  }
+  // row max of tile t and the rescale decision, as vector fillers of gaps 0-3 (they used to run serially at the head of the
+  // iteration: 8 us of a 90 us launch with nothing to overlap); four independent v_max3 chains, not one 16-deep chain
+#define LX_MCHUNK(g, SC)                                                                                               \
+  if ((g) == 0) {                                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                    \
+      const int kb = c >> 1, r0 = (c & 1) * 8;                                                                         \
+      mx[c] = __builtin_fmaxf(__builtin_fmaxf(SC[kb][r0], SC[kb][r0 + 1]), SC[kb][r0 + 2]);                            \
+      mx[c] = __builtin_fmaxf(__builtin_fmaxf(mx[c], SC[kb][r0 + 3]), SC[kb][r0 + 4]);                                 \
+    }                                                                                                                  \
+    asm volatile("" : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "+v"(mx[3]));                                             \
+  } else if ((g) == 1) {                                                                                               \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                    \
+      const int kb = c >> 1, r0 = (c & 1) * 8;                                                                         \
+      mx[c] = __builtin_fmaxf(__builtin_fmaxf(mx[c], SC[kb][r0 + 5]), SC[kb][r0 + 6]);                                 \
+      mx[c] = __builtin_fmaxf(mx[c], SC[kb][r0 + 7]);                                                                  \
+    }                                                                                                                  \
+    mx[0] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx[0], mx[1]), mx[2]), mx[3]);                             \
+    asm volatile("" : "+v"(mx[0]));                                                                                    \
+  } else if ((g) == 2) {                                                                                               \
+    const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[0]), __float_as_uint(mx[0]), false, false);   \
+    t_new = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * c2 + bl;                                         \
+    asm volatile("" : "+v"(t_new));                                                                                    \
+  } else if ((g) == 3) {                                                                                               \
+    bool rescale = true;                                                                                               \
+    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;                                  \
+    if (rescale) {                                                                                                     \
+      const float m_new = fmaxf(m_run, t_new);                                                                         \
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                       \
+      l_run *= alpha;                                                                                                  \
+      m_run = m_new;                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha; \
+    }                                                                                                                  \
+    off = bl - m_run;                                                                                                  \
+    asm volatile("" : "+v"(off));                                                                                      \
   }
 #define LX_GAP(g, SC, SN)                                                                                              \
   LX_WAITL((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1));                                                         \
   LX_MM(g, SC, SN, false);                                                                                             \
   LX_RD((g) + LOOK, 32, false);                                                                                        \
+  LX_MCHUNK(g, SC)                                                                                                     \
   if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
   if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }         \
   if ((g) == 1) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                              \
@@ -442,43 +481,15 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     bv = (t & 1) * STAGE_BYTES;                                                                                        \
     LX_WAITL(0);                                                                                                       \
     LX_RDP(0, 32, false); LX_RDP(1, 32, false); LX_RDP(2, 32, false); LX_RDP(3, 32, false); LX_RDP(4, 32, false); LX_RDP(5, 32, false); \
-    /* ---- row max of tile t, under the first LDS round trip ---- */                                                  \
+    /* ---- ragged last tile of the segment: mask keys past its end (rare, before the stream) ---- */                  \
     const float bl = t0.bl;                                                                                            \
-    if (t0.nvalid < KVBLK) {            /* ragged last tile of the segment: mask keys past its end */                  \
+    if (t0.nvalid < KVBLK) {                                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* keeps this a wave-uniform branch: if-converted it is ~100 VALU on every tile */ \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {                \
         const int key = 4 * lhi + kb * 32 + 8 * (r >> 2) + (r & 3);                                                    \
         if (key >= t0.nvalid) SC[kb][r] = -1e30f;                                                                      \
       }                                                                                                                \
     }                                                                                                                  \
-    float tmax;                                                                                                        \
-    {   /* four independent v_max3 chains instead of one 16-deep dependent chain */                                    \
-      float m_[4];                                                                                                     \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                  \
-        const int kb = c >> 1, r0 = (c & 1) * 8;                                                                       \
-        m_[c] = __builtin_fmaxf(__builtin_fmaxf(SC[kb][r0], SC[kb][r0 + 1]), SC[kb][r0 + 2]);                          \
-        m_[c] = __builtin_fmaxf(__builtin_fmaxf(m_[c], SC[kb][r0 + 3]), SC[kb][r0 + 4]);                               \
-        m_[c] = __builtin_fmaxf(__builtin_fmaxf(m_[c], SC[kb][r0 + 5]), SC[kb][r0 + 6]);                               \
-        m_[c] = __builtin_fmaxf(m_[c], SC[kb][r0 + 7]);                                                                \
-      }                                                                                                                \
-      tmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m_[0], m_[1]), m_[2]), m_[3]);                            \
-    }                                                                                                                  \
-    {                                                                                                                  \
-      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);   \
-      tmax = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                                  \
-    }                                                                                                                  \
-    const float t_new = tmax * c2 + bl;                                                                                \
-    bool rescale = true;                                                                                               \
-    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;                                  \
-    if (rescale) {                                                                                                     \
-      const float m_new = fmaxf(m_run, t_new);                                                                         \
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                       \
-      l_run *= alpha;                                                                                                  \
-      m_run = m_new;                                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha; \
-    }                                                                                                                  \
-    off = bl - m_run;                                                                                                  \
-    asm volatile("" : "+v"(off));                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     LX_GAP4(0, SC, SN); LX_GAP4(4, SC, SN); LX_GAP4(8, SC, SN); LX_GAP4(12, SC, SN);                                   \
     LX_GAP4(16, SC, SN); LX_GAP4(20, SC, SN); LX_GAP4(24, SC, SN); LX_GAP4(28, SC, SN);                                \
@@ -514,6 +525,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_ITER
 #undef LX_GAP4
 #undef LX_GAP
+#undef LX_MCHUNK
 #undef LX_HALF
 #undef LX_MM
 #undef LX_RD
