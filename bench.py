@@ -170,6 +170,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01d_pmc_*.txt)",
+                               "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
                                "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
                                "share_of_step_time": round(gm["ms"] / (elapsed_ms / a.steps), 3)}
             if at:

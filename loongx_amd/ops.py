@@ -78,10 +78,12 @@ class LaunchTimer:
 
     def __init__(self):
         self.records = {}   # kind -> list of (start_event, end_event, algorithmic_flops)
+        self.bytes = {}     # kind -> algorithmic operand + output bytes summed over the bracketed launches
 
-    def bracket(self, kind: str, flops: float):
+    def bracket(self, kind: str, flops: float, nbytes: float = 0.0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.setdefault(kind, []).append((s, e, flops))
+        self.bytes[kind] = self.bytes.get(kind, 0.0) + nbytes
         return s, e
 
     def summary(self):
@@ -89,7 +91,7 @@ class LaunchTimer:
         out = {}
         for kind, recs in self.records.items():
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            out[kind] = dict(launches=len(recs), flops=sum(f for _, _, f in recs), ms=ms)
+            out[kind] = dict(launches=len(recs), flops=sum(f for _, _, f in recs), ms=ms, bytes=self.bytes.get(kind, 0.0))
         return out
 
 
@@ -100,7 +102,11 @@ def gemm(problems: Sequence[GemmDesc]) -> None:
     n = len(problems)
     arr = (GemmDesc * n)(*problems)
     if TIMER is not None:
-        s, e = TIMER.bracket("gemm", sum(2.0 * p.M * p.N * p.K for p in problems))
+        def _bytes(p):   # each operand read once, the output written once (the fp32 residual epilogue also reads it)
+            epi = p.epilogue & 0xff
+            out_b = 2 if epi == LX_EPI_STORE_BF16 else (8 if epi == LX_EPI_RESID_F32 else 4)
+            return 2.0 * p.M * p.K + 2.0 * p.N * p.K + float(out_b) * p.M * p.N
+        s, e = TIMER.bracket("gemm", sum(2.0 * p.M * p.N * p.K for p in problems), sum(_bytes(p) for p in problems))
         s.record()
         check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
         e.record()
