@@ -47,4 +47,4 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / a.steps
 S = T + 2 * N
 flop = (cfg.num_layers + cfg.num_single_layers) * B * (24 * S * 3072**2 + 4 * S * S * 3072)
-print(f"step {dt*1e3:.2f} ms  -> {flop/dt/1e12:.1f} TFLOP/s  ({1/(28*dt)*B:.3f} img/s)  finite={bool(torch.isfinite(v).all())}")
+print(f"step {dt*1e3:.2f} ms  -> {flop/dt/1e12:.1f} TFLOP/s  ({1/(28*dt)*B:.3f} img/s)  finite={bool(torch.isfinite(v).all())} checksum={float(v.double().abs().sum()):.6f}")
