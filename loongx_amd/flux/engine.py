@@ -427,7 +427,8 @@ class DiTEngine:
         pre = step_index is not None and self.sched is not None
         if pre and not 0 <= step_index < len(self.sched[0]):
             raise IndexError(f"step_index {step_index} outside the prepared schedule of {len(self.sched[0])} steps")
-        if not self.use_graph or ops.TIMER is not None:
+        timed = ops.TIMER is not None and ops.TIMER.next_call()      # event brackets need the eager launch path
+        if not self.use_graph or timed:
             if pre:
                 self.mods.copy_(self.sched[1][step_index])
             return self._forward_eager(latents, timestep, pre)

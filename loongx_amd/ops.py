@@ -74,11 +74,23 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
 
 
 class LaunchTimer:
-    """Brackets selected kernel launches with HIP events on the launch stream (bench.py roofline measurement)."""
+    """Brackets selected kernel launches with HIP events on the launch stream (bench.py roofline measurement).
+    Events cannot be recorded inside a replayed graph, so a bracketed denoise step runs the eager launch path (~2 % slower
+    than the replay). `only_calls` limits that to the given DiTEngine.forward calls (0-based, counted while this timer is
+    installed as ops.TIMER); every other call replays the captured graph and `active` is False."""
 
-    def __init__(self):
+    def __init__(self, only_calls=None):
         self.records = {}   # kind -> list of (start_event, end_event, algorithmic_flops)
         self.bytes = {}     # kind -> algorithmic operand + output bytes summed over the bracketed launches
+        self.only_calls = None if only_calls is None else set(only_calls)
+        self.calls = 0
+        self.active = only_calls is None
+
+    def next_call(self) -> bool:
+        """DiTEngine.forward asks once per call: bracket (and therefore run eagerly) this one?"""
+        self.active = self.only_calls is None or self.calls in self.only_calls
+        self.calls += 1
+        return self.active
 
     def bracket(self, kind: str, flops: float, nbytes: float = 0.0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -101,7 +113,7 @@ TIMER: Optional[LaunchTimer] = None
 def gemm(problems: Sequence[GemmDesc]) -> None:
     n = len(problems)
     arr = (GemmDesc * n)(*problems)
-    if TIMER is not None:
+    if TIMER is not None and TIMER.active:
         def _bytes(p):   # each operand read once, the output written once (the fp32 residual epilogue also reads it)
             epi = p.epilogue & 0xff
             out_b = 2 if epi == LX_EPI_STORE_BF16 else (8 if epi == LX_EPI_RESID_F32 else 4)
