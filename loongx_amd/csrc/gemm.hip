@@ -120,11 +120,38 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
 
   // (2) transpose each 32x64 accumulator block through a wave-private LDS patch so that every global access of
   //     the epilogue (bias, gate, residual read-modify-write, stores) is a coalesced 16-B-per-lane row access.
+  //     vmcnt counts loads and stores in one in-order queue: a load issued behind a store cannot be waited for without
+  //     waiting for that store's acknowledgement from L2 first. So no load may sit between the stores: the bias (a function
+  //     of the column only) is loaded once per tile, and the residual / gate rows of a 32-row block are all loaded before
+  //     the block's first store (one exposed store latency per block instead of one per 4-row group: -5...-9 us per tile).
   __syncthreads();                                   // every wave is done with the operand tiles
   constexpr int EP_LD = 68;                          // fp32 row stride of the patch (64 + 4 pad)
   float* patch = (float*)smem + wave * (32 * EP_LD);
+  const bool bf16_out = epi == LX_EPI_STORE_BF16;
+  const int c8 = (lane & 7) * 8, c4 = (lane & 15) * 4;
+  const int ncol = nw0 + (bf16_out ? c8 : c4);       // first of this lane's 8 (bf16 store) or 4 (fp32 paths) columns
+  const bool col_ok = ncol < N;
+  f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+  if (P.bias && col_ok) {
+    bias0 = *(const f32x4*)(P.bias + ncol);
+    if (bf16_out) bias1 = *(const f32x4*)(P.bias + ncol + 4);
+  }
+  const bool gelu0 = do_gelu && ncol >= P.gelu_col_start;      // gelu_col_start is a multiple of 8: one answer per lane
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int mb = mw0 + i * 32;
+    // residual + gate rows of this block, issued before the patch is even written
+    f32x4 res[8], gat[8];
+    if (epi == LX_EPI_RESID_F32) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int m = mb + t * 4 + (lane >> 4);
+        if (m < M && col_ok) {
+          res[t] = *(const f32x4*)((const float*)P.C + (size_t)m * P.ldc + ncol);
+          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + ncol);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -133,58 +160,47 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
       }
     __builtin_amdgcn_wave_barrier();
-    const int mb = mw0 + i * 32;
-    if (epi == LX_EPI_STORE_BF16) {
-      const int c8 = (lane & 7) * 8, n = nw0 + c8;
+    if (bf16_out) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = t * 8 + (lane >> 3), m = mb + row;
         f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
         f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
-        if (m < M && n < N) {
-          if (P.bias) {
-            const f32x4 b0 = *(const f32x4*)(P.bias + n), b1 = *(const f32x4*)(P.bias + n + 4);
+        if (m < M && col_ok) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] += b0[c]; v1[c] += b1[c]; }
-          }
-          if (do_gelu && n >= P.gelu_col_start) {
+          for (int c = 0; c < 4; ++c) { v0[c] += bias0[c]; v1[c] += bias1[c]; }
+          if (gelu0) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { v0[c] = gelu_tanh(v0[c]); v1[c] = gelu_tanh(v1[c]); }
           }
           u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + n) = o;
+          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
         }
       }
     } else {
-      const int c4 = (lane & 15) * 4, n = nw0 + c4;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int row = t * 4 + (lane >> 4), m = mb + row;
         f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
-        if (m < M && n < N) {
-          if (P.bias) {
-            const f32x4 bv = *(const f32x4*)(P.bias + n);
+        if (m < M && col_ok) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += bv[c];
-          }
-          if (do_gelu && n >= P.gelu_col_start) {
+          for (int c = 0; c < 4; ++c) v[c] += bias0[c];
+          if (gelu0) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
           }
-          float* cp = (float*)P.C + (size_t)m * P.ldc + n;
           if (epi == LX_EPI_RESID_F32) {
-            f32x4 o = *(const f32x4*)cp;
+            f32x4 o = res[t];
             if (P.gate) {
-              const f32x4 gv = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + n);
 #pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] += gv[c] * v[c];
+              for (int c = 0; c < 4; ++c) o[c] += gat[t][c] * v[c];
             } else {
 #pragma unroll
               for (int c = 0; c < 4; ++c) o[c] += v[c];
             }
             v = o;
           }
-          *(f32x4*)cp = v;
+          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
         }
       }
     }
@@ -192,17 +208,36 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   }
 }
 
-// One output tile. `pid` = index of this workgroup among the launch's tiles of height BM; `smem` = the workgroup's LDS buffer
-// (gemm_lds_bytes<BM>() bytes, 1 KiB aligned).
 template <int BM>
 constexpr int gemm_lds_bytes() { return BM == 128 ? 3 * (128 * BK * 2) + 3 * (BN * BK * 2) : 2 * (256 * BK * 2) + 2 * (BN * BK * 2); }
 
+// lid (position in the launch's tile order) -> (sub)problem g and tile (tm, tn): 4-tile-tall column groups inside a problem.
 template <int BM>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, char* smem) {
+__device__ __forceinline__ void tile_lookup(const GemmArgs& args, const int lid, int& g, int& tm, int& tn) {
+  g = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_SUB; ++i)
+    if (i < args.n && lid >= args.tile_start[i]) g = i;
+  const lx_gemm_desc& P = args.p[g];
+  const int local = lid - args.tile_start[g];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int gs = GROUP_M * tiles_n;
+  const int gi = local / gs, in_g = local - gi * gs;
+  const int first_m = gi * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  tm = first_m + in_g % gm;
+  tn = in_g / gm;
+}
+
+// K tiles [kt0, kt1) of output tile (m0, n0) accumulated into acc (which the caller has cleared). `smem` = the workgroup's LDS
+// buffer (gemm_lds_bytes<BM>() bytes, 1 KiB aligned). On return no wave reads the operand rings any more.
+template <int BM>
+__device__ __forceinline__ void gemm_mainloop(const lx_gemm_desc& P, const int m0, const int n0, const int tn, const int kt0, const int kt1,
+                                              char* smem, f32x16 (&acc)[2][BM / 64], const int tid) {
   constexpr int MI = BM / 64;               // 32-row m-blocks per wave
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
-  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
   // LDS rings. The activation operand A is L2/MALL-hot (just written by the previous kernel); the weight operand W streams
   // cold from HBM and needs more lead (measured: long-K GEMMs lose 21-23 % with a single K tile of DMA in flight).
   //   BM=128: A ring 3 x 16 KiB + W ring 3 x 32 KiB = 144 KiB: two K tiles of lead (long-K ff.net.2 / proj_out GEMMs:
@@ -218,39 +253,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
   static_assert(W_BASE + NSW * W_BYTES >= 8 * 32 * 68 * 4, "epilogue patch must fit");
   static_assert(W_BASE + NSW * W_BYTES == gemm_lds_bytes<BM>(), "gemm_lds_bytes out of sync with the ring layout");
 
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lhi = lane >> 5;
-
-  // ---- XCD-aware block -> tile map ---------------------------------------------------------------
-  const int total = args.tile_start[args.n];
-  int lid;
-  {
-    const int q = total >> 3, r = total & 7;
-    const int xcd = pid & 7, inx = pid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
-  }
-  int g = 0;
-#pragma unroll
-  for (int i = 1; i < MAX_SUB; ++i)
-    if (i < args.n && lid >= args.tile_start[i]) g = i;
-  const lx_gemm_desc& P = args.p[g];
-  const int m_base = args.m_base[g];
-  const int local = lid - args.tile_start[g];
-  const int tiles_m = (P.M + BM - 1) / BM;
-  const int tiles_n = (P.N + BN - 1) / BN;
-  int tm, tn;
-  {
-    const int gs = GROUP_M * tiles_n;
-    const int gi = local / gs, in_g = local - gi * gs;
-    const int first_m = gi * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    tm = first_m + in_g % gm;
-    tn = in_g / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
   const int M = P.M, N = P.N, K = P.K;
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
 
@@ -290,13 +296,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
     char* base = smem + slot * A_BYTES;
 #pragma unroll
     for (int j = 0; j < MI; ++j)
-      lx_buf_to_lds(rs_a, (lptr_t)(base + (j * 8 + wave) * 1024), aoff[j], kt * (BK * 2));
+      lx_buf_to_lds(rs_a, (lptr_t)(base + (j * 8 + wave) * 1024), aoff[j], (kt0 + kt) * (BK * 2));
   };
   auto stage_w = [&](int kt, int slot) {
     char* base = smem + W_BASE + slot * W_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      lx_buf_to_lds(rs_w, (lptr_t)(base + (j * 8 + wave) * 1024), woff[j], kt * w_kstride_b);
+      lx_buf_to_lds(rs_w, (lptr_t)(base + (j * 8 + wave) * 1024), woff[j], (kt0 + kt) * w_kstride_b);
   };
 
   // ---- fragment read offsets -----------------------------------------------------------------------
@@ -306,14 +312,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
   for (int ks = 0; ks < 4; ++ks) slot_off[ks] = ((ks * 2 + lhi) ^ sw) * 16;
   const int a_row_off = (wm * (BM / 2) + l31) * 128;
   const int w_row_off = (wn * 64 + l31) * 128;
-
-  f32x16 acc[2][MI];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   // ---- main loop: software pipelined ------------------------------------------------------------------
   // Fragment registers are double buffered (set A / set B alternate over the four 16-deep k steps of a K tile):
@@ -337,7 +335,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
       else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
     }
   };
-  const int nkt = K / BK;
+  const int nkt = kt1 - kt0;                          // K tiles of this segment; `kt` below counts from kt0
   bf16x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
   // prologue: A tiles 0..NSA-1 and W tiles 0..NSW-1 in (A0 W0 A1 W1 [A2] W2) order; wait only for tile 0
   {
@@ -408,8 +406,39 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
 #undef LX_STEP
   // the inline-asm MFMAs are opaque to the hazard recogniser: cover MFMA write -> v_accvgpr_read by hand (18 wait states)
   if (LX_ACC_AGPR) asm volatile("s_nop 15\n s_nop 7" ::: "memory");
+}
 
-  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
+template <int MI>
+__device__ __forceinline__ void acc_clear(f32x16 (&acc)[2][MI]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+}
+
+// One whole output tile. `pid` = index of this workgroup among the launch's tiles of height BM.
+template <int BM>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, char* smem) {
+  constexpr int MI = BM / 64;
+  // ---- XCD-aware block -> tile map: each XCD (pid & 7) owns a contiguous run of the tile order ----
+  const int total = args.tile_start[args.n];
+  int lid;
+  {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, inx = pid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  }
+  int g, tm, tn;
+  tile_lookup<BM>(args, lid, g, tm, tn);
+  const lx_gemm_desc& P = args.p[g];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 acc[2][MI];
+  acc_clear<MI>(acc);
+  gemm_mainloop<BM>(P, tm * BM, tn * BN, tn, 0, P.K / BK, smem, acc, tid);
+  gemm_epilogue<BM, MI>(P, acc, smem, tm * BM, tn * BN, args.m_base[g], wave, wave >> 2, wave & 3, lane, lane & 31, lane >> 5);
 }
 
 template <int BM>
@@ -436,6 +465,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs 
 // rocprofv3 kernel durations over a K sweep (tools/gemm_ksweep.py): fixed (launch + prologue + epilogue burst) plus a
 // per-64-deep-K-tile slope at full occupancy.
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
+
 
 static long tiles_of(const lx_gemm_desc& p, int bm) { return (long)((p.M + bm - 1) / bm) * ((p.N + BN - 1) / BN); }
 

@@ -12,8 +12,11 @@ def timed(d, it=20):
     for _ in range(it): ops.gemm([d])
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / it
-for M, N, Ks in ((2560, 21504, (1024, 2048, 3072, 6144)), (2560, 12288, (1024, 2048, 3072, 6144)), (2560, 9216, (1024, 2048, 3072, 6144)), (2560, 3072, (3072, 6144, 12288, 15360)),
-                 (4096, 16384, (1024, 2048, 3072, 6144)), (16384, 4096, (1024, 2048, 3072, 6144))):
+import sys
+SHAPES = ((2560, 21504, (1024, 2048, 3072, 6144)), (2560, 12288, (1024, 2048, 3072, 6144)), (2560, 9216, (1024, 2048, 3072, 6144)), (2560, 3072, (3072, 6144, 12288, 15360)),
+          (4096, 16384, (1024, 2048, 3072, 6144)), (16384, 4096, (1024, 2048, 3072, 6144)))
+if len(sys.argv) > 1: SHAPES = tuple(SHAPES[int(i)] for i in sys.argv[1].split(","))
+for M, N, Ks in SHAPES:
     res = {}
     for K in Ks:
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
