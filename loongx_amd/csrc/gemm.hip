@@ -136,22 +136,12 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
     bias0 = *(const f32x4*)(P.bias + ncol);
     if (bf16_out) bias1 = *(const f32x4*)(P.bias + ncol + 4);
   }
+  // The loads above sit under a condition, and hipcc's wait-count pass then re-waits vmcnt(0) at every later use of their
+  // registers -- which, inside the store loops below, means waiting for the previous store after all. Wait here, once, and
+  // hand the values on through an empty asm so that they are no longer "results of a load" to the compiler.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias0), "+v"(bias1)::"memory");
   const bool gelu0 = do_gelu && ncol >= P.gelu_col_start;      // gelu_col_start is a multiple of 8: one answer per lane
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int mb = mw0 + i * 32;
-    // residual + gate rows of this block, issued before the patch is even written
-    f32x4 res[8], gat[8];
-    if (epi == LX_EPI_RESID_F32) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int m = mb + t * 4 + (lane >> 4);
-        if (m < M && col_ok) {
-          res[t] = *(const f32x4*)((const float*)P.C + (size_t)m * P.ldc + ncol);
-          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + ncol);
-        }
-      }
-    }
+  auto to_patch = [&](int i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -160,7 +150,14 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
       }
     __builtin_amdgcn_wave_barrier();
-    if (bf16_out) {
+  };
+  // One specialised block loop per output kind (the kind is wave-uniform): with the three kinds inside one loop, the waits
+  // hipcc places at the control-flow joins are vmcnt(0) again.
+  if (bf16_out) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = mw0 + i * 32;
+      to_patch(i);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = t * 8 + (lane >> 3), m = mb + row;
@@ -177,7 +174,27 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
           *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
         }
       }
-    } else {
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (epi == LX_EPI_RESID_F32) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = mw0 + i * 32;
+      // residual + gate rows of this block, issued before the patch is even written
+      f32x4 res[8], gat[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int m = mb + t * 4 + (lane >> 4);
+        if (m < M && col_ok) {
+          res[t] = *(const f32x4*)((const float*)P.C + (size_t)m * P.ldc + ncol);
+          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + ncol);
+        }
+      }
+      to_patch(i);
+      // same reason as for the bias: one explicit wait for the block's rows, none in the store loop
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(res[t]), "+v"(gat[t]));
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int row = t * 4 + (lane >> 4), m = mb + row;
@@ -189,22 +206,40 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
           }
-          if (epi == LX_EPI_RESID_F32) {
-            f32x4 o = res[t];
-            if (P.gate) {
+          f32x4 o = res[t];
+          if (P.gate) {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] += gat[t][c] * v[c];
-            } else {
+            for (int c = 0; c < 4; ++c) o[c] = __builtin_fmaf(gat[t][c], v[c], o[c]);      // explicit: not left to the contraction heuristics
+          } else {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] += v[c];
-            }
-            v = o;
+            for (int c = 0; c < 4; ++c) o[c] += v[c];
+          }
+          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = mw0 + i * 32;
+      to_patch(i);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 4 + (lane >> 4), m = mb + row;
+        f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
+        if (m < M && col_ok) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += bias0[c];
+          if (gelu0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
           }
           *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
