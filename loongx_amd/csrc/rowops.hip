@@ -125,6 +125,12 @@ struct QkvSegs {
   const float* wq[3]; const float* wk[3]; const float* cos_tab[3]; const float* sin_tab[3];
 };
 
+// FAST: every segment has norm_q / norm_k weights and RoPE tables (the DiT case). The launch is one resident generation of waves
+// (3840 waves on 1024 SIMDs at S = 2560), so its duration is the length of one thread's dependent chain of memory round trips,
+// not bandwidth. The FAST body therefore issues all loads of two of the thread's four rows (q, k, v chunks, RoPE table rows) before
+// anything is computed or stored -- the q / k stores go to the buffer the next rows' loads read, so hipcc cannot hoist them
+// itself -- without branches in between (at a control-flow join its wait-count pass falls back to vmcnt(0)).
+template <bool FAST>
 __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
                                                        const QkvSegs segs, float eps, uint16_t* __restrict__ VT, int vt_ld, int H) {
   __shared__ uint16_t vt_s[64][128 + 8];
@@ -142,6 +148,69 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
   const int sub = tid & 15;        // 16-B chunk within the 128-wide head vector
   const int rloc = tid >> 4;       // 0..15 : row within a 16-row pass
   const size_t rbase = (size_t)row0 + (size_t)b * rows_per_batch;
+  if constexpr (FAST) {
+    const f32x4 wq0 = *(const f32x4*)(wq + sub * 8), wq1 = *(const f32x4*)(wq + sub * 8 + 4);
+    const f32x4 wk0 = *(const f32x4*)(wk + sub * 8), wk1 = *(const f32x4*)(wk + sub * 8 + 4);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      uint16_t* rowp[2];
+      bool valid[2];
+      u32x4 raw[2][3];
+      f32x4 cs[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = p0 + (half * 2 + u) * 16 + rloc;
+        valid[u] = p < rows_per_batch;
+        const int pc = valid[u] ? p : 0;          // row 0 of the batch stands in for rows past the end (loaded, never stored)
+        rowp[u] = QKV + (rbase + pc) * ld + h * 128 + sub * 8;
+        raw[u][0] = *(const u32x4*)(rowp[u] + q_col);
+        raw[u][1] = *(const u32x4*)(rowp[u] + k_col);
+        raw[u][2] = *(const u32x4*)(rowp[u] + v_col);
+        const float* ct = cos_tab + (size_t)pc * 128 + sub * 8;
+        const float* st = sin_tab + (size_t)pc * 128 + sub * 8;
+        cs[u][0] = *(const f32x4*)ct; cs[u][1] = *(const f32x4*)(ct + 4);
+        cs[u][2] = *(const f32x4*)st; cs[u][3] = *(const f32x4*)(st + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 out[2];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {   // 0: q, 1: k
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(raw[u][which][i] << 16);
+            x[2 * i + 1] = __uint_as_float(raw[u][which][i] & 0xffff0000u);
+          }
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+          const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+          const f32x4 w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { x[i] = x[i] * r * w0[i]; x[4 + i] = x[4 + i] * r * w1[i]; }
+          float y[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {   // pairs (2i, 2i+1): out = x*cos + rot*sin, rot = (-x_odd, x_even)
+            const float ce = i < 2 ? cs[u][0][2 * i] : cs[u][1][2 * i - 4], co = i < 2 ? cs[u][0][2 * i + 1] : cs[u][1][2 * i - 3];
+            const float se = i < 2 ? cs[u][2][2 * i] : cs[u][3][2 * i - 4], so = i < 2 ? cs[u][2][2 * i + 1] : cs[u][3][2 * i - 3];
+            y[2 * i] = x[2 * i] * ce - x[2 * i + 1] * se;
+            y[2 * i + 1] = x[2 * i + 1] * co + x[2 * i] * so;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[which][i] = pack_bf16x2(y[2 * i], y[2 * i + 1]);
+        }
+        if (valid[u]) {
+          *(u32x4*)(rowp[u] + q_col) = out[0];
+          *(u32x4*)(rowp[u] + k_col) = out[1];
+        }
+        if (VT) *(u32x4*)&vt_s[(half * 2 + u) * 16 + rloc][sub * 8] = valid[u] ? raw[u][2] : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
     const int p = p0 + pass * 16 + rloc;
@@ -197,6 +266,7 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
       if (valid) raw = *(const u32x4*)(rowp + v_col);
       *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = raw;
     }
+  }
   }
   if (!VT) return;
   __syncthreads();
@@ -509,8 +579,12 @@ static int qkv_launch(void* QKV, int ld, int q_col, int k_col, int v_col, QkvSeg
     t += (segs.rows_per_batch[i] + 63) / 64;
   }
   segs.tile0[segs.n] = t;
-  hipLaunchKernelGGL(qkv_prep_kernel, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col, v_col,
-                     segs, eps, (uint16_t*)VT, vt_ld, H);
+  bool fast = true;
+  for (int i = 0; i < segs.n; ++i) fast = fast && segs.wq[i] && segs.wk[i] && segs.cos_tab[i];
+  if (fast) hipLaunchKernelGGL(qkv_prep_kernel<true>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col,
+                               v_col, segs, eps, (uint16_t*)VT, vt_ld, H);
+  else hipLaunchKernelGGL(qkv_prep_kernel<false>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col,
+                          v_col, segs, eps, (uint16_t*)VT, vt_ld, H);
   LX_LAUNCH_CHECK("lx_qkv_prep");
   return LX_OK;
 }
