@@ -64,38 +64,67 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   // (1) LoRA up-projection as ONE extra MFMA k-step per 4 ranks. t and up are split into bf16 hi + lo parts and
   //     the 16 k-slots carry the four cross terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy
   //     (2^-16 relative) at the cost of 2*MI MFMAs, instead of a scalar epilogue loop.
+  //     Every load of the step -- the up rows of the wave's 64 columns, and t of its BM/2 rows from all K-split slabs of
+  //     lx_lora_down -- is issued before the first value is used: one memory round trip per tile. (One slab at a time,
+  //     one row block at a time, the phase was 16 dependent round trips: ~5 us per tile, and with the condition rows in
+  //     every round of a launch that is ~5 us per ROUND: 17 us of the 326-us fused single-block launch.)
   if (P.lora_t != nullptr) {
     const int R = P.lora_r;
     const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+    const int nsplit = P.lora_nsplit;
+    // 16-B vector loads when rank, strides and bases allow it (always, for the ranks peft is used with); else element loads
+    const bool vec = ((R | P.lora_ldt | P.lora_split_stride | toff) & 3) == 0 && ((((uintptr_t)P.lora_t) | ((uintptr_t)P.lora_up)) & 15) == 0;
+    auto ld4 = [&](const float* p, int nvalid) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        v = *(const f32x4*)p;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) v[e] = p[e];
+      }
+      return v;
+    };
     for (int r0 = 0; r0 < R; r0 += 4) {
+      const int nvalid = min(R - r0, 4);
+      f32x4 u4[2], t4[MI];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) u4[j] = ld4(P.lora_up + (size_t)min(nw0 + j * 32 + l31, N - 1) * R + r0, nvalid);
+      const float* tp[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) tp[i] = P.lora_t + (size_t)min(mw0 + i * 32 + l31, M - 1) * P.lora_ldt + toff + r0;
+      for (int sp0 = 0; sp0 < nsplit; sp0 += 4) {          // K-split partial slabs from lx_lora_down, four per round trip
+        f32x4 sv[MI][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) sv[i][q] = ld4(tp[i] + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride, nvalid);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                          // same summation order as slab-by-slab: ((s0 + s1) + s2) + s3 ...
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            if (sp0 + q == 0) t4[i] = sv[i][q];
+            else if (sp0 + q < nsplit) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t4[i][e] += sv[i][q][e];
+            }
+          }
+      }
       bf16x8 wf[2], xf[MI];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = min(nw0 + j * 32 + l31, N - 1);
-        float u[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = (r0 + e < R) ? P.lora_up[(size_t)n * R + r0 + e] : 0.f;
         u32x4 w;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const uint16_t h0 = f32_to_bf16(u[2 * e]), h1 = f32_to_bf16(u[2 * e + 1]);
-          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                            // slots 0-3: up_hi
-          w[2 + e] = pack_bf16x2(u[2 * e] - bf16_to_f32(h0), u[2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
+          const uint16_t h0 = f32_to_bf16(u4[j][2 * e]), h1 = f32_to_bf16(u4[j][2 * e + 1]);
+          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                                    // slots 0-3: up_hi
+          w[2 + e] = pack_bf16x2(u4[j][2 * e] - bf16_to_f32(h0), u4[j][2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
         }
         wf[j] = __builtin_bit_cast(bf16x8, w);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int m = min(mw0 + i * 32 + l31, M - 1);
-        const float* tp = P.lora_t + (size_t)m * P.lora_ldt + toff + r0;
-        float t[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (r0 + e < R) ? tp[e] : 0.f;
-        for (int sp = 1; sp < P.lora_nsplit; ++sp) {        // K-split partial slabs from lx_lora_down
-          const float* tq = tp + (size_t)sp * P.lora_split_stride;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] += (r0 + e < R) ? tq[e] : 0.f;
-        }
+        const f32x4 t = t4[i];
         u32x2 h;
         if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
           h[0] = pack_bf16x2(t[0], t[1]);
