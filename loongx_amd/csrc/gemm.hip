@@ -49,10 +49,108 @@ struct GemmArgs {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// ---- LoRA up-projection as ONE extra MFMA k-step per 4 ranks ---------------------------------------------------------
+// t (= x . A_down^T, fp32, from lx_lora_down) and up are split into bf16 hi + lo parts and the 16 k-slots carry the four cross
+// terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy (2^-16 relative) at the cost of 2*MI MFMAs, instead of a
+// scalar epilogue loop.
+//   Every load of the step -- the up rows of the wave's 64 columns, and t of its BM/2 rows from up to four K-split slabs of
+// lx_lora_down -- is issued before the first value is used: one memory round trip. (One slab at a time, one row block at a
+// time, the phase was 16 dependent round trips: ~5 us per tile, and with the condition rows in every round of a launch that
+// is ~5 us per ROUND: -5.2 % per denoise step when it went.) lora_issue only loads; lora_sum adds the slabs in slab order
+// (((s0 + s1) + s2) + s3 ...); lora_apply converts and runs the MFMAs.
+template <int MI>
+__device__ __forceinline__ void lora_issue(const lx_gemm_desc& P, int n0, int mw0, int nw0, int l31, int r0, int sp0, f32x4 (&u4)[2],
+                                           f32x4 (&sv)[MI][4]) {
+  const int R = P.lora_r, nsplit = P.lora_nsplit;
+  const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+  const int nvalid = min(R - r0, 4);
+  // 16-B vector loads when rank, strides and bases allow it (always, for the ranks peft is used with); else element loads
+  const bool vec = ((R | P.lora_ldt | P.lora_split_stride | toff) & 3) == 0 && ((((uintptr_t)P.lora_t) | ((uintptr_t)P.lora_up)) & 15) == 0;
+  auto ld4 = [&](const float* p) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      v = *(const f32x4*)p;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) v[e] = p[e];
+    }
+    return v;
+  };
+  if (sp0 == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) u4[j] = ld4(P.lora_up + (size_t)min(nw0 + j * 32 + l31, P.N - 1) * R + r0);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const float* tp = P.lora_t + (size_t)min(mw0 + i * 32 + l31, P.M - 1) * P.lora_ldt + toff + r0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[i][q] = ld4(tp + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride);
+  }
+}
+
+template <int MI>
+__device__ __forceinline__ void lora_sum(const lx_gemm_desc& P, int sp0, const f32x4 (&sv)[MI][4], f32x4 (&t4)[MI]) {
+  const int nsplit = P.lora_nsplit;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (sp0 + q == 0) t4[i] = sv[i][q];
+      else if (sp0 + q < nsplit) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[i][e] += sv[i][q][e];
+      }
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void lora_apply(const f32x4 (&u4)[2], const f32x4 (&t4)[MI], int lhi, f32x16 (&acc)[2][MI]) {
+  bf16x8 wf[2], xf[MI];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint16_t h0 = f32_to_bf16(u4[j][2 * e]), h1 = f32_to_bf16(u4[j][2 * e + 1]);
+      w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                                    // slots 0-3: up_hi
+      w[2 + e] = pack_bf16x2(u4[j][2 * e] - bf16_to_f32(h0), u4[j][2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
+    }
+    wf[j] = __builtin_bit_cast(bf16x8, w);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const f32x4 t = t4[i];
+    u32x2 h;
+    if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
+      h[0] = pack_bf16x2(t[0], t[1]);
+      h[1] = pack_bf16x2(t[2], t[3]);
+    } else {
+      float lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lo[e] = t[e] - bf16_to_f32(f32_to_bf16(t[e]));
+      h[0] = pack_bf16x2(lo[0], lo[1]);
+      h[1] = pack_bf16x2(lo[2], lo[3]);
+    }
+    u32x4 x = {h[0], h[1], h[0], h[1]};
+    xf[i] = __builtin_bit_cast(bf16x8, x);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+}
+
+// Rank <= 4 and <= 4 slabs (the shipped adapters: r = 4, 4 slabs): the whole step is one batch of loads, and it is done at the
+// START of the tile -- loads issued ahead of the prologue's operand DMA, MFMAs into the still-empty accumulators while that DMA
+// is in flight -- so that its memory round trip hides under the DMA latency the tile waits for anyway.
+__device__ __forceinline__ bool lora_in_prologue(const lx_gemm_desc& P) { return P.lora_t != nullptr && P.lora_r <= 4 && P.lora_nsplit <= 4; }
+
 // Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
 template <int BM, int MI>
 __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
-                                              int wave, int wm, int wn, int lane, int l31, int lhi) {
+                                              int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done) {
   const int M = P.M, N = P.N;
   // ---- epilogue ----------------------------------------------------------------------------------
   // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
@@ -61,89 +159,18 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   const int mw0 = m0 + wm * (BM / 2);          // first row of this wave's tile
   const int nw0 = n0 + wn * 64;                // first column of this wave's tile
 
-  // (1) LoRA up-projection as ONE extra MFMA k-step per 4 ranks. t and up are split into bf16 hi + lo parts and
-  //     the 16 k-slots carry the four cross terms (hi*hi, hi*lo, lo*hi, lo*lo) of 4 ranks: fp32-class accuracy
-  //     (2^-16 relative) at the cost of 2*MI MFMAs, instead of a scalar epilogue loop.
-  //     Every load of the step -- the up rows of the wave's 64 columns, and t of its BM/2 rows from all K-split slabs of
-  //     lx_lora_down -- is issued before the first value is used: one memory round trip per tile. (One slab at a time,
-  //     one row block at a time, the phase was 16 dependent round trips: ~5 us per tile, and with the condition rows in
-  //     every round of a launch that is ~5 us per ROUND: 17 us of the 326-us fused single-block launch.)
-  if (P.lora_t != nullptr) {
-    const int R = P.lora_r;
-    const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
-    const int nsplit = P.lora_nsplit;
-    // 16-B vector loads when rank, strides and bases allow it (always, for the ranks peft is used with); else element loads
-    const bool vec = ((R | P.lora_ldt | P.lora_split_stride | toff) & 3) == 0 && ((((uintptr_t)P.lora_t) | ((uintptr_t)P.lora_up)) & 15) == 0;
-    auto ld4 = [&](const float* p, int nvalid) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        v = *(const f32x4*)p;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) v[e] = p[e];
-      }
-      return v;
-    };
+  // (1) LoRA up-projection (see lora_issue / lora_apply below). When rank and slab count fit one batch the whole step has
+  //     already been done in the tile's prologue (lora_in_prologue) and there is nothing to do here.
+  if (P.lora_t != nullptr && !lora_done) {
+    const int R = P.lora_r, nsplit = P.lora_nsplit;
     for (int r0 = 0; r0 < R; r0 += 4) {
-      const int nvalid = min(R - r0, 4);
       f32x4 u4[2], t4[MI];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) u4[j] = ld4(P.lora_up + (size_t)min(nw0 + j * 32 + l31, N - 1) * R + r0, nvalid);
-      const float* tp[MI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) tp[i] = P.lora_t + (size_t)min(mw0 + i * 32 + l31, M - 1) * P.lora_ldt + toff + r0;
       for (int sp0 = 0; sp0 < nsplit; sp0 += 4) {          // K-split partial slabs from lx_lora_down, four per round trip
         f32x4 sv[MI][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int i = 0; i < MI; ++i) sv[i][q] = ld4(tp[i] + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride, nvalid);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)                          // same summation order as slab-by-slab: ((s0 + s1) + s2) + s3 ...
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            if (sp0 + q == 0) t4[i] = sv[i][q];
-            else if (sp0 + q < nsplit) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t4[i][e] += sv[i][q][e];
-            }
-          }
+        lora_issue<MI>(P, n0, mw0, nw0, l31, r0, sp0, u4, sv);
+        lora_sum<MI>(P, sp0, sv, t4);
       }
-      bf16x8 wf[2], xf[MI];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        u32x4 w;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint16_t h0 = f32_to_bf16(u4[j][2 * e]), h1 = f32_to_bf16(u4[j][2 * e + 1]);
-          w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);                                                    // slots 0-3: up_hi
-          w[2 + e] = pack_bf16x2(u4[j][2 * e] - bf16_to_f32(h0), u4[j][2 * e + 1] - bf16_to_f32(h1));  // slots 4-7: up_lo
-        }
-        wf[j] = __builtin_bit_cast(bf16x8, w);
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const f32x4 t = t4[i];
-        u32x2 h;
-        if (lhi == 0) {       // k-slots 0-7 pair with t_hi, slots 8-15 (upper half-wave) with t_lo
-          h[0] = pack_bf16x2(t[0], t[1]);
-          h[1] = pack_bf16x2(t[2], t[3]);
-        } else {
-          float lo[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) lo[e] = t[e] - bf16_to_f32(f32_to_bf16(t[e]));
-          h[0] = pack_bf16x2(lo[0], lo[1]);
-          h[1] = pack_bf16x2(lo[2], lo[3]);
-        }
-        u32x4 x = {h[0], h[1], h[0], h[1]};
-        xf[i] = __builtin_bit_cast(bf16x8, x);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+      lora_apply<MI>(u4, t4, lhi, acc);
     }
   }
 
@@ -294,11 +321,12 @@ __device__ __forceinline__ void tile_lookup(const GemmArgs& args, const int lid,
   tn = in_g / gm;
 }
 
-// K tiles [kt0, kt1) of output tile (m0, n0) accumulated into acc (which the caller has cleared). `smem` = the workgroup's LDS
+// K tiles [kt0, kt1) of output tile (m0, n0) accumulated into acc (which the caller has cleared). `after_issue` runs between the
+// issue of the prologue's operand DMA and the wait for it. `smem` = the workgroup's LDS
 // buffer (gemm_lds_bytes<BM>() bytes, 1 KiB aligned). On return no wave reads the operand rings any more.
-template <int BM>
+template <int BM, class F>
 __device__ __forceinline__ void gemm_mainloop(const lx_gemm_desc& P, const int m0, const int n0, const int tn, const int kt0, const int kt1,
-                                              char* smem, f32x16 (&acc)[2][BM / 64], const int tid) {
+                                              char* smem, f32x16 (&acc)[2][BM / 64], const int tid, F&& after_issue) {
   constexpr int MI = BM / 64;               // 32-row m-blocks per wave
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
@@ -407,6 +435,7 @@ __device__ __forceinline__ void gemm_mainloop(const lx_gemm_desc& P, const int m
     stage_w(0, 0);
     if (nkt > 1) { stage_a(1, 1); stage_w(1, 1); }
     if (nkt > 2) { if constexpr (NSA > 2) stage_a(2, 2); if constexpr (NSW > 2) stage_w(2, 2); }
+    after_issue();                                            // work that fits under the DMA latency (LoRA step)
     if (nkt > 2 && NSW > 2) {
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // BM=128: A1 W1 A2 W2 / BM=256: A1 W1 W2 may stay in flight
     } else {
@@ -501,8 +530,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   f32x16 acc[2][MI];
   acc_clear<MI>(acc);
-  gemm_mainloop<BM>(P, tm * BM, tn * BN, tn, 0, P.K / BK, smem, acc, tid);
-  gemm_epilogue<BM, MI>(P, acc, smem, tm * BM, tn * BN, args.m_base[g], wave, wave >> 2, wave & 3, lane, lane & 31, lane >> 5);
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bool lora_early = lora_in_prologue(P);
+  f32x4 u4[2], sv[MI][4];
+  if (lora_early) lora_issue<MI>(P, n0, m0 + wm * (BM / 2), n0 + wn * 64, l31, 0, 0, u4, sv);
+  gemm_mainloop<BM>(P, m0, n0, tn, 0, P.K / BK, smem, acc, tid, [&]() {
+    if (lora_early) {
+      f32x4 t4[MI];
+      lora_sum<MI>(P, 0, sv, t4);
+      lora_apply<MI>(u4, t4, lhi, acc);
+    }
+  });
+  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, args.m_base[g], wave, wm, wn, lane, l31, lhi, lora_early);
 }
 
 template <int BM>

@@ -11,7 +11,8 @@ def rn(*s, scale=1.0, dt=torch.float32): return (torch.randn(*s, device=dev, gen
 def launch(N, K, kind, nmod):
     A = rn(S, K, dt=torch.bfloat16); W = ops.tile_weight(rn(N, K, scale=0.02, dt=torch.bfloat16)); Wt = ops.tile_weight(rn(N, K, scale=0.02, dt=torch.bfloat16))
     bias = rn(N, scale=0.1); Ad = rn(nmod * r, K, scale=0.1, dt=torch.bfloat16); Bu = rn(N, r, scale=0.1)
-    Tl = torch.empty(Ms[2], nmod * r, dtype=torch.float32, device=dev); ops.lora_down(A[1536:], Ad, Tl)
+    Tls = torch.zeros(4, Ms[2], 16, dtype=torch.float32, device=dev); Tl = Tls[0]          # 4 K-split slabs, as the engine uses
+    ops.lora_down(A[1536:], Ad, Tl[:, :nmod * r], n_split=4, split_stride=Tls.stride(0))
     gate = rn(3, N)
     C = rn(S, N) if kind == "resid" else torch.empty(S, N, device=dev, dtype=torch.bfloat16)
     ds, r0 = [], 0
@@ -20,9 +21,10 @@ def launch(N, K, kind, nmod):
         if kind == "resid": kw.update(epilogue=ops.LX_EPI_RESID_F32, gate=gate[i:i + 1])
         elif kind == "gelu": kw.update(epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU)
         elif kind == "fused": kw.update(epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=3 * D)
-        if i == 2: kw.update(lora_t=Tl, lora_up=Bu, lora_mod_cols=D if nmod > 1 else 0, lora_toff_max=nmod - 1)
+        if i == 2 and not os.environ.get("NOLORA"):
+            kw.update(lora_t=Tl, lora_up=Bu, lora_mod_cols=D if nmod > 1 else 0, lora_toff_max=nmod - 1, lora_nsplit=4, lora_split_stride=Tls.stride(0))
         ds.append(ops.gemm_desc(A[r0:r0 + M], Wt if (i == 0 and kind != "fused" and N != D * 0) else W, C[r0:r0 + M], **kw)); r0 += M
-    return ds, (A, W, Wt, bias, Ad, Bu, Tl, gate, C)
+    return ds, (A, W, Wt, bias, Ad, Bu, Tls, gate, C)
 def timed(ds, it=20):
     for _ in range(3): ops.gemm(ds)
     torch.cuda.synchronize()
