@@ -66,26 +66,37 @@ __device__ __forceinline__ void lora_issue(const lx_gemm_desc& P, int n0, int mw
   const int nvalid = min(R - r0, 4);
   // 16-B vector loads when rank, strides and bases allow it (always, for the ranks peft is used with); else element loads
   const bool vec = ((R | P.lora_ldt | P.lora_split_stride | toff) & 3) == 0 && ((((uintptr_t)P.lora_t) | ((uintptr_t)P.lora_up)) & 15) == 0;
-  auto ld4 = [&](const float* p) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-      v = *(const f32x4*)p;
-    } else {
+  const float* up[2];
+  const float* tp[MI];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) up[j] = P.lora_up + (size_t)min(nw0 + j * 32 + l31, P.N - 1) * R + r0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) tp[i] = P.lora_t + (size_t)min(mw0 + i * 32 + l31, P.M - 1) * P.lora_ldt + toff + r0;
+  if (vec) {                          // ONE branch around all loads, not one per load: they must issue back to back
+    if (sp0 == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) u4[j] = *(const f32x4*)up[j];
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sv[i][q] = *(const f32x4*)(tp[i] + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride);
+  } else {
+    auto ld4 = [&](const float* p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (e < nvalid) v[e] = p[e];
+      return v;
+    };
+    if (sp0 == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) u4[j] = ld4(up[j]);
     }
-    return v;
-  };
-  if (sp0 == 0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) u4[j] = ld4(P.lora_up + (size_t)min(nw0 + j * 32 + l31, P.N - 1) * R + r0);
-  }
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const float* tp = P.lora_t + (size_t)min(mw0 + i * 32 + l31, P.M - 1) * P.lora_ldt + toff + r0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sv[i][q] = ld4(tp + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride);
+      for (int q = 0; q < 4; ++q) sv[i][q] = ld4(tp[i] + (size_t)min(sp0 + q, nsplit - 1) * P.lora_split_stride);
   }
 }
 
