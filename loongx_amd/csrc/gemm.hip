@@ -20,6 +20,7 @@
 //  * blockIdx -> tile map is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous run of tiles,
 //    ordered in 4-tile-tall column groups so co-resident tiles share A / W panels in that L2.
 #include "common.h"
+#include <type_traits>
 
 #ifndef LX_ACC_AGPR
 #define LX_ACC_AGPR 0
@@ -161,7 +162,8 @@ __device__ __forceinline__ bool lora_in_prologue(const lx_gemm_desc& P) { return
 // Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
 template <int BM, int MI>
 __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
-                                              int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done) {
+                                              int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done, int i_begin = 0, int i_end = MI) {
+  // [i_begin, i_end): the 32-row blocks of each wave's tile that this workgroup finishes (all of them, except in the pair kernel)
   const int M = P.M, N = P.N;
   // ---- epilogue ----------------------------------------------------------------------------------
   // acc[j][i][r]: m = m0 + wm*BM/2 + i*32 + l31 ; n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*lhi + (r&3)
@@ -223,6 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   if (bf16_out) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (i < i_begin || i >= i_end) continue;
       const int mb = mw0 + i * 32;
       to_patch(i);
 #pragma unroll
@@ -246,6 +249,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   } else if (epi == LX_EPI_RESID_F32) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (i < i_begin || i >= i_end) continue;
       const int mb = mw0 + i * 32;
       // residual + gate rows of this block, issued before the patch is even written
       f32x4 res[8], gat[8];
@@ -289,6 +293,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (i < i_begin || i >= i_end) continue;
       const int mb = mw0 + i * 32;
       to_patch(i);
 #pragma unroll
@@ -573,6 +578,107 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs 
   else if (bid >= n_big_pad) gemm_tile<128>(tail, bid - n_big_pad, smem);
 }
 
+// ---- 256-row tiles for launches with too few of them: two workgroups per tile, each half of K ------------------------------
+// The N = 3072 projections of the DiT have 120 tiles of 256 x 256 at M = 2560: one per CU would leave half the chip idle, so
+// they ran as 240 tiles of 128 x 256 -- whose main loop moves 1.5x the LDS-DMA bytes per flop and measures 13 % slower per flop
+// (0.867 vs 1.50 / 2 us per K tile). Here the 256 x 256 tile is kept and two workgroups (blockIdx p and p ^ 8: same XCD, same L2)
+// take K ranges [0, nkt/2) and [nkt/2, nkt) of it. Afterwards they swap halves instead of one of them collecting everything:
+// in workgroup h every wave keeps the accumulators of its 32-row blocks 2h and 2h+1 and sends the other two blocks (128 KiB per
+// workgroup, lane-linear fp32, straight from registers, agent-scope write-through) to the partner's slot; each then adds what
+// it received and runs the fused epilogue on its two blocks per wave -- all eight waves busy, the epilogue as short as the
+// 128-row kernel's. One fp32 addition per element, commutative, so both halves of the tile round the same way and the result
+// does not depend on timing.
+//   Hand-off: stores, s_waitcnt vmcnt(0), barrier, flag[p] = 1; then wait for flag[p ^ 8] and clear it (each flag has one writer
+// and one reader, and ends the launch at 0: hipGraph replays need no reset). Both partners wait for each other, so both must
+// get a CU: workgroups are dispatched in blockIdx order and a launch has at most 256 of them, so a workgroup waiting for a
+// partner that is not resident yet only ever waits for complete pairs ahead of it to finish.
+constexpr int PAIR_SLOT_FLOATS = 8 * 16 * 64 * 4;   // eight waves x 16 x f32x4 per lane = 128 KiB
+constexpr int PAIR_AUX_SC1 = 16;                    // gfx940+ buffer cache policy: sc1 (agent scope)
+constexpr int PAIR_MAX_WG = 256;
+
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs args, float* __restrict__ slots, int* __restrict__ flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, MI = 4;
+  __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<256>()];
+  const int pid = blockIdx.x, xcd = pid & 7, inx = pid >> 3;
+  const int jx = inx >> 1, half = inx & 1;
+  const int total = args.tile_start[args.n];
+  const int q = total >> 3, r = total & 7;
+  if (jx >= q + (xcd < r ? 1 : 0)) return;                  // (both partners of a tile that does not exist leave together)
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jx;
+  int g, tm, tn;
+  tile_lookup<BM>(args, lid, g, tm, tn);
+  const lx_gemm_desc& P = args.p[g];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = P.K / BK, kmid = nkt >> 1;
+  f32x16 acc[2][MI];
+  acc_clear<MI>(acc);
+  const bool lora_early = lora_in_prologue(P);              // the LoRA term enters once: through workgroup 0 of the pair
+  f32x4 u4[2], sv[MI][4];
+  if (lora_early && half == 0) lora_issue<MI>(P, n0, m0 + wm * (BM / 2), n0 + wn * 64, l31, 0, 0, u4, sv);
+  gemm_mainloop<BM>(P, m0, n0, tn, half ? kmid : 0, half ? nkt : kmid, smem, acc, tid, [&]() {
+    if (lora_early && half == 0) {
+      f32x4 t4[MI];
+      lora_sum<MI>(P, 0, sv, t4);
+      lora_apply<MI>(u4, t4, lhi, acc);
+    }
+  });
+  // ---- swap halves with the partner: every wave keeps two of its four 32-row blocks and sends the other two ----
+  const int partner = pid ^ 8;
+  const uint32_t lane_off = (uint32_t)(wave * 16 * 1024 + lane * 16);     // slot: [wave][j][kept block][rq][lane] x f32x4
+  auto send = [&](auto I0) {
+    constexpr int i0 = decltype(I0)::value;
+    const lx_rsrc_t rs = lx_make_rsrc(slots + (size_t)pid * PAIR_SLOT_FLOATS);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x16& a = acc[j][i0 + ii];
+          u32x4 v = {__float_as_uint(a[rq * 4]), __float_as_uint(a[rq * 4 + 1]), __float_as_uint(a[rq * 4 + 2]), __float_as_uint(a[rq * 4 + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off, ((j * 2 + ii) * 4 + rq) * 1024, PAIR_AUX_SC1);
+        }
+  };
+  auto recv = [&](auto I0) {
+    constexpr int i0 = decltype(I0)::value;
+    const lx_rsrc_t rs = lx_make_rsrc(slots + (size_t)partner * PAIR_SLOT_FLOATS);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 v[2][4];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) v[ii][rq] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, ((j * 2 + ii) * 4 + rq) * 1024, PAIR_AUX_SC1);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[j][i0 + ii][rq * 4 + c] += __uint_as_float(v[ii][rq][c]);
+      __builtin_amdgcn_sched_barrier(0);       // 8 loads in flight, not 16: the accumulators leave few free registers
+    }
+  };
+  // workgroup `half` keeps blocks 2*half, 2*half + 1 (compile-time register indices on both sides of the branch)
+  if (half == 0) send(std::integral_constant<int, 2>{});
+  else send(std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(flags + pid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (half == 0) recv(std::integral_constant<int, 0>{});
+  else recv(std::integral_constant<int, 2>{});
+  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, args.m_base[g], wave, wm, wn, lane, l31, lhi, lora_early, half * 2, half * 2 + 2);
+#endif
+}
+
 }  // namespace
 
 // ---- launch planning ---------------------------------------------------------------------------------------------
@@ -581,6 +687,48 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs 
 // per-64-deep-K-tile slope at full occupancy.
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
+
+
+// ---- pair-kernel scratch: one accumulator-exchange slot + flag per workgroup, per device ------------------------------------
+// Shared by every stream of the device: lx_gemm_bf16 launches that may run CONCURRENTLY on one device (different streams, no
+// dependency between them) must not both take the pair path -- set LX_GEMM_PAIR=0 in such a process. The DiT step is one
+// in-order stream (or its captured graph), where launches cannot overlap.
+namespace {
+struct PairScratch { int device; float* slots; int* flags; };
+PairScratch g_pair[16];
+int g_pair_n = 0;
+
+// Returns the scratch of the current device, allocating it on first use; nullptr if it cannot be allocated now (the stream is
+// being captured into a graph, table full, out of memory) -- the caller then uses the one-tile-per-workgroup kernels.
+const PairScratch* pair_scratch(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (int i = 0; i < g_pair_n; ++i)
+    if (g_pair[i].device == dev) return &g_pair[i];
+  if (g_pair_n == 16) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  PairScratch e{dev, nullptr, nullptr};
+  if (hipMalloc((void**)&e.slots, (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMalloc((void**)&e.flags, PAIR_MAX_WG * sizeof(int)) != hipSuccess || hipMemset(e.flags, 0, PAIR_MAX_WG * sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(e.slots);
+    return nullptr;
+  }
+  g_pair[g_pair_n] = e;
+  return &g_pair[g_pair_n++];
+}
+
+int device_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 0;
+  }
+  return n;
+}
+}  // namespace
 
 static long tiles_of(const lx_gemm_desc& p, int bm) { return (long)((p.M + bm - 1) / bm) * ((p.N + BN - 1) / BN); }
 
@@ -641,6 +789,29 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int NCU = 256;
   const int forced = env_int("LX_GEMM_BM", 0);      // 256 | 128 | 0 = plan
+  // Two workgroups per 256-row tile (lx_gemm_pair_kernel) when there are at most 128 such tiles: needs one K for the whole
+  // group, a 256-CU device and the scratch slots. LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144:
+  // the swap costs ~6 us, the better loop saves 0.12 us per K tile) | 2 whenever possible (tests).
+  {
+    const int pair_mode = env_int("LX_GEMM_PAIR", 1);
+    bool uniform_k = true;
+    for (int i = 1; i < n; ++i) uniform_k = uniform_k && problems[i].K == problems[0].K;
+    const int per_xcd = (int)(t256 / 8 + (t256 % 8 ? 1 : 0));
+    const bool fits = per_xcd * 16 <= NCU && kmax / BK >= 2;
+    const bool pays = pair_mode == 2 || kmax / BK >= env_int("LX_GEMM_PAIR_MIN_KT", 96);
+    if (pair_mode && forced == 0 && uniform_k && fits && pays && device_cus() == NCU) {
+      if (const PairScratch* sc = pair_scratch(s)) {
+        GemmArgs all;
+        all.n = 0;
+        all.tile_start[0] = 0;
+        for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+        for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
+        hipLaunchKernelGGL(lx_gemm_pair_kernel, dim3(per_xcd * 16), dim3(NTHREADS), 0, s, all, sc->slots, sc->flags);
+        LX_LAUNCH_CHECK("lx_gemm_bf16");
+        return LX_OK;
+      }
+    }
+  }
   // candidate schedules: all 256-row tiles, all 128-row tiles, or full rounds of 256-row tiles + a 128-row-tile tail
   const double c_a = (double)((t256 + NCU - 1) / NCU) * round_us(256, kmax);
   const double c_b = (double)((t128 + NCU - 1) / NCU) * round_us(128, kmax);

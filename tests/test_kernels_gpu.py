@@ -29,10 +29,23 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("bm", [256, 128])
+PLANS = [256, 128, "pair"]
+
+
+def _plan(monkeypatch, bm):
+    """Force one launch plan: all 256-row tiles, all 128-row tiles, or two workgroups per 256-row tile, each half of K
+    ("pair": lx_gemm_pair_kernel wherever the launch has <= 128 tiles and K >= 128)."""
+    if bm == "pair":
+        monkeypatch.delenv("LX_GEMM_BM", raising=False)
+        monkeypatch.setenv("LX_GEMM_PAIR", "2")
+    else:
+        monkeypatch.setenv("LX_GEMM_BM", str(bm))
+
+
+@pytest.mark.parametrize("bm", PLANS)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (2560, 3072, 3072)])
 def test_gemm_store_bf16_bias(ops, M, N, K, bm, monkeypatch):
-    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _plan(monkeypatch, bm)
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
     bias = rnd(N, seed=3)
@@ -53,9 +66,9 @@ def test_gemm_asymmetric_identity(ops):
     assert torch.equal(Cc, W.float().T)
 
 
-@pytest.mark.parametrize("bm", [256, 128])
+@pytest.mark.parametrize("bm", PLANS)
 def test_gemm_gelu_colstart_and_f32(ops, bm, monkeypatch):
-    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _plan(monkeypatch, bm)
     M, N, K = 520, 1024, 192
     A = rnd(M, K, seed=4, dtype=torch.bfloat16)
     W = rnd(N, K, seed=5, scale=0.1, dtype=torch.bfloat16)
@@ -70,10 +83,10 @@ def test_gemm_gelu_colstart_and_f32(ops, bm, monkeypatch):
     assert relerr(C32.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
 
-@pytest.mark.parametrize("bm", [256, 128])
+@pytest.mark.parametrize("bm", PLANS)
 def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
     """Three-stream launch: text (own weights), image (base weights), condition (base + LoRA), gated residual."""
-    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _plan(monkeypatch, bm)
     B, T, Nn, Cn, D, K, r = 2, 48, 80, 96, 512, 256, 4
     Wt = rnd(D, K, seed=1, scale=0.05, dtype=torch.bfloat16)
     Wi = rnd(D, K, seed=2, scale=0.05, dtype=torch.bfloat16)
@@ -126,10 +139,10 @@ def test_gemm_lora_module_offsets(ops):
     assert relerr(Cc.cpu(), ref.cpu()) < 2e-5
 
 
-@pytest.mark.parametrize("bm", [256, 128])
+@pytest.mark.parametrize("bm", PLANS)
 def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     """LX_W_TILED: the load-time tiled/swizzled weight image must give bit-identical results to the row-major weight."""
-    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _plan(monkeypatch, bm)
     M, N, K = 700, 768, 320
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
@@ -142,6 +155,49 @@ def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     ops.gemm([ops.gemm_desc(A, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
     assert torch.equal(C1, C2)
     assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
+
+
+def test_gemm_pair_kernel_long_k(ops, monkeypatch):
+    """Two workgroups per tile on the single-block proj_out shape (120 tiles, K = 15360, gated fp32 residual + LoRA): against the
+    128-row-tile kernel on the same inputs, bit-identical from run to run, and again after HIP-graph capture + replays (each
+    flag is cleared by its reader, so replays need no reset)."""
+    monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    M, N, K, r = 2560, 3072, 15360, 4
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3, scale=0.1)
+    gate = rnd(1, N, seed=4)
+    X0 = rnd(M, N, seed=5)
+    Ad = rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16)
+    Bu = rnd(N, r, seed=8, scale=0.1)
+    Tls = torch.zeros(4, M, 16, dtype=torch.float32, device=DEV)
+    ops.lora_down(A, Ad, Tls[0][:, :r], n_split=4, split_stride=Tls.stride(0))
+    out = {}
+    X = torch.empty_like(X0)
+    d = ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
+                      lora_split_stride=Tls.stride(0))
+    for mode in ("0", "2"):
+        monkeypatch.setenv("LX_GEMM_PAIR", mode)
+        X.copy_(X0)
+        ops.gemm([d])
+        torch.cuda.synchronize()
+        out[mode] = X.clone()
+    t = Tls.sum(0)[:, :r]
+    ref = X0 + gate * (A.float() @ W.float().T + bias + t @ Bu.T)
+    assert relerr(out["2"].cpu(), ref.cpu()) < 2e-5
+    assert relerr(out["2"].cpu(), out["0"].cpu()) < 2e-6      # same products, one more fp32 rounding per element
+    for _ in range(3):
+        X.copy_(X0)
+        ops.gemm([d])
+        assert torch.equal(X, out["2"])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        X.copy_(X0)
+        ops.gemm([d])
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(X, out["2"])
 
 
 def test_gemm_planner_mixed_tail(ops, monkeypatch):
