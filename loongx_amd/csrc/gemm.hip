@@ -589,9 +589,10 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs 
 // 128-row kernel's. One fp32 addition per element, commutative, so both halves of the tile round the same way and the result
 // does not depend on timing.
 //   Hand-off: stores, s_waitcnt vmcnt(0), barrier, flag[p] = 1; then wait for flag[p ^ 8] and clear it (each flag has one writer
-// and one reader, and ends the launch at 0: hipGraph replays need no reset). Both partners wait for each other, so both must
-// get a CU: workgroups are dispatched in blockIdx order and a launch has at most 256 of them, so a workgroup waiting for a
-// partner that is not resident yet only ever waits for complete pairs ahead of it to finish.
+// and one reader, and ends the launch at 0: hipGraph replays need no reset). The data path assumes nothing about placement (sc1
+// stores AND sc1 loads: correct across XCDs; p ^ 8 is only the likely-same-L2 choice). Both partners wait for each other, so
+// both must get a CU: a launch has at most 256 workgroups of one per CU on a 256-CU device (checked on the host) and the stream
+// is in order, so all of them are resident together; the poll is bounded and traps instead of hanging if that ever fails.
 constexpr int PAIR_SLOT_FLOATS = 8 * 16 * 64 * 4;   // eight waves x 16 x f32x4 per lane = 128 KiB
 constexpr int PAIR_AUX_SC1 = 16;                    // gfx940+ buffer cache policy: sc1 (agent scope)
 constexpr int PAIR_MAX_WG = 256;
@@ -669,7 +670,13 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(flags + pid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    // bounded: ~1 s of polling, against microseconds of expected wait. A partner that never shows up (a device whose CUs
+    // are held by something else for good) becomes a launch failure the host sees, not a hung GPU.
+    int spins = 0;
+    while (__hip_atomic_load(flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) __builtin_trap();
+    }
     __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
