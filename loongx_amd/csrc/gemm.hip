@@ -319,14 +319,18 @@ template <int BM>
 constexpr int gemm_lds_bytes() { return BM == 128 ? 3 * (128 * BK * 2) + 3 * (BN * BK * 2) : 2 * (256 * BK * 2) + 2 * (BN * BK * 2); }
 
 // lid (position in the launch's tile order) -> (sub)problem g and tile (tm, tn): 4-tile-tall column groups inside a problem.
-template <int BM>
-__device__ __forceinline__ void tile_lookup(const GemmArgs& args, const int lid, int& g, int& tm, int& tn) {
-  g = 0;
+// Two steps, with the descriptor copied BY VALUE in between: indexing the kernarg array lazily, field by field, made the tile
+// start a chain of nine dependent scalar-load round trips before the first operand DMA could be issued.
+__device__ __forceinline__ int tile_group(const GemmArgs& args, const int lid) {
+  int g = 0;                                   // (entries past the last problem hold the total, which no lid reaches: no need for args.n)
 #pragma unroll
   for (int i = 1; i < MAX_SUB; ++i)
-    if (i < args.n && lid >= args.tile_start[i]) g = i;
-  const lx_gemm_desc& P = args.p[g];
-  const int local = lid - args.tile_start[g];
+    if (lid >= args.tile_start[i]) g = i;
+  return g;
+}
+
+template <int BM>
+__device__ __forceinline__ void tile_coords(const lx_gemm_desc& P, const int local, int& tm, int& tn) {
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
   const int gs = GROUP_M * tiles_n;
@@ -532,16 +536,17 @@ template <int BM>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, char* smem) {
   constexpr int MI = BM / 64;
   // ---- XCD-aware block -> tile map: each XCD (pid & 7) owns a contiguous run of the tile order ----
-  const int total = args.tile_start[args.n];
+  const int total = args.tile_start[MAX_SUB];     // plan_add keeps every entry past the last problem equal to the total
   int lid;
   {
     const int q = total >> 3, r = total & 7;
     const int xcd = pid & 7, inx = pid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
   }
-  int g, tm, tn;
-  tile_lookup<BM>(args, lid, g, tm, tn);
-  const lx_gemm_desc& P = args.p[g];
+  const int g = tile_group(args, lid);
+  const lx_gemm_desc P = args.p[g];            // by value: one batch of scalar loads
+  int tm, tn;
+  tile_coords<BM>(P, lid - args.tile_start[g], tm, tn);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   f32x16 acc[2][MI];
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) 
 __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs big, const GemmArgs tail, const int n_big_pad) {
   __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<128>() > gemm_lds_bytes<256>() ? gemm_lds_bytes<128>() : gemm_lds_bytes<256>()];
   const int bid = blockIdx.x;
-  if (bid < big.tile_start[big.n]) gemm_tile<256>(big, bid, smem);
+  if (bid < big.tile_start[MAX_SUB]) gemm_tile<256>(big, bid, smem);
   else if (bid >= n_big_pad) gemm_tile<128>(tail, bid - n_big_pad, smem);
 }
 
@@ -603,13 +608,14 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
   __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<256>()];
   const int pid = blockIdx.x, xcd = pid & 7, inx = pid >> 3;
   const int jx = inx >> 1, half = inx & 1;
-  const int total = args.tile_start[args.n];
+  const int total = args.tile_start[MAX_SUB];     // plan_add keeps every entry past the last problem equal to the total
   const int q = total >> 3, r = total & 7;
   if (jx >= q + (xcd < r ? 1 : 0)) return;                  // (both partners of a tile that does not exist leave together)
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jx;
-  int g, tm, tn;
-  tile_lookup<BM>(args, lid, g, tm, tn);
-  const lx_gemm_desc& P = args.p[g];
+  const int g = tile_group(args, lid);
+  const lx_gemm_desc P = args.p[g];            // by value: one batch of scalar loads
+  int tm, tn;
+  tile_coords<BM>(P, lid - args.tile_start[g], tm, tn);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
