@@ -59,8 +59,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) == x * sigmoid(2u)
+  // v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division here compiles to v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup
+  // per element -- ~10 VALU instructions x 128 outputs per lane, 4.4 us per tile round of the MLP GEMMs (measured: 15 us of the
+  // 309-us fused single-block launch). The output is rounded to bf16 (or added to an fp32 residual at 2^-8 relative weight).
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -253,12 +253,17 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
       const int mb = mw0 + i * 32;
       // residual + gate rows of this block, issued before the patch is even written
       f32x4 res[8], gat[8];
+      // batch (= gate row) of each of the block's rows: one wave-uniform division per block when a batch has >= 32 rows (then the
+      // block straddles at most one batch boundary), instead of a ~25-instruction integer division per row group and lane
+      const int rpb = P.rows_per_batch;
+      const int b_first = (m_base + mb) / rpb, rem_first = (m_base + mb) - b_first * rpb;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const int m = mb + t * 4 + (lane >> 4);
+        const int rr = t * 4 + (lane >> 4), m = mb + rr;
         if (m < M && col_ok) {
           res[t] = *(const f32x4*)((const float*)P.C + (size_t)m * P.ldc + ncol);
-          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)((m_base + m) / P.rows_per_batch) * P.gate_ld + ncol);
+          const int b = rpb >= 32 ? b_first + (rem_first + rr >= rpb ? 1 : 0) : (m_base + m) / rpb;
+          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)b * P.gate_ld + ncol);
         }
       }
       to_patch(i);
