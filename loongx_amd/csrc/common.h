@@ -62,8 +62,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   // v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division here compiles to v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup
   // per element -- ~10 VALU instructions x 128 outputs per lane, 4.4 us per tile round of the MLP GEMMs (measured: 15 us of the
   // 309-us fused single-block launch). The output is rounded to bf16 (or added to an fp32 residual at 2^-8 relative weight).
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+  // Constants folded so that exp(-2u) is ONE v_exp_f32 of x * (C1 + C2 x^2): C1 = -2 sqrt(2/pi) log2(e), C2 = 0.044715 C1.
+  const float p = x * __builtin_fmaf(x * x, -0.10294324221f, -2.30220819813f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
