@@ -32,7 +32,11 @@ ROOFLINE_STEPS = (9, 18)     # denoise steps of the last timed image whose GEMM 
 def flops_per_image(n_img_tokens: int, n_cond_tokens: int, layers: int = 57) -> float:
     """per block per sample 24*S*D^2 + 4*S^2*D (2*MAC), x57 blocks x28 steps."""
     S = T_TXT + n_img_tokens + n_cond_tokens
-    return STEPS * layers * (24.0 * S * D * D + 4.0 * S * S * D)
+    total = STEPS * layers * (24.0 * S * D * D + 4.0 * S * S * D)
+    # The engine does not compute what nobody reads: in the LAST single block the text / condition rows get no queries, no
+    # MLP branch and no output projection (DiTEngine.single_block(image_out_only=True)): 2 * 5 D^2 MACs per such token.
+    skipped = STEPS * 2.0 * (T_TXT + n_cond_tokens) * (2 * 5 * D * D) if layers == 57 else 0.0
+    return total - skipped
 
 
 def cpu_baseline(threads: int):

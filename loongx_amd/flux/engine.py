@@ -276,16 +276,27 @@ class DiTEngine:
 
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
                       gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
-                      gelu_col_start: int = 0) -> None:
+                      gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None) -> None:
         """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
-        (None => text rows use `main` too: single blocks)."""
+        (None => text rows use `main` too: single blocks). `only` restricts the launch to those streams and `ncols[s]` to the
+        first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
         w = self.w
-        lo, lr0 = self._lora_t(A, main, include_txt=txt is None)
+        lora_needed = only is None or "cond" in only or self.latent_lora
+        lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
         probs = []
         for s, L in self._streams():
+            if only is not None and s not in only:
+                continue
             name = txt if (s == "txt" and txt is not None) else main
             a, c = self.rows(A, s), self.rows(Cbuf, s)
-            kw = dict(bias=w.t[name + ".b"], epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
+            W, bias = w.t[name + ".w"], w.t[name + ".b"]
+            n_out = ncols.get(s) if ncols else None
+            if n_out is not None and n_out < W.shape[0]:
+                tiled = getattr(W, "lx_tiled", False)
+                W, bias, c = W[:n_out], bias[:n_out], c[:, :n_out]
+                if tiled:
+                    W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
+            kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
             if gate_off is not None:
                 mods = self.cmods if s == "cond" else self.mods
                 kw["gate"] = mods[:, gate_off[s]:]
@@ -293,9 +304,9 @@ class DiTEngine:
                                                     (s == "txt" and self.latent_lora and txt is None)):
                 row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
                 if row0 >= lr0:
-                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up, lora_mod_cols=lora_mod_cols,
+                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up[:W.shape[0]], lora_mod_cols=lora_mod_cols,
                               lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
-            probs.append(ops.gemm_desc(a, w.t[name + ".w"], c, **kw))
+            probs.append(ops.gemm_desc(a, W, c, **kw))
         ops.gemm(probs)
 
     def _attention(self, wq, wk, wq_txt, wk_txt) -> None:
@@ -361,18 +372,24 @@ class DiTEngine:
         gate = {s: base[s] + 5 * D for s in base}
         self._gemm_streams(Yf, self.X, p + ".ff2", p + ".ff2_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
 
-    def single_block(self, j: int) -> None:
+    def single_block(self, j: int, image_out_only: bool = False) -> None:
+        """image_out_only: the caller reads nothing but the image rows of X afterwards (the LAST block of a forward: norm_out /
+        proj_out run on the image tokens, transformer.py:243-252). The text and condition rows then still need their keys and
+        values (the image queries attend to them) but neither queries, MLP branch nor output projection: 145 + 145 of the
+        block's 580 GFLOP of GEMM work are skipped, with bit-identical image rows."""
         cfg, w = self.cfg, self.w
         D = cfg.inner_dim
         b = cfg.mod_base_single(j)
         base = {"img": b, "cond": b, "txt": b}
         p = f"s{j}"
         self._ln(base, 0, D)
+        kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
         self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                           lora_mod_cols=D, lora_toff_max=3)
+                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only)
         self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
         gate = {s: b + 2 * D for s in base}
-        self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate)
+        self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
+                           only=("img",) if image_out_only else None)
 
     # ------------------------------------------------------------------------------------------ one step
     def embed_step_inputs(self, latents: torch.Tensor, timestep: torch.Tensor, mods_ready: bool = False) -> None:
@@ -409,8 +426,9 @@ class DiTEngine:
         self.embed_step_inputs(latents, timestep, mods_ready)
         for i in range(self.cfg.num_layers):
             self.double_block(i)
+        last = self.cfg.num_single_layers - 1
         for j in range(self.cfg.num_single_layers):
-            self.single_block(j)
+            self.single_block(j, image_out_only=(j == last))
         return self.final_layer()
 
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, step_index: Optional[int] = None) -> torch.Tensor:
