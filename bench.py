@@ -159,13 +159,13 @@ def main():
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one image
             # HBM-side traffic per launch is not observable from inside the process: it comes from the committed rocprofv3
-            # PMC passes of this same workload (profiles/r01e_pmc_*.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+            # PMC passes of this same workload (profiles/r01f_pmc_*.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
             # launch-weighted mean over the GEMM launches of one step), or null if that summary is absent.
             traffic = None
             try:
                 import re
                 tot, n_l = 0.0, 0
-                for fn, key, mult in (("r01e_pmc_FETCH.txt", "FETCH_SIZE", 2.0), ("r01e_pmc_WRITE.txt", "WRITE_SIZE", 1.0)):
+                for fn, key, mult in (("r01f_pmc_FETCH.txt", "FETCH_SIZE", 2.0), ("r01f_pmc_WRITE.txt", "WRITE_SIZE", 1.0)):
                     n_l = 0
                     for line in open(os.path.join(ROOT, "profiles", fn)):
                         if "lx_gemm_" in line:
@@ -176,7 +176,7 @@ def main():
                 traffic = None
             res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                               "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01e_pmc_*.txt)",
+                               "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01f_pmc_*.txt)",
                                "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
                                "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
                                "share_of_step_time": round(gm["ms"] * to_image / (elapsed_ms / a.steps), 3),
