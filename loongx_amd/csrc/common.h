@@ -66,6 +66,18 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   const float p = x * __builtin_fmaf(x * x, -0.10294324221f, -2.30220819813f);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p));
 }
+// Two at a time: the polynomial part on the packed-fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two elements per instruction),
+// only the exp2 and the reciprocal per element. Same arithmetic as gelu_tanh, element by element.
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+  const f32x2 c1 = {-2.30220819813f, -2.30220819813f}, c2 = {-0.10294324221f, -0.10294324221f}, one = {1.0f, 1.0f};
+  const f32x2 p = x * __builtin_elementwise_fma(x * x, c2, c1);
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])} + one;
+  return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x4 gelu_tanh4(f32x4 v) {
+  const f32x2 a = gelu_tanh2(f32x2{v[0], v[1]}), b = gelu_tanh2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -236,10 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         if (m < M && col_ok) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) { v0[c] += bias0[c]; v1[c] += bias1[c]; }
-          if (gelu0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] = gelu_tanh(v0[c]); v1[c] = gelu_tanh(v1[c]); }
-          }
+          if (gelu0) { v0 = gelu_tanh4(v0); v1 = gelu_tanh4(v1); }
           u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
           *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
         }
@@ -278,10 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         if (m < M && col_ok) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += bias0[c];
-          if (gelu0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
-          }
+          if (gelu0) v = gelu_tanh4(v);
           f32x4 o = res[t];
           if (P.gate) {
 #pragma unroll
@@ -308,10 +302,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         if (m < M && col_ok) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += bias0[c];
-          if (gelu0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
-          }
+          if (gelu0) v = gelu_tanh4(v);
           *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
         }
       }
