@@ -79,7 +79,14 @@ typedef struct lx_gemm_desc {
 
 #define LX_GEMM_MAX_GROUP 4
 /* One launch over `n` independent problems (the three token streams of a block share one launch so
- * that small-M streams still fill the chip).  K % 64 == 0, N % 8 == 0, lda/ldw/ldc % 8 == 0. */
+ * that small-M streams still fill the chip).  K % 64 == 0, N % 8 == 0, lda/ldw/ldc % 8 == 0.
+ * The launch plan is chosen per call (256-row tiles / 128-row tiles / full rounds of 256 + a 128-row tail / two workgroups
+ * per 256-row tile, each half of K); results are deterministic for a given plan, and plans that split K differ from the others
+ * by one fp32 rounding per element. Environment: LX_GEMM_BM=256|128 forces a tile height; LX_GEMM_PAIR=0 disables the split-K
+ * pair plan (it is used when the launch has <= 128 tiles of 256x256, one K, K >= 6144, on a 256-CU device). The pair plan
+ * keeps one 32 MiB scratch + flag array per device, allocated on the first eligible call made OUTSIDE stream capture (calls
+ * inside a capture before that use the other plans); it is shared by all streams of the device, so two lx_gemm_bf16 launches
+ * that may run concurrently on one device (different streams, no dependency) need LX_GEMM_PAIR=0. */
 int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
 
 /* LoRA down-projection (peft lora_A): T_s[M, R] (fp32, ldt) = X[M, K_s] (bf16, ldx) . Adown[R, K_s]^T (bf16), R <= 16,
