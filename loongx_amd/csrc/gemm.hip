@@ -672,12 +672,12 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(flags + pid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // bounded: ~1 s of polling, against microseconds of expected wait. A partner that never shows up (a device whose CUs
+    // bounded: ~1-2 s of polling (each iteration is one L2 round trip), against microseconds of expected wait. A partner that never shows up (a device whose CUs
     // are held by something else for good) becomes a launch failure the host sees, not a hung GPU.
     int spins = 0;
     while (__hip_atomic_load(flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 24)) __builtin_trap();
+      if (++spins > (1 << 20)) __builtin_trap();
     }
     __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
