@@ -11,6 +11,12 @@ as in the reference) + 28 three-stream DiT forwards + Euler updates, packed late
 shape (19 double + 38 single blocks, D=3072, 11.9 B params) with synthetic weights (no network for checkpoints).
 Multi-GPU: data parallel, one process per GPU, independent images per rank, no collective inside the loop; rank 0
 draws the weights and broadcasts them over RCCL/xGMI before the timed region.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts its N ranks itself (re-executes under
+`python -m torch.distributed.run`, as the reference's inference.py:432-452 spawns its own workers).
+
+Besides the contract fields the line carries `roofline` (dominant kernel, live HIP events), `cpu_baseline` (the oracle on
+this box's host cores, bounded sample) and `parity` (the engine against the fp32 oracle on identical inputs at
+FULL depth -- 57 blocks x 28 steps -- per-step noise_pred rel-err, final-latent rel-err and cosine; N=1 only).
 """
 import argparse
 import json
@@ -65,6 +71,43 @@ def cpu_baseline(threads: int):
                       f"extrapolated x(19,38) blocks x28 steps"}
 
 
+def parity_check(precise: bool = False):
+    """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
+    timed region) at full depth and width on this GPU."""
+    from oracle.parity import full_depth_parity
+    return full_depth_parity("cuda:0", steps=STEPS, precise=precise)
+
+
+def _gemm_traffic_mb():
+    """HBM-side bytes per GEMM launch cannot be observed from inside the process: they come from separate rocprofv3 --pmc passes
+    of this workload, summarised by tools/pmc_traffic.py into profiles/pmc_traffic.json together with the hash of the kernel
+    source they were measured on. A summary of a different gemm.hip is stale: report null rather than a number that no longer
+    describes the kernel."""
+    import hashlib
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+        if rec.get("gemm_hip_sha16") != sha:
+            return None, None
+        return rec["gemm_traffic_MB_per_launch"], rec.get("source")
+    except Exception:
+        return None, None
+
+
+def _self_launch(n: int) -> int:
+    """Re-execute this script under torch.distributed.run with n ranks on this node (one process per GPU, RCCL)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,14 +116,18 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (N=1 only; ~1 min on the GPU)")
+    ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32 attention)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(a.gpus))
 
     from loongx_amd import dist as lxd
     from loongx_amd import ops
     rank, local, world = lxd.init()
     if world != a.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
     torch.cuda.set_device(local)
@@ -96,8 +143,12 @@ def main():
     cfg = FluxConfig()
     t0 = time.time()
     pw = synthetic_weights(cfg, dev, seed=0 if rank == 0 else 1000 + rank)   # non-zero ranks hold garbage until the broadcast
+    torch.cuda.synchronize()
+    t_draw = time.time() - t0
+    t1 = time.time()
     moved = lxd.broadcast_packed_weights(pw, src=0)
     torch.cuda.synchronize()
+    t_bcast = time.time() - t1
     t_weights = time.time() - t0
     model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), {"union_cond_attn": True}, dev)
 
@@ -112,7 +163,8 @@ def main():
         c = Condition("subject", latents=x["cond"], latent_hw=(hw, hw), position_delta=[0, -hw])
         return generate(model, model.flux_pipe, conditions=[c], height=512, width=512, num_inference_steps=STEPS, latents=x["lat"],
                         prompt_embeds=x["pe"], pooled_prompt_embeds=x["pooled"], output_type="latent", model_config=model.model_config,
-                        default_lora=True, additional_condition1=x["eeg"], use_brain_condition=True, fuse_flag=False).images
+                        default_lora=True, additional_condition1=x["eeg"], use_brain_condition=True, fuse_flag=False,
+                        brain_replace="per_stream").images      # EEG-only conditioning (configs[1]) needs the per-stream rule
 
     batches = [batch() for _ in range(a.warmup + a.steps)]
     for i in range(a.warmup):
@@ -149,7 +201,8 @@ def main():
                "config": {"workload": "BASELINE configs[1]: EEG-only CS3 conditioning, 512x512 edit (512 txt + 1024 img + 1024 cond "
                                       "tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, D=3072), LoRA r=4 on the condition stream",
                           "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
-                          "weight_broadcast_GB": round(moved / 1e9, 2), "init_s": round(t_weights, 2)},
+                          "rccl_ranks": world, "weight_broadcast_GB": round(moved / 1e9, 2), "weight_broadcast_s": round(t_bcast, 2),
+                          "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)},
                "outputs_finite": finite,
                "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
                "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
@@ -158,25 +211,11 @@ def main():
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one image
-            # HBM-side traffic per launch is not observable from inside the process: it comes from the committed rocprofv3
-            # PMC passes of this same workload (profiles/r01f_pmc_*.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
-            # launch-weighted mean over the GEMM launches of one step), or null if that summary is absent.
-            traffic = None
-            try:
-                import re
-                tot, n_l = 0.0, 0
-                for fn, key, mult in (("r01f_pmc_FETCH.txt", "FETCH_SIZE", 2.0), ("r01f_pmc_WRITE.txt", "WRITE_SIZE", 1.0)):
-                    n_l = 0
-                    for line in open(os.path.join(ROOT, "profiles", fn)):
-                        if "lx_gemm_" in line:
-                            n = int(re.search(r" n=\s*(\d+)", line).group(1)); v = float(re.search(key + r"=([0-9.e+]+)", line).group(1))
-                            tot += mult * v * 1024 * n; n_l += n
-                traffic = round(tot / max(n_l, 1) / 1e6, 1)
-            except Exception:
-                traffic = None
+            traffic, traffic_src = _gemm_traffic_mb()
             res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                               "traffic_unit": "MB per launch (rocprofv3 PMC, profiles/r01f_pmc_*.txt)",
+                               "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",
+                               "traffic_source": traffic_src,
                                "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
                                "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
                                "share_of_step_time": round(gm["ms"] * to_image / (elapsed_ms / a.steps), 3),
@@ -189,6 +228,13 @@ def main():
                                              "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / a.steps), 3)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        if world == 1 and not a.no_parity:
+            del model, pw, batches, out
+            torch.cuda.empty_cache()
+            try:
+                res["parity"] = parity_check(a.precise)
+            except Exception as e:          # the checker must never take the measurement down with it
+                res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

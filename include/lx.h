@@ -80,14 +80,28 @@ typedef struct lx_gemm_desc {
 #define LX_GEMM_MAX_GROUP 4
 /* One launch over `n` independent problems (the three token streams of a block share one launch so
  * that small-M streams still fill the chip).  K % 64 == 0, N % 8 == 0, lda/ldw/ldc % 8 == 0.
- * The launch plan is chosen per call (256-row tiles / 128-row tiles / full rounds of 256 + a 128-row tail / two workgroups
- * per 256-row tile, each half of K); results are deterministic for a given plan, and plans that split K differ from the others
- * by one fp32 rounding per element. Environment: LX_GEMM_BM=256|128 forces a tile height; LX_GEMM_PAIR=0 disables the split-K
- * pair plan (it is used when the launch has <= 128 tiles of 256x256, one K, K >= 6144, on a 256-CU device). The pair plan
- * keeps one 32 MiB scratch + flag array per device, allocated on the first eligible call made OUTSIDE stream capture (calls
- * inside a capture before that use the other plans); it is shared by all streams of the device, so two lx_gemm_bf16 launches
- * that may run concurrently on one device (different streams, no dependency) need LX_GEMM_PAIR=0. */
+ * The launch plan is chosen per call (256-row tiles / 128-row tiles / full rounds of 256 + a 128-row tail); results are
+ * deterministic for a given plan. Environment, read when the library is loaded (lx_gemm_reload_env() re-reads it):
+ * LX_GEMM_BM=256|128 forces a tile height. */
 int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream);
+void lx_gemm_reload_env(void);
+
+/* The same with a caller-owned workspace, which unlocks launch plans that exchange partial accumulators between workgroups:
+ * the split-K PAIR plan (two workgroups per 256-row tile, each half of K, accumulator blocks swapped through L2) for long-K
+ * launches with <= 128 tiles of 256x256 that would otherwise leave half the chip idle (the N = 3072 projections of the DiT
+ * at batch 1). Plans that split K differ from the others by one fp32 rounding per element.
+ *   workspace: lx_gemm_workspace_bytes() bytes of device memory, 256-byte aligned, ZERO-FILLED ONCE by the caller before its
+ *   first use and never touched by the caller afterwards; ONE PER STREAM that may have an lx_gemm_bf16_ws call in flight
+ *   (the library keeps no scratch of its own, so launches on different streams never share slots or flags).
+ *   NULL / 0 => exactly lx_gemm_bf16.
+ * LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144) | 2 whenever possible (tests).
+ * The pair plan needs both workgroups of a tile resident at once (<= 256 workgroups on a 256-CU device, checked); if other work
+ * holds CUs for longer than the bounded wait (~1 s), the waiting workgroup raises the workspace's error word and finishes with
+ * an invalid tile instead of hanging or trapping: lx_gemm_workspace_status() (synchronises `stream`) then returns
+ * LX_ERR_LAUNCH once, resets the workspace, and the caller should recompute without the workspace. */
+size_t lx_gemm_workspace_bytes(void);
+int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* workspace, size_t ws_bytes, void* stream);
+int lx_gemm_workspace_status(void* workspace, void* stream);
 
 /* LoRA down-projection (peft lora_A): T_s[M, R] (fp32, ldt) = X[M, K_s] (bf16, ldx) . Adown[R, K_s]^T (bf16), R <= 16,
  * for n_split contiguous K slices s (n_split = 1: the whole K); slab s is written at T + s*split_stride. Splitting K

@@ -71,7 +71,7 @@ def inference_single(model, item, condition_type, position_delta, target_size, u
                    prompt_embeds=item["prompt_embeds"], pooled_prompt_embeds=item["pooled"], output_type="latent",
                    model_config=model.model_config, default_lora=True, additional_condition1=sig["eeg"],
                    additional_condition2=sig["fnirs"], additional_condition3=sig["ppg"], additional_condition4=sig["motion"],
-                   use_brain_condition=sig["eeg"] is not None or sig["fnirs"] is not None, fuse_flag=False)
+                   use_brain_condition=sig["eeg"] is not None or sig["fnirs"] is not None, fuse_flag=False)      # inference.py:99-117
     return out.images[0]
 
 

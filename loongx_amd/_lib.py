@@ -56,6 +56,10 @@ _SIGS = {
     "lx_last_error": (C.c_char_p, []),
     "lx_device_arch": (C.c_int, [C.c_char_p, _Z]),
     "lx_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _I, _P]),
+    "lx_gemm_reload_env": (None, []),
+    "lx_gemm_workspace_bytes": (_Z, []),
+    "lx_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmDesc), _I, _P, _Z, _P]),
+    "lx_gemm_workspace_status": (C.c_int, [_P, _P]),
     "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -592,8 +592,9 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_mixed_kernel(const GemmArgs 
 //   Hand-off: stores, s_waitcnt vmcnt(0), barrier, flag[p] = 1; then wait for flag[p ^ 8] and clear it (each flag has one writer
 // and one reader, and ends the launch at 0: hipGraph replays need no reset). The data path assumes nothing about placement (sc1
 // stores AND sc1 loads: correct across XCDs; p ^ 8 is only the likely-same-L2 choice). Both partners wait for each other, so
-// both must get a CU: a launch has at most 256 workgroups of one per CU on a 256-CU device (checked on the host) and the stream
-// is in order, so all of them are resident together; the poll is bounded and traps instead of hanging if that ever fails.
+// both must get a CU: a launch has at most 256 workgroups of one per CU on a 256-CU device (checked on the host), so all of them
+// are resident together unless something else holds CUs; the poll is bounded and raises the workspace's error word (the host
+// reads it with lx_gemm_workspace_status) instead of hanging or trapping if a partner does not show up in time.
 constexpr int PAIR_SLOT_FLOATS = 8 * 16 * 64 * 4;   // eight waves x 16 x f32x4 per lane = 128 KiB
 constexpr int PAIR_AUX_SC1 = 16;                    // gfx940+ buffer cache policy: sc1 (agent scope)
 constexpr int PAIR_MAX_WG = 256;
@@ -672,14 +673,17 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(flags + pid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // bounded: ~1-2 s of polling (each iteration is one L2 round trip), against microseconds of expected wait. A partner that never shows up (a device whose CUs
-    // are held by something else for good) becomes a launch failure the host sees, not a hung GPU.
+    // bounded: ~1-2 s of polling (each iteration is one L2 round trip), against microseconds of expected wait. A partner that never
+    // shows up (a device whose CUs are held by something else for good) sets the workspace's error word and lets this workgroup
+    // finish with an invalid tile: the host sees it in lx_gemm_workspace_status, the context survives, nothing hangs.
     int spins = 0;
+    bool ok = true;
     while (__hip_atomic_load(flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 20)) __builtin_trap();
+      if (++spins > (1 << 20)) { ok = false; break; }
     }
-    __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok) __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(flags + PAIR_MAX_WG, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // error word: lx_gemm_workspace_status
   }
   __syncthreads();
   if (half == 0) recv(std::integral_constant<int, 0>{});
@@ -696,37 +700,20 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
 // per-64-deep-K-tile slope at full occupancy.
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
-
-
-// ---- pair-kernel scratch: one accumulator-exchange slot + flag per workgroup, per device ------------------------------------
-// Shared by every stream of the device: lx_gemm_bf16 launches that may run CONCURRENTLY on one device (different streams, no
-// dependency between them) must not both take the pair path -- set LX_GEMM_PAIR=0 in such a process. The DiT step is one
-// in-order stream (or its captured graph), where launches cannot overlap.
-namespace {
-struct PairScratch { int device; float* slots; int* flags; };
-PairScratch g_pair[16];
-int g_pair_n = 0;
-
-// Returns the scratch of the current device, allocating it on first use; nullptr if it cannot be allocated now (the stream is
-// being captured into a graph, table full, out of memory) -- the caller then uses the one-tile-per-workgroup kernels.
-const PairScratch* pair_scratch(hipStream_t s) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  for (int i = 0; i < g_pair_n; ++i)
-    if (g_pair[i].device == dev) return &g_pair[i];
-  if (g_pair_n == 16) return nullptr;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-  PairScratch e{dev, nullptr, nullptr};
-  if (hipMalloc((void**)&e.slots, (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (hipMalloc((void**)&e.flags, PAIR_MAX_WG * sizeof(int)) != hipSuccess || hipMemset(e.flags, 0, PAIR_MAX_WG * sizeof(int)) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(e.slots);
-    return nullptr;
-  }
-  g_pair[g_pair_n] = e;
-  return &g_pair[g_pair_n++];
+// runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid; };
+static GemmEnv read_gemm_env() {
+  return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1)};
 }
+static GemmEnv g_gemm_env = read_gemm_env();
+static const GemmEnv& gemm_env() { return g_gemm_env; }
+extern "C" void lx_gemm_reload_env(void) { g_gemm_env = read_gemm_env(); }
+
+// ---- pair-kernel scratch: one accumulator-exchange slot + flag per workgroup, in a CALLER-PROVIDED workspace ------------------
+// (lx_gemm_bf16_ws): [PAIR_MAX_WG slots of 128 KiB | PAIR_MAX_WG flags | error word]. The library keeps no scratch of its own:
+// whoever owns a stream owns its workspace, so launches on different streams never share slots or flags.
+namespace {
+constexpr size_t PAIR_WS_BYTES = (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float) + (PAIR_MAX_WG + 64) * sizeof(int);
 
 int device_cus() {
   static int n = -1;
@@ -768,7 +755,29 @@ static void plan_add(GemmArgs& a, const lx_gemm_desc& p, int m_base, int bm) {
   for (int i = a.n + 1; i <= MAX_SUB; ++i) a.tile_start[i] = a.tile_start[a.n];
 }
 
-extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
+extern "C" size_t lx_gemm_workspace_bytes(void) { return PAIR_WS_BYTES; }
+
+extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
+  LX_CHECK_ARG(workspace, "lx_gemm_workspace_status: NULL workspace");
+  int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
+  int v = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(&v, err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    lx_set_error("lx_gemm_workspace_status: reading the error word failed: %s", hipGetErrorString(hipGetLastError()));
+    return LX_ERR_LAUNCH;
+  }
+  if (v == 0) return LX_OK;
+  // a timed-out pair leaves flags behind: reset all of them with the error word so the workspace is usable again
+  (void)hipMemsetAsync((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
+  (void)hipStreamSynchronize(s);
+  lx_set_error("lx_gemm_bf16_ws: a split-K pair workgroup timed out waiting for its partner (CUs held by other work?); the results "
+               "of that launch are invalid. Re-run with the workspace omitted (lx_gemm_bf16) or LX_GEMM_PAIR=0");
+  return LX_ERR_LAUNCH;
+}
+
+extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) { return lx_gemm_bf16_ws(problems, n, nullptr, 0, stream); }
+
+extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* workspace, size_t ws_bytes, void* stream) {
   LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
   long t256 = 0, t128 = 0;
   int kmax = 0;
@@ -796,26 +805,30 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
     kmax = p.K > kmax ? p.K : kmax;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int NCU = 256;
-  const int forced = env_int("LX_GEMM_BM", 0);      // 256 | 128 | 0 = plan
+  const int NCU = device_cus() > 0 ? device_cus() : 256;   // one workgroup per CU: a launch runs in rounds of NCU tiles
+  const GemmEnv& env = gemm_env();
+  const int forced = env.bm;      // 256 | 128 | 0 = plan
   // Two workgroups per 256-row tile (lx_gemm_pair_kernel) when there are at most 128 such tiles: needs one K for the whole
   // group, a 256-CU device and the scratch slots. LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144:
   // the swap costs ~6 us, the better loop saves 0.12 us per K tile) | 2 whenever possible (tests).
   {
-    const int pair_mode = env_int("LX_GEMM_PAIR", 1);
+    const int pair_mode = env.pair;
     bool uniform_k = true;
     for (int i = 1; i < n; ++i) uniform_k = uniform_k && problems[i].K == problems[0].K;
     const int per_xcd = (int)(t256 / 8 + (t256 % 8 ? 1 : 0));
-    const bool fits = per_xcd * 16 <= NCU && kmax / BK >= 2;
-    const bool pays = pair_mode == 2 || kmax / BK >= env_int("LX_GEMM_PAIR_MIN_KT", 96);
-    if (pair_mode && forced == 0 && uniform_k && fits && pays && device_cus() == NCU) {
-      if (const PairScratch* sc = pair_scratch(s)) {
+    const bool fits = per_xcd * 16 <= PAIR_MAX_WG && kmax / BK >= 2;
+    const bool pays = pair_mode == 2 || kmax / BK >= env.pair_min_kt;
+    if (workspace) LX_CHECK_ARG(ws_bytes >= PAIR_WS_BYTES && ((uintptr_t)workspace & 255) == 0, "lx_gemm_bf16_ws: workspace needs %zu bytes, 256-byte aligned", PAIR_WS_BYTES);
+    if (workspace && pair_mode && forced == 0 && uniform_k && fits && pays && NCU == PAIR_MAX_WG) {
+      {
+        float* slots = (float*)workspace;
+        int* flags = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float));
         GemmArgs all;
         all.n = 0;
         all.tile_start[0] = 0;
         for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
         for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
-        hipLaunchKernelGGL(lx_gemm_pair_kernel, dim3(per_xcd * 16), dim3(NTHREADS), 0, s, all, sc->slots, sc->flags);
+        hipLaunchKernelGGL(lx_gemm_pair_kernel, dim3(per_xcd * 16), dim3(NTHREADS), 0, s, all, slots, flags);
         LX_LAUNCH_CHECK("lx_gemm_bf16");
         return LX_OK;
       }
@@ -856,7 +869,7 @@ extern "C" int lx_gemm_bf16(const lx_gemm_desc* problems, int n, void* stream) {
   }
   int choice = forced == 256 ? 0 : forced == 128 ? 1 : (c_c < c_a && c_c < c_b) ? 2 : (c_b < c_a ? 1 : 0);
   if (choice == 2) {
-    static const bool one_grid = env_int("LX_GEMM_MIXED_ONE_GRID", 1) != 0;
+    const bool one_grid = env.one_grid != 0;
     if (one_grid && big.n > 0 && tail.n > 0) {
       const int n_big = big.tile_start[big.n], n_big_pad = (n_big + 7) & ~7;
       hipLaunchKernelGGL(lx_gemm_mixed_kernel, dim3(n_big_pad + tail.tile_start[tail.n]), dim3(NTHREADS), 0, s, big, tail, n_big_pad);

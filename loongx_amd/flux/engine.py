@@ -47,6 +47,12 @@ class DiTEngine:
         self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
         self.model_config: Dict = {}
         self.c_factor: Optional[float] = None
+        # Split-K pair plan of the GEMM (lx_gemm_bf16_ws): needs a caller-owned workspace, one per stream -- this engine owns one
+        # and runs on one stream at a time. LX_PAIR_PLAN=0 (or engine.pair_plan = False before the first step) gives launch plans
+        # that do not depend on the batch size, i.e. data-parallel shards equal the single-GPU batch bit for bit.
+        self.pair_plan = os.environ.get("LX_PAIR_PLAN", "1") != "0"
+        self.lora_scale = 1.0            # lora_controller.enable_lora / set_lora_scale drive this (0 = adapters off everywhere)
+        self._gemm_ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------------------------ workspace
     def setup(self, B: int, T: int, N: int, C: int) -> None:
@@ -91,6 +97,53 @@ class DiTEngine:
         self.shape = (B, T, N, C)
         self.cond_ready = False
 
+    def set_lora_scale(self, s: float) -> None:
+        """Multiplier on every adapter term (reference lora_controller.py: scale_layer). Changes what the captured step graphs
+        and the cached condition-stream modulations contain, so both are dropped."""
+        s = float(s)
+        if s != self.lora_scale:
+            self.lora_scale = s
+            self.graphs = {}
+            self.cond_ready = False
+            self.sched = None
+
+    def gemm_ws(self) -> Optional[torch.Tensor]:
+        if not self.pair_plan:
+            return None
+        if self._gemm_ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None                      # never allocate inside a capture; the eager warm-up pass allocates it
+            self._gemm_ws = ops.gemm_workspace(self.device)
+        return self._gemm_ws
+
+    def check_status(self, sync: bool = True) -> None:
+        """Raises LxError if a split-K pair workgroup timed out (the results of that step are invalid); the pair plan is then
+        switched off for this engine, so a retry takes the plain plans. sync=True drains the stream and checks now. sync=False
+        costs no synchronisation: it looks at the error word copied to pinned host memory by the previous call (if that copy has
+        landed) and enqueues the next copy -- generate() does this once per image, so a time-out surfaces at most one image late."""
+        if self._gemm_ws is None:
+            return
+        if sync:
+            try:
+                ops.gemm_workspace_status(self._gemm_ws)
+            except Exception:
+                self.pair_plan, self.graphs, self._err_event = False, {}, None
+                raise
+            return
+        n = self._gemm_ws.numel()
+        if getattr(self, "_err_host", None) is None:
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._err_event = None
+        if self._err_event is not None and self._err_event.query():
+            self._err_event = None
+            if int(self._err_host[0]) != 0:
+                self.check_status(sync=True)          # resets the workspace and raises
+        if self._err_event is None:
+            word = self._gemm_ws[n - 64 * 4: n - 63 * 4].view(torch.int32)      # [slots | 256 flags | error word + pad]
+            self._err_host.copy_(word, non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
+
     # row views ---------------------------------------------------------------------------------------
     def rows(self, buf: torch.Tensor, stream: str) -> torch.Tensor:
         if stream == "txt":
@@ -119,12 +172,14 @@ class DiTEngine:
         w = self.w
         if not lora_only:
             ops.linear_skinny(temb, w.t["mod.w"], w.t["mod.b"], out, act_in=1)
-        if lora and "mod.lora_down" in w.t:
+        if lora and "mod.lora_down" in w.t and self.lora_scale != 0.0:
             cfg, r, D = self.cfg, self.cfg.lora_r, self.cfg.inner_dim
             nb = cfg.num_layers + cfg.num_single_layers
             rows = temb.shape[0]
             tm = self.tmod[:, : nb * r] if rows == self.B else torch.zeros(rows, nb * r, dtype=torch.float32, device=self.device)
             ops.linear_skinny(temb, w.t["mod.lora_down"], None, tm, act_in=1)
+            if self.lora_scale != 1.0:
+                tm.mul_(self.lora_scale)
             for idx in range(nb):
                 if idx < cfg.num_layers:
                     base, width = cfg.mod_base_double(idx), 6 * D
@@ -200,6 +255,7 @@ class DiTEngine:
         N = img_ids.shape[0]
         C = 0 if condition_latents is None else condition_latents.shape[1]
         self.setup(B, T, N, C)
+        self.gemm_ws()                   # allocated here, outside any stream capture
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))
@@ -213,11 +269,13 @@ class DiTEngine:
         # x_embedder(condition_latents) with LoRA active -> cached condition rows
         if C:
             cl = condition_latents.to(device=dev, dtype=bf16).reshape(B * C, -1).contiguous()
-            lo = w.lora.get("x_embedder")
+            lo = w.lora.get("x_embedder") if self.lora_scale != 0.0 else None
             tl = None
             if lo is not None:
                 tl = self.TL[: B * C, : cfg.lora_r]
                 ops.lora_down(cl, lo.down, tl)
+                if self.lora_scale != 1.0:
+                    tl.mul_(self.lora_scale)
             ops.gemm([ops.gemm_desc(cl, w.t["x_embedder.w"], self.X_cond_init, bias=w.t["x_embedder.b"], epilogue=LX_EPI_STORE_F32,
                                     lora_t=tl, lora_up=lo.up if lo is not None else None)])
         # RoPE tables: [text; image] and condition (transformer.py:130-134)
@@ -267,11 +325,13 @@ class DiTEngine:
 
     def _lora_t(self, A: torch.Tensor, name: str, include_txt: bool = False):
         lo = self.w.lora.get(name)
-        if lo is None or (self.C == 0 and not self.latent_lora):
+        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0:
             return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
         ops.lora_down(A[r0:r0 + n], lo.down, t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
+        if self.lora_scale != 1.0:
+            self.TLs[:, r0:r0 + n, : lo.down.shape[0]].mul_(self.lora_scale)
         return lo, r0
 
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
@@ -307,7 +367,7 @@ class DiTEngine:
                     kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up[:W.shape[0]], lora_mod_cols=lora_mod_cols,
                               lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, W, c, **kw))
-        ops.gemm(probs)
+        ops.gemm(probs, self.gemm_ws())
 
     def _attention(self, wq, wk, wq_txt, wk_txt) -> None:
         cfg = self.cfg
@@ -361,7 +421,7 @@ class DiTEngine:
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
         if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
-            lo = w.lora.get(p + ".out")
+            lo = w.lora.get(p + ".out") if self.lora_scale != 0.0 else None
             a = self.rows(Ya, "cond")
             kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up, lora_nsplit=self.TL_SPLIT,
                       lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
@@ -396,11 +456,13 @@ class DiTEngine:
         """x_embedder(latents), reset text/condition rows, temb(t) and every image/text modulation vector."""
         w, cfg = self.w, self.cfg
         ops.convert(self.lat16, latents.reshape(self.B * self.N, -1).contiguous())
-        lo = w.lora.get("x_embedder") if self.latent_lora else None
+        lo = w.lora.get("x_embedder") if (self.latent_lora and self.lora_scale != 0.0) else None
         tl = None
         if lo is not None:
             tl = self.TL[: self.B * self.N, : cfg.lora_r]
             ops.lora_down(self.lat16, lo.down, tl)
+            if self.lora_scale != 1.0:
+                tl.mul_(self.lora_scale)
         ops.gemm([ops.gemm_desc(self.lat16, w.t["x_embedder.w"], self.rows(self.X, "img"), bias=w.t["x_embedder.b"],
                                 epilogue=LX_EPI_STORE_F32, lora_t=tl, lora_up=lo.up if lo is not None else None)])
         self.rows(self.X, "txt").copy_(self.X_txt_init)
@@ -454,7 +516,7 @@ class DiTEngine:
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre)
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan)
         g = self.graphs.get(key)
         if g is None:
             if not self._warmed:                                  # lazy code-object loads must not happen inside capture
@@ -498,15 +560,18 @@ class DiTEngine:
                 continue
             vec = vec.to(device=self.device, dtype=torch.float32).contiguous()
             ops.linear_skinny(vec, w.t["mod.w"][base:base + width], w.t["mod.b"][base:base + width], out[:, base:], act_in=1)
-            if lora and "mod.lora_down" in w.t:
+            if lora and "mod.lora_down" in w.t and self.lora_scale != 0.0:
                 tm = self.tmod[:, :r]
                 ops.linear_skinny(vec, w.t["mod.lora_down"][li * r:(li + 1) * r], None, tm, act_in=1)
+                if self.lora_scale != 1.0:
+                    tm.mul_(self.lora_scale)
                 ops.linear_f32(tm, w.t[f"mod.lora_up.{li}"], None, out[:, base:], M=self.B, N=lw, K=r, ldx=tm.stride(0),
                                ldy=out.stride(0), accumulate=True)
 
     def configure(self, B, T, N, C, model_config=None, c_factor=None, rope_main=None, rope_cond=None) -> None:
         """Shape + config + RoPE tables without the prompt/condition embedders (block-level use)."""
         self.setup(B, T, N, C)
+        self.gemm_ws()
         self.graphs = {}
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor

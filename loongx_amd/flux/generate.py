@@ -3,8 +3,10 @@
 
 Differences from the reference, all deliberate and recorded in DESIGN.md:
   Q1  brain signals reach the CS3 encoders as [B,C,L] (what OminiModel.step does, model.py:659-673), not flatten(1);
-  Q2  with fuse_flag=False each side replaces its own embedding (EEG[+PPG] -> prompt_embeds, fNIRS[+Motion] -> pooled),
-      so EEG-only conditioning (BASELINE config 2) takes effect; `brain_replace="both"` restores the literal rule;
+  Q2  with fuse_flag=False the reference replaces the text embeddings only when BOTH brain sides exist (generate.py:252-255);
+      that literal rule is the default here (`brain_replace="both"`). `brain_replace="per_stream"` is the opt-in extension that
+      lets each side replace its own embedding (EEG[+PPG] -> prompt_embeds, fNIRS[+Motion] -> pooled), which is what makes
+      EEG-only conditioning (BASELINE configs[1]) take effect; bench.py / inference.py --synthetic ask for it explicitly;
   Q5  signals may carry a batch dimension ([B,C,L]); a [C,L] tensor is treated as batch 1 like the reference.
 """
 from __future__ import annotations
@@ -67,9 +69,15 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
              additional_condition2: Optional[torch.Tensor] = None,   # fNIRS
              additional_condition3: Optional[torch.Tensor] = None,   # PPG
              additional_condition4: Optional[torch.Tensor] = None,   # Motion
-             use_brain_condition: bool = True, fuse_flag: bool = True, brain_replace: str = "per_stream", **params):
+             use_brain_condition: bool = True, fuse_flag: bool = True, brain_replace: str = "both", **params):
     model_config = model_config or get_config(config_path).get("model", {})
     self = pipeline
+    if brain_replace not in ("both", "per_stream"):
+        raise ValueError(f"brain_replace must be 'both' (the reference rule) or 'per_stream', got {brain_replace!r}")
+    # the step-invariant conditioning cache of the transformer lives for the steps of ONE image: every tensor made below is
+    # freed on return and its address may come back with different content on the next call
+    if hasattr(pipeline.transformer, "invalidate_conditioning"):
+        pipeline.transformer.invalidate_conditioning()
     if condition_scale != 1:
         pipeline.transformer.c_factor = float(condition_scale)
     (prompt, prompt_2, height, width, num_inference_steps, timesteps, guidance_scale, num_images_per_prompt, generator, latents,
@@ -203,6 +211,9 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
     self.maybe_free_model_hooks()
     if condition_scale != 1:
         pipeline.transformer.c_factor = None
+    if hasattr(pipeline.transformer, "invalidate_conditioning"):
+        pipeline.transformer.invalidate_conditioning()
+        pipeline.transformer.engine.check_status(sync=False)      # split-K pair time-outs surface here, at most one image late
     if not return_dict:
         return (image,)
     return FluxPipelineOutput(images=image)

@@ -121,9 +121,8 @@ class LxFluxPipeline:
         eng = self.transformer.engine
         n = install_lora(eng.w, sd, lora_scale=lora_scale)
         eng.graphs = {}
-        eng.cond_ready = False
-        eng.sched = None
-        self.transformer._cond_key = None
+        eng.shape = None               # the adapter rank sizes the modulation scratch: re-run setup()
+        self.transformer.invalidate_conditioning()
         return n
 
     def set_adapters(self, *a, **k):

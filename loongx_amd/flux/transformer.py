@@ -50,6 +50,13 @@ class LxFluxTransformer:
         self.gradient_checkpointing = False
         self.c_factor: Optional[float] = None      # generate(condition_scale != 1) sets this (generate.py:90-94)
         self._cond_key = None
+        self._cond_refs = None                      # strong references to the tensors _cond_key was computed from
+
+    def invalidate_conditioning(self) -> None:
+        """Forget the step-invariant conditioning cache (generate() calls this at the start and end of every image)."""
+        self._cond_key = self._cond_refs = None
+        self.engine.cond_ready = False
+        self.engine.sched = None
 
     @classmethod
     def from_state_dict(cls, sd, cfg: FluxConfig, device="cuda", lora_scale: float = 1.0, prefix: str = ""):
@@ -73,6 +80,11 @@ class LxFluxTransformer:
 
 
 def _tkey(t: Optional[torch.Tensor]):
+    """Identity of a conditioning tensor for the step-invariant cache. Identity (address, shape, dtype, version) is only a valid
+    stand-in for content while the tensor is ALIVE -- a freed tensor's address is handed to the next allocation of that size --
+    so the cache also keeps strong references to every keyed tensor (LxFluxTransformer._cond_refs), and generate() drops the
+    cache at the start and end of every image. What identity cannot see is an in-place write that bypasses torch's version
+    counter (a raw kernel through the C ABI): callers that do that between calls must call invalidate_conditioning()."""
     return None if t is None else (t.data_ptr(), tuple(t.shape), t.dtype, t._version)
 
 
@@ -103,6 +115,7 @@ def tranformer_forward(transformer: LxFluxTransformer, condition_latents: torch.
                              condition_latents if use_condition else None, condition_ids if use_condition else None,
                              c_t=float(c_t), model_config=mc, c_factor=transformer.c_factor)
         transformer._cond_key = key
+        transformer._cond_refs = (encoder_hidden_states, pooled_projections, guidance, txt_ids, img_ids, condition_latents, condition_ids)
     # Extension (the reference swallows unknown kwargs): lx_schedule=(i, timesteps) tells the engine that `timestep` is entry
     # i of a known schedule (same units as `timestep`), so all steps' modulation vectors come from one weight pass.
     step_index = None

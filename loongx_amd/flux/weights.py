@@ -92,6 +92,24 @@ class PackedWeights:
         return n
 
 
+def _check_lora_ranks(cfg: FluxConfig, ranks: Dict[str, int], group_sizes: Dict[str, int]) -> None:
+    """One rank r for every adapter of a checkpoint, and r * (modules fused into one GEMM) <= 16: lx_lora_down produces at most
+    16 columns per launch (the TL slabs of the engine are 16 columns wide) and the fused single-block GEMM evaluates four
+    adapters (to_k, to_v, to_q, proj_mlp) from one slab. Sets cfg.lora_r, which sizes the engine's modulation scratch."""
+    if not ranks:
+        return
+    rs = sorted(set(ranks.values()))
+    if len(rs) != 1:
+        bad = {k: v for k, v in ranks.items() if v != rs[0]}
+        raise ValueError(f"LoRA adapters must share one rank; found ranks {rs} (e.g. {list(bad.items())[:3]})")
+    r = rs[0]
+    for name, n in group_sizes.items():
+        if n * r > 16:
+            raise ValueError(f"LoRA rank {r} is too large for the fused GEMM '{name}' ({n} adapters share one down-projection "
+                             f"launch: needs {n} * r <= 16, i.e. r <= {16 // n})")
+    cfg.lora_r = r
+
+
 # --------------------------------------------------------------------------------------------------------------
 def _sd_get(sd, name: str, what: str) -> Optional[torch.Tensor]:
     for k in (f"{name}.{what}", f"{name}.base_layer.{what}"):
@@ -118,6 +136,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     pw = PackedWeights(cfg)
     D = cfg.inner_dim
+    ranks: Dict[str, int] = {}
+    groups: Dict[str, int] = {}
 
     def W(names: List[str]) -> torch.Tensor:
         ws = []
@@ -141,6 +161,9 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
             return None
         if any(p is None for p in parts):
             raise ValueError(f"LoRA adapters must cover all of {names} or none")
+        for n, p in zip(names, parts):
+            ranks[n] = p[0].shape[0]
+        groups[names[0]] = len(names)
         down = torch.cat([p[0].float() for p in parts], 0).to(device=device, dtype=torch.bfloat16).contiguous()
         up = torch.cat([p[1].float() * lora_scale for p in parts], 0).to(device=device, dtype=torch.float32).contiguous()
         return Lora(down, up)
@@ -184,6 +207,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
     if any(m is not None for m in mod_lora):
         if any(m is None for m in mod_lora):
             raise ValueError("LoRA must cover every norm1.linear / norm.linear or none")
+        for idx, m in enumerate(mod_lora):
+            ranks[f"mod.{idx}"] = m[0].shape[0]
         pw.t["mod.lora_down"] = torch.cat([m[0].float() for m in mod_lora], 0).to(device=device, dtype=torch.bfloat16).contiguous()
         for idx, m in enumerate(mod_lora):
             pw.t[f"mod.lora_up.{idx}"] = (m[1].float() * lora_scale).to(device).contiguous()
@@ -194,6 +219,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
     for e in emb:
         for l in ("linear_1", "linear_2"):
             put(f"tte.{e}.{l}", [f"time_text_embed.{e}.{l}"], [D])
+    _check_lora_ranks(cfg, ranks, groups)
     return pw
 
 
@@ -245,12 +271,17 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
     fused, mods = lora_layout(pw.cfg)
     n = 0
     new_lora = {}
+    ranks: Dict[str, int] = {}
+    groups: Dict[str, int] = {}
     for fname, names in fused:
         parts = [get(m) for m in names]
         if all(q is None for q in parts):
             continue
         if any(q is None for q in parts):
             raise ValueError(f"LoRA adapters must cover all of {names} or none")
+        for m, q in zip(names, parts):
+            ranks[m] = q[0].shape[0]
+        groups[fname] = len(names)
         n += len(parts)
         new_lora[fname] = Lora(torch.cat([q[0] for q in parts], 0).to(device=dev, dtype=torch.bfloat16).contiguous(),
                                torch.cat([q[1] for q in parts], 0).to(device=dev, dtype=torch.float32).contiguous())
@@ -260,6 +291,8 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
         if any(q is None for q in mparts):
             raise ValueError("LoRA must cover every norm1.linear / norm.linear or none")
         n += len(mparts)
+        for m, q in zip(mods, mparts):
+            ranks[m] = q[0].shape[0]
         new_t["mod.lora_down"] = torch.cat([q[0] for q in mparts], 0).to(device=dev, dtype=torch.bfloat16).contiguous()
         for idx, q in enumerate(mparts):
             new_t[f"mod.lora_up.{idx}"] = q[1].to(dev).contiguous()
@@ -268,6 +301,7 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
         raise KeyError(f"LoRA keys that match no module of this transformer: {unknown[:4]}{' ...' if len(unknown) > 4 else ''}")
     if n == 0:
         raise ValueError("no LoRA adapter found in the state dict")
+    _check_lora_ranks(pw.cfg, ranks, groups)
     pw.lora.clear()
     pw.lora.update(new_lora)
     for k in [k for k in pw.t if k.startswith("mod.lora_")]:

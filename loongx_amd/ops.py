@@ -110,9 +110,23 @@ class LaunchTimer:
 TIMER: Optional[LaunchTimer] = None
 
 
-def gemm(problems: Sequence[GemmDesc]) -> None:
+def gemm_workspace(device) -> torch.Tensor:
+    """Zero-filled scratch for lx_gemm_bf16_ws (split-K pair plan): one per stream / engine, owned by the caller."""
+    return torch.zeros(lib.lx_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def gemm_workspace_status(ws: torch.Tensor) -> None:
+    """Synchronises the current stream; raises LxError if a pair-plan workgroup timed out since the last check."""
+    check(lib.lx_gemm_workspace_status(ws.data_ptr(), _stream()), "lx_gemm_workspace_status")
+
+
+def gemm(problems: Sequence[GemmDesc], workspace: Optional[torch.Tensor] = None) -> None:
     n = len(problems)
     arr = (GemmDesc * n)(*problems)
+    if workspace is not None:
+        call = lambda: check(lib.lx_gemm_bf16_ws(arr, n, workspace.data_ptr(), workspace.numel(), _stream()), "lx_gemm_bf16_ws")
+    else:
+        call = lambda: check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
     if TIMER is not None and TIMER.active:
         def _bytes(p):   # each operand read once, the output written once (the fp32 residual epilogue also reads it)
             epi = p.epilogue & 0xff
@@ -120,10 +134,10 @@ def gemm(problems: Sequence[GemmDesc]) -> None:
             return 2.0 * p.M * p.K + 2.0 * p.N * p.K + float(out_b) * p.M * p.N
         s, e = TIMER.bracket("gemm", sum(2.0 * p.M * p.N * p.K for p in problems), sum(_bytes(p) for p in problems))
         s.record()
-        check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
+        call()
         e.record()
         return
-    check(lib.lx_gemm_bf16(arr, n, _stream()), "lx_gemm_bf16")
+    call()
 
 
 def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor, n_split: int = 1, split_stride: int = 0) -> None:

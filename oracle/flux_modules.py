@@ -235,7 +235,7 @@ def rope_tables(ids: torch.Tensor, axes_dim: Sequence[int] = (16, 56, 56), theta
     pos = ids.float()
     cos_out, sin_out = [], []
     for a, d in enumerate(axes_dim):
-        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=pos.device)[: d // 2] / d))
         f = torch.outer(pos[:, a].to(torch.float64), freqs)
         cos_out.append(f.cos().repeat_interleave(2, dim=1).float())
         sin_out.append(f.sin().repeat_interleave(2, dim=1).float())

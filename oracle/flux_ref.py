@@ -45,18 +45,18 @@ def _heads(x, h):
     return x.view(b, l, h, d // h).transpose(1, 2)
 
 
-def attention_mask(n_q: int, n_cond: int, model_config: Dict[str, Any], c_factor, dtype):
+def attention_mask(n_q: int, n_cond: int, model_config: Dict[str, Any], c_factor, dtype, device=None):
     """block.py:106-128 -> additive/bool mask or None."""
     mask = None
     if not model_config.get("union_cond_attn", True):
-        mask = torch.ones(n_q, n_q, dtype=torch.bool)
+        mask = torch.ones(n_q, n_q, dtype=torch.bool, device=device)
         mask[-n_cond:, :-n_cond] = False
         mask[:-n_cond, -n_cond:] = False
     elif model_config.get("independent_condition", False):
-        mask = torch.ones(n_q, n_q, dtype=torch.bool)
+        mask = torch.ones(n_q, n_q, dtype=torch.bool, device=device)
         mask[-n_cond:, :-n_cond] = False
     if c_factor is not None:
-        mask = torch.zeros(n_q, n_q, dtype=dtype)
+        mask = torch.zeros(n_q, n_q, dtype=dtype, device=device)
         bias = math.log(float(c_factor))
         mask[-n_cond:, :-n_cond] = bias
         mask[:-n_cond, -n_cond:] = bias
@@ -92,7 +92,7 @@ def joint_attention(attn, hid, enc, cond, rope_main, rope_cond, model_config) ->
     c_factor = getattr(attn, "c_factor", None)
     if c_factor is not None:
         c_factor = float(torch.as_tensor(c_factor).flatten()[0])
-    mask = attention_mask(q.shape[2], n_cond, model_config, c_factor, q.dtype) if n_cond else None
+    mask = attention_mask(q.shape[2], n_cond, model_config, c_factor, q.dtype, q.device) if n_cond else None
     o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=False)
     b = o.shape[0]
     o = o.transpose(1, 2).reshape(b, -1, H * o.shape[-1]).to(q.dtype)
@@ -240,7 +240,7 @@ def denoise_loop(transformer, scheduler, latents, prompt_embeds, pooled, txt_ids
         ts = t.expand(latents.shape[0]).to(latents.dtype)
         guidance = None
         if transformer.config.guidance_embeds:
-            guidance = torch.tensor([guidance_scale]).expand(latents.shape[0])
+            guidance = torch.tensor([guidance_scale], device=latents.device).expand(latents.shape[0])
         v = tranformer_forward(transformer, condition_latents, condition_ids, None, model_config,
                                hidden_states=latents, encoder_hidden_states=prompt_embeds,
                                pooled_projections=pooled, timestep=ts / 1000, img_ids=img_ids,

@@ -1,0 +1,131 @@
+"""Full-depth parity harness: the MI355X engine against the fp32 oracle, same weights, same inputs, same GPU.
+
+TEST INFRASTRUCTURE (imported by tests/ and by bench.py's `parity_check` leg only, as the checker -- never as the thing
+measured or shipped).  The oracle is `oracle/flux_ref.py` (the restatement of the reference's src/flux/transformer.py:47-252
+and src/flux/block.py, pinned to reference-generated goldens) evaluated in fp32 by torch-ROCm on the SAME GPU, which is what
+makes 57 full-width blocks x 28 steps affordable (37.7 TFLOP per forward: ~0.5 s on the fp32 matrix path, hours on host cores).
+
+What is compared (last row):
+  * teacher-forced: at every step i of the oracle's own denoise trajectory, the engine's `noise_pred` for the ORACLE's
+    latents x_i against the oracle's (isolates the error of one forward at full depth);
+  * free-running: the product's `generate()` from the same start -> final latents rel-err and cosine (error as it compounds
+    over 28 Euler steps).
+Weights: synthetic N(0, 0.02^2) as BASELINE.md section 4; the base weights are rounded to bf16-representable values first
+(`bf16_exact_base=True`), which is what FLUX.1-dev checkpoints hold (the reference upcasts a bf16 checkpoint to its
+configured dtype, train/config/seed_512.yaml:2), so both sides compute with the SAME weights and the number measures
+arithmetic, not weight quantisation. LoRA matrices stay fp32 on the oracle side.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import flux_modules as fm
+from . import flux_ref as fr
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def build_pair(device, num_layers: int = 19, num_single_layers: int = 38, heads: int = 24, seed: int = 0, std: float = 0.02,
+               bf16_exact_base: bool = True, joint_dim: int = 4096, pooled_dim: int = 768, precise: bool = False):
+    """-> (oracle FluxTransformer2DModel on `device`, LxFluxTransformer packed from ITS state dict)."""
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
+    with torch.device(device):
+        tr = fm.FluxTransformer2DModel(num_layers=num_layers, num_single_layers=num_single_layers, heads=heads, head_dim=128,
+                                       in_channels=64, joint_dim=joint_dim, pooled_dim=pooled_dim, guidance_embeds=True, lora=True)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in tr.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, std, generator=g)
+                if bf16_exact_base and ".lora_" not in name:
+                    p.copy_(p.to(torch.bfloat16).float())
+            elif name.endswith("bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)
+    tr.eval()
+    cfg = FluxConfig(num_layers=num_layers, num_single_layers=num_single_layers, num_attention_heads=heads, in_channels=64,
+                     joint_attention_dim=joint_dim, pooled_projection_dim=pooled_dim, guidance_embeds=True)
+    kw = dict(precise=True) if precise else {}
+    lx = LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, device, **kw)
+    return tr, lx
+
+
+@torch.no_grad()
+def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, num_single_layers: int = 38, hw: int = 32,
+                      n_txt: int = 512, seed: int = 0, precise: bool = False, model_config: Optional[Dict] = None,
+                      every: int = 1) -> Dict:
+    """Runs both sides at batch 1 on identical synthetic inputs (BASELINE.md section 4 shapes) and returns the parity record
+    that bench.py prints as `parity`. `every`: compare the teacher-forced noise_pred at every `every`-th step (the oracle still
+    runs all steps)."""
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    from loongx_amd.flux.transformer import tranformer_forward
+    dev = torch.device(device)
+    t0 = time.time()
+    tr, lx = build_pair(dev, num_layers, num_single_layers, seed=seed, precise=precise)
+    mc = dict(model_config or {"union_cond_attn": True})
+    N = hw * hw
+    g = torch.Generator(device=dev).manual_seed(4321 + seed)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    lat0, cond, pe, pooled = r(1, N, 64), r(1, N, 64), r(1, n_txt, 4096) * 0.1, r(1, 768)
+    ids = fm.prepare_latent_image_ids(hw, hw).to(dev)
+    cids = ids.clone()
+    cids[:, 2] -= hw
+    txt_ids = torch.zeros(n_txt, 3, device=dev)
+    guidance = torch.full((1,), 3.5, device=dev)
+
+    # ---- oracle trajectory + teacher-forced engine predictions ------------------------------------------------
+    sch = fm.FlowMatchEulerDiscreteScheduler()
+    sig = np.linspace(1.0, 1 / steps, steps)
+    mu = fm.calculate_shift(N, sch.config.base_image_seq_len, sch.config.max_image_seq_len, sch.config.base_shift, sch.config.max_shift)
+    timesteps, _ = fm.retrieve_timesteps(sch, steps, dev, None, sig, mu=mu)
+    lat = lat0.clone()
+    per_step = []
+    t_oracle = 0.0
+    for i, t in enumerate(timesteps):
+        ts = t.expand(1).to(lat.dtype) / 1000
+        kw = dict(hidden_states=lat, encoder_hidden_states=pe, pooled_projections=pooled, timestep=ts, img_ids=ids, txt_ids=txt_ids,
+                  guidance=guidance)
+        torch.cuda.synchronize(dev); t1 = time.time()
+        want = fr.tranformer_forward(tr, cond, cids, None, mc, **kw)[0]
+        torch.cuda.synchronize(dev); t_oracle += time.time() - t1
+        if i % every == 0 or i == len(timesteps) - 1:
+            got = tranformer_forward(lx, cond, cids, None, mc, return_dict=False, **kw)[0]
+            per_step.append((i, relerr(got, want)))
+        lat = sch.step(want, t, lat)[0]
+    final_oracle = lat
+
+    # ---- free-running product loop ---------------------------------------------------------------------------------
+    lx.invalidate_conditioning()
+    pipe = LxFluxPipeline(lx)
+    c = Condition("subject", latents=cond, latent_hw=(hw, hw), position_delta=[0, -hw])
+    final = generate(None, pipe, conditions=[c], height=16 * hw, width=16 * hw, num_inference_steps=steps, latents=lat0.clone(),
+                     prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent", model_config=mc, default_lora=True,
+                     use_brain_condition=False, guidance_scale=3.5).images
+    errs = [e for _, e in per_step]
+    rec = {"mode": "precise (split-bf16 MFMA, fp32 attention)" if precise else "bf16 MFMA operands, fp32 accumulate / residual",
+           "oracle": "oracle/flux_ref.py fp32 on the same GPU (torch-ROCm), identical weights and inputs",
+           "blocks": [num_layers, num_single_layers], "steps": steps, "tokens": [n_txt, N, N],
+           "noise_pred_relerr_first": round(errs[0], 6), "noise_pred_relerr_max": round(max(errs), 6),
+           "noise_pred_relerr_mean": round(float(np.mean(errs)), 6), "noise_pred_relerr_last": round(errs[-1], 6),
+           "steps_compared": len(errs),
+           "final_latent_relerr": round(relerr(final, final_oracle), 6), "final_latent_cosine": round(cosine(final, final_oracle), 8),
+           "oracle_s_per_forward": round(t_oracle / len(timesteps), 3), "wall_s": round(time.time() - t0, 1)}
+    del tr, lx, pipe
+    torch.cuda.empty_cache()
+    return rec

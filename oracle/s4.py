@@ -5,7 +5,7 @@ and instantiated at :31,:46,:153,:224,:293, but it is listed in NO requirements 
 (unpinned) and is absent from the image, so this is a restatement of its published
 algorithm (the "annotated S4" NPLR construction that s4torch ports) -- **parity
 unpinned**; self-consistency is established three independent ways instead
-(generating-function kernel vs explicit recurrence vs diagonalised scan, tests/test_s4_oracle.py).
+(generating-function kernel vs explicit recurrence vs diagonalised scan, tests/test_oracle_cs3.py::test_s4_kernel_three_ways, test_s4_fft_conv_equals_direct_conv).
 
 Model used by the reference: S4Model(d_input, d_model=, d_output=, n_blocks=2, n=d_model,
 l_max=L) with library defaults (GELU, post LayerNorm, no dropout/pooling/collapse):

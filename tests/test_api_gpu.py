@@ -159,11 +159,16 @@ def test_generate_matches_oracle_loop():
     pe, pooled = torch.randn(B, 512, 4096, generator=g) * 0.1, torch.randn(B, 768, generator=g)
     eeg, ppg = torch.randn(4, 3000, generator=g), torch.randn(4, 256, generator=g)
     fnirs, motion = torch.randn(6, 600, generator=g), torch.randn(6, 128, generator=g)
-    for fuse_flag, sig in ((False, dict(eeg=eeg)), (False, dict(eeg=eeg, ppg=ppg, fnirs=fnirs, motion=motion)),
-                           (True, dict(eeg=eeg, ppg=ppg, fnirs=fnirs, motion=motion)), (False, {})):
+    allsig = dict(eeg=eeg, ppg=ppg, fnirs=fnirs, motion=motion)
+    # (fuse_flag, signals, brain_replace): "both" = the reference's literal rule and the default (EEG alone leaves the text
+    # embeddings untouched, generate.py:252-255); "per_stream" = the opt-in extension BASELINE configs[1] runs with
+    outs = {}
+    for fuse_flag, sig, rule in ((False, dict(eeg=eeg), "per_stream"), (False, dict(eeg=eeg), "both"), (False, allsig, "both"),
+                                 (True, allsig, "both"), (False, {}, "both")):
         with torch.no_grad():
             s = {k: v.unsqueeze(0) for k, v in sig.items()}
-            rpe, rpool = ref_cs3.brain_embeds(pe, pooled, s.get("eeg"), s.get("fnirs"), s.get("ppg"), s.get("motion"), fuse_flag=fuse_flag)
+            rpe, rpool = ref_cs3.brain_embeds(pe, pooled, s.get("eeg"), s.get("fnirs"), s.get("ppg"), s.get("motion"), fuse_flag=fuse_flag,
+                                              per_stream=rule == "per_stream")
             ids = fm.prepare_latent_image_ids(hw, hw)
             cids = ids.clone()
             cids[:, 2] -= hw
@@ -174,8 +179,12 @@ def test_generate_matches_oracle_loop():
                        prompt_embeds=pe.cuda(), pooled_prompt_embeds=pooled.cuda(), output_type="latent", model_config={},
                        default_lora=True, additional_condition1=sig.get("eeg"), additional_condition2=sig.get("fnirs"),
                        additional_condition3=sig.get("ppg"), additional_condition4=sig.get("motion"),
-                       use_brain_condition=bool(sig), fuse_flag=fuse_flag)
-        assert relerr(out.images.cpu(), want) < 3e-2, (fuse_flag, list(sig))
+                       use_brain_condition=bool(sig), fuse_flag=fuse_flag, **({} if rule == "both" else {"brain_replace": rule}))
+        assert relerr(out.images.cpu(), want) < 3e-2, (fuse_flag, list(sig), rule)
+        outs[(fuse_flag, tuple(sig), rule)] = out.images.clone()
+    # the literal rule ignores a lone EEG (== no signals at all); the per-stream rule does not
+    assert torch.equal(outs[(False, ("eeg",), "both")], outs[(False, (), "both")])
+    assert relerr(outs[(False, ("eeg",), "per_stream")].cpu(), outs[(False, (), "both")].cpu()) > 1e-3
 
 
 def test_scheduler_and_latent_utils_match_oracle():

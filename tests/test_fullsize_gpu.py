@@ -74,12 +74,13 @@ def _fwd(lx, x, sl=slice(None), model_config=None):
     return eng.forward(x["lat"][sl], torch.full((B,), 0.5, device="cuda")).clone()
 
 
-def test_full_size_batch_independence_and_determinism(full, monkeypatch):
+def test_full_size_batch_independence_and_determinism(full):
     _, lx, ids, cids, _ = full
     x = _cond_inputs(3, 5, ids, cids)
     # Default launch plans. A batch-1 step runs its N = 3072 long-K projections on lx_gemm_pair_kernel (two workgroups per tile,
     # each half of K: one extra fp32 rounding per element), a batch-3 step has enough tiles not to: equal within rounding.
     lx.engine.graphs.clear()
+    lx.engine.pair_plan = True
     vb = _fwd(lx, x)
     assert torch.isfinite(vb).all()
     assert torch.equal(vb, _fwd(lx, x))                                  # deterministic (no atomics anywhere)
@@ -88,12 +89,12 @@ def test_full_size_batch_independence_and_determinism(full, monkeypatch):
         assert torch.equal(vi, _fwd(lx, x, slice(i, i + 1))[0])
         assert relerr(vi.cpu(), vb[i].cpu()) < 5e-3
     # With the same tile kernels for every batch size, data-parallel shards == the single-GPU batch, bit for bit.
-    monkeypatch.setenv("LX_GEMM_PAIR", "0")
-    lx.engine.graphs.clear()                                             # captured step graphs hold the old plans
+    lx.engine.check_status()                                             # no pair workgroup timed out
+    lx.engine.pair_plan = False                                          # (part of the step-graph key)
     vb = _fwd(lx, x)
     for i in range(3):
         assert torch.equal(_fwd(lx, x, slice(i, i + 1))[0], vb[i])
-    lx.engine.graphs.clear()
+    lx.engine.pair_plan = True
 
 
 def test_full_size_condition_decoupling(full):

@@ -32,25 +32,51 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
 PLANS = [256, 128, "pair"]
 
 
+_WS = []
+
+
+def _ws():
+    """The caller-owned workspace the split-K pair plan needs (lx_gemm_bf16_ws); one for this test module's stream."""
+    if not _WS:
+        from loongx_amd import ops as o
+        _WS.append(o.gemm_workspace(DEV))
+    return _WS[0]
+
+
+@pytest.fixture(autouse=True)
+def _restore_gemm_env():
+    """The library reads its LX_GEMM_* switches when it is loaded; tests that change them call lx_gemm_reload_env() and this
+    re-reads the restored environment afterwards."""
+    yield
+    if torch.cuda.is_available():
+        from loongx_amd import _lib
+        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR"):
+            os.environ.pop(k, None)
+        _lib.lib.lx_gemm_reload_env()
+
+
 def _plan(monkeypatch, bm):
     """Force one launch plan: all 256-row tiles, all 128-row tiles, or two workgroups per 256-row tile, each half of K
-    ("pair": lx_gemm_pair_kernel wherever the launch has <= 128 tiles and K >= 128)."""
+    ("pair": lx_gemm_pair_kernel wherever the launch has <= 128 tiles and K >= 128). Returns the workspace to launch with."""
+    from loongx_amd import _lib
     if bm == "pair":
         monkeypatch.delenv("LX_GEMM_BM", raising=False)
         monkeypatch.setenv("LX_GEMM_PAIR", "2")
     else:
         monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _lib.lib.lx_gemm_reload_env()
+    return _ws() if bm == "pair" else None
 
 
 @pytest.mark.parametrize("bm", PLANS)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (2560, 3072, 3072)])
 def test_gemm_store_bf16_bias(ops, M, N, K, bm, monkeypatch):
-    _plan(monkeypatch, bm)
+    ws = _plan(monkeypatch, bm)
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
     bias = rnd(N, seed=3)
     Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias)])
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias)], ws)
     ref = A.float() @ W.float().T + bias
     assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
     assert torch.isfinite(Cc.float()).all()
@@ -68,25 +94,25 @@ def test_gemm_asymmetric_identity(ops):
 
 @pytest.mark.parametrize("bm", PLANS)
 def test_gemm_gelu_colstart_and_f32(ops, bm, monkeypatch):
-    _plan(monkeypatch, bm)
+    ws = _plan(monkeypatch, bm)
     M, N, K = 520, 1024, 192
     A = rnd(M, K, seed=4, dtype=torch.bfloat16)
     W = rnd(N, K, seed=5, scale=0.1, dtype=torch.bfloat16)
     bias = rnd(N, seed=6, scale=0.1)
     Cc = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=512)])
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=512)], ws)
     ref = A.float() @ W.float().T + bias
     ref[:, 512:] = torch.nn.functional.gelu(ref[:, 512:], approximate="tanh")
     assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
     C32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    ops.gemm([ops.gemm_desc(A, W, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32)], ws)
     assert relerr(C32.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("bm", PLANS)
 def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
     """Three-stream launch: text (own weights), image (base weights), condition (base + LoRA), gated residual."""
-    _plan(monkeypatch, bm)
+    ws = _plan(monkeypatch, bm)
     B, T, Nn, Cn, D, K, r = 2, 48, 80, 96, 512, 256, 4
     Wt = rnd(D, K, seed=1, scale=0.05, dtype=torch.bfloat16)
     Wi = rnd(D, K, seed=2, scale=0.05, dtype=torch.bfloat16)
@@ -109,7 +135,7 @@ def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
         ops.gemm_desc(Ai, Wi, Xi, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[B:2 * B], rows_per_batch=Nn),
         ops.gemm_desc(Ac, Wi, Xc, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[2 * B:], rows_per_batch=Cn,
                       lora_t=Tl, lora_up=Bu),
-    ])
+    ], ws)
     def gated(y, g, L):
         return y * g.repeat_interleave(L, dim=0)
     ref_t = X0[: B * T] + gated(At.float() @ Wt.float().T + bt, gate[0:B], T)
@@ -142,17 +168,17 @@ def test_gemm_lora_module_offsets(ops):
 @pytest.mark.parametrize("bm", PLANS)
 def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     """LX_W_TILED: the load-time tiled/swizzled weight image must give bit-identical results to the row-major weight."""
-    _plan(monkeypatch, bm)
+    ws = _plan(monkeypatch, bm)
     M, N, K = 700, 768, 320
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
     bias = rnd(N, seed=3)
     C1 = torch.empty(M, N, dtype=torch.float32, device=DEV)
     C2 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, C1, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    ops.gemm([ops.gemm_desc(A, W, C1, bias=bias, epilogue=ops.LX_EPI_STORE_F32)], ws)
     Wt = ops.tile_weight(W)
     assert Wt.shape == W.shape and not torch.equal(Wt, W)
-    ops.gemm([ops.gemm_desc(A, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_F32)])
+    ops.gemm([ops.gemm_desc(A, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_F32)], ws)
     assert torch.equal(C1, C2)
     assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
@@ -162,6 +188,7 @@ def test_gemm_pair_kernel_long_k(ops, monkeypatch):
     128-row-tile kernel on the same inputs, bit-identical from run to run, and again after HIP-graph capture + replays (each
     flag is cleared by its reader, so replays need no reset)."""
     monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    ops.lib.lx_gemm_reload_env()
     M, N, K, r = 2560, 3072, 15360, 4
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16)
@@ -176,34 +203,50 @@ def test_gemm_pair_kernel_long_k(ops, monkeypatch):
     X = torch.empty_like(X0)
     d = ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
                       lora_split_stride=Tls.stride(0))
+    ws = _ws()
     for mode in ("0", "2"):
-        monkeypatch.setenv("LX_GEMM_PAIR", mode)
         X.copy_(X0)
-        ops.gemm([d])
+        ops.gemm([d], ws if mode == "2" else None)          # default LX_GEMM_PAIR=1: the pair plan runs iff a workspace is given
         torch.cuda.synchronize()
         out[mode] = X.clone()
+    ops.gemm_workspace_status(ws)                            # no pair workgroup timed out
     t = Tls.sum(0)[:, :r]
     ref = X0 + gate * (A.float() @ W.float().T + bias + t @ Bu.T)
     assert relerr(out["2"].cpu(), ref.cpu()) < 2e-5
     assert relerr(out["2"].cpu(), out["0"].cpu()) < 2e-6      # same products, one more fp32 rounding per element
     for _ in range(3):
         X.copy_(X0)
-        ops.gemm([d])
+        ops.gemm([d], ws)
         assert torch.equal(X, out["2"])
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         X.copy_(X0)
-        ops.gemm([d])
+        ops.gemm([d], ws)
     for _ in range(3):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(X, out["2"])
+    # two streams, each with its OWN workspace, may run the pair plan concurrently (the library keeps no scratch of its own)
+    ws2, X2 = ops.gemm_workspace(DEV), X0.clone()
+    d2 = ops.gemm_desc(A, W, X2, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
+                       lora_split_stride=Tls.stride(0))
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    X.copy_(X0)
+    torch.cuda.synchronize()
+    ops.gemm([d], ws)
+    with torch.cuda.stream(s2):
+        ops.gemm([d2], ws2)
+    torch.cuda.synchronize()
+    assert torch.equal(X, out["2"]) and torch.equal(X2, out["2"])
+    ops.gemm_workspace_status(ws); ops.gemm_workspace_status(ws2)
 
 
 def test_gemm_planner_mixed_tail(ops, monkeypatch):
     """No LX_GEMM_BM override: 280 tiles of 256x256 -> the planner runs full rounds of 256-row tiles plus a 128-row-tile
     tail launch. Gate batch index, LoRA rows and residual must stay right across the split."""
     monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    ops.lib.lx_gemm_reload_env()
     M1, M2, N, K, r = 1536, 1024, 7168, 128, 4
     A = rnd(M1 + M2, K, seed=1, dtype=torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
