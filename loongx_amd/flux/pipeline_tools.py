@@ -16,8 +16,8 @@ def encode_images(pipeline, images):
     z = (z - pipeline.vae.config.shift_factor) * pipeline.vae.config.scaling_factor
     tokens = pipeline._pack_latents(z, *z.shape)
     ids = pipeline._prepare_latent_image_ids(z.shape[0], z.shape[2], z.shape[3], pipeline.device, torch.float32)
-    if tokens.shape[1] != ids.shape[0]:   # newer diffusers take pre-halved sizes (reference :22-29)
-        ids = pipeline._prepare_latent_image_ids(z.shape[0], z.shape[2] * 2, z.shape[3] * 2, pipeline.device, torch.float32)
+    if tokens.shape[1] != ids.shape[0]:   # pipelines whose id helper takes pre-halved sizes (reference :22-29)
+        ids = pipeline._prepare_latent_image_ids(z.shape[0], z.shape[2] // 2, z.shape[3] // 2, pipeline.device, torch.float32)
     return tokens, ids
 
 

@@ -64,10 +64,11 @@ class EEGEncoder(nn.Module):
     """[B,4,4096] -> [B,512,4096]  (model.py:16-134)."""
     fixed_length = 4096
 
-    def __init__(self, g=None):
+    def __init__(self, g=None, g2=None):
+        """g / g2: generators the two S4Model instances draw their S4 parameters from (g2 defaults to continuing g)."""
         super().__init__()
         self.s41 = S4Model(4, 64, 64, 2, 64, 4096, g)
-        self.s42 = S4Model(4, 4, 4, 2, 4, 4096, g)
+        self.s42 = S4Model(4, 4, 4, 2, 4, 4096, g if g2 is None else g2)
         self.fpp = FeaturePyramidPooling([128, 256, 512, 1024, 2048])
         self.projection = _mlp_head(4 * 4096, 2048, 4096, 4096)
 

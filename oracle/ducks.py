@@ -1,0 +1,157 @@
+"""Duck-typed stand-ins for the third-party objects the reference's generate() / Condition.encode() are handed
+(diffusers' FluxPipeline, AutoencoderKL, VaeImageProcessor, a PIL image) -- TEST INFRASTRUCTURE.
+
+`oracle/make_goldens.py` drives the REAL reference functions (src/flux/generate.py:72-394, src/flux/condition.py:106-138,
+src/flux/pipeline_tools.py:7-30) with these objects; the tests rebuild the same objects from the same seeds and hand them to
+the product's mirrors, so the goldens pin the reference's OWN logic on both sides of the boundary. The pipeline slice below
+restates diffusers==0.31.0 `FluxPipeline` (train/requirements.txt:1): check_inputs, prepare_latents, _pack_latents /
+_unpack_latents / _prepare_latent_image_ids, progress_bar. The VAE and the image processor are deterministic toys: what
+matters for Condition.encode is the wire format around them ((x - shift) * scale, 2x2 packing, ids), not their arithmetic.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import flux_modules as fm
+
+
+class DuckImage:
+    """What Condition.encode reads off a PIL image: `.size == (width, height)` (condition.py:127)."""
+
+    def __init__(self, width: int, height: int, seed: int = 0):
+        self.size = (width, height)
+        self.seed = seed
+
+
+class DuckImageProcessor:
+    def preprocess(self, img: DuckImage) -> torch.Tensor:
+        w, h = img.size
+        g = torch.Generator().manual_seed(1000 + img.seed)
+        return torch.rand(1, 3, h, w, generator=g) * 2 - 1
+
+    def postprocess(self, image, output_type="pil"):
+        return image
+
+
+class DuckVAE:
+    """encode: 8x8 average pool + a fixed 3->16 channel mix; decode: the adjoint-ish upsample. FLUX VAE config constants."""
+
+    def __init__(self, seed: int = 7):
+        g = torch.Generator().manual_seed(seed)
+        self.mix = torch.randn(16, 3, generator=g)
+        self.config = SimpleNamespace(shift_factor=0.1159, scaling_factor=0.3611)
+
+    def encode(self, images: torch.Tensor):
+        z = torch.einsum("oc,bchw->bohw", self.mix.to(images), F.avg_pool2d(images, 8))
+        return SimpleNamespace(latent_dist=SimpleNamespace(sample=lambda: z))
+
+    def decode(self, z: torch.Tensor, return_dict: bool = False):
+        x = torch.einsum("oc,bohw->bchw", self.mix.to(z), F.interpolate(z, scale_factor=8, mode="nearest"))
+        return (x,)
+
+
+class DuckFluxPipeline:
+    """The slice of diffusers 0.31.0 FluxPipeline that generate() / Condition.encode() touch."""
+    vae_scale_factor = 16
+    default_sample_size = 64
+
+    def __init__(self, transformer, device="cpu", dtype=torch.float32, vae=None, image_processor=None):
+        self.transformer = transformer
+        self.scheduler = fm.FlowMatchEulerDiscreteScheduler()
+        self.vae = vae if vae is not None else DuckVAE()
+        self.image_processor = image_processor if image_processor is not None else DuckImageProcessor()
+        self.device, self.dtype = torch.device(device), dtype
+        self._guidance_scale, self._joint_attention_kwargs, self._interrupt, self._num_timesteps = 3.5, None, False, 0
+        self.adapters_set = []
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    @property
+    def joint_attention_kwargs(self):
+        return self._joint_attention_kwargs
+
+    def set_adapters(self, name):
+        self.adapters_set.append(name)
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    @contextmanager
+    def progress_bar(self, total=None):
+        yield SimpleNamespace(update=lambda *a, **k: None)
+
+    def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
+                     callback_on_step_end_tensor_inputs=None, max_sequence_length=None):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed.")
+        if max_sequence_length is not None and max_sequence_length > 512:
+            raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+
+    def encode_prompt(self, prompt=None, prompt_2=None, prompt_embeds=None, pooled_prompt_embeds=None, device=None,
+                      num_images_per_prompt=1, max_sequence_length=512, lora_scale=None):
+        assert prompt_embeds is not None, "the duck pipeline has no text encoders: pass prompt_embeds"
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device, dtype=prompt_embeds.dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
+
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        x = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2).permute(0, 2, 4, 1, 3, 5)
+        return x.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        return fm.unpack_latents(latents, height, width, vae_scale_factor)
+
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        ids = torch.zeros(height // 2, width // 2, 3)
+        ids[..., 1] = ids[..., 1] + torch.arange(height // 2)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(width // 2)[None, :]
+        return ids.reshape(-1, 3).to(device=device, dtype=dtype)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        height = 2 * (int(height) // self.vae_scale_factor)
+        width = 2 * (int(width) // self.vae_scale_factor)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), self._prepare_latent_image_ids(batch_size, height, width, device, dtype)
+        shape = (batch_size, num_channels_latents, height, width)
+        noise = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        return (self._pack_latents(noise, batch_size, num_channels_latents, height, width),
+                self._prepare_latent_image_ids(batch_size, height, width, device, dtype))
+
+
+def generate_cases():
+    """(name, fuse_flag, signals used, condition_scale) of the generate() goldens."""
+    allsig = ("eeg", "fnirs", "ppg", "motion")
+    return [("plain", False, (), 1.0), ("eeg_only", False, ("eeg",), 1.0), ("replace", False, allsig, 1.0),
+            ("fuse", True, allsig, 1.0), ("fuse_cscale2", True, allsig, 2.0), ("fnirs_motion", True, ("fnirs", "motion"), 1.0)]
+
+
+def generate_inputs(hw: int = 4, seed: int = 3):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return dict(lat=r(1, hw * hw, 64), pe=r(1, 512, 4096) * 0.1, pooled=r(1, 768),
+                eeg=r(4, 3000), ppg=r(4, 256), fnirs=r(6, 600), motion=r(6, 100))
+
+
+def generate_transformer(seed: int = 4):
+    tr = fm.FluxTransformer2DModel(num_layers=2, num_single_layers=2, heads=2, head_dim=128, in_channels=64, joint_dim=4096,
+                                   pooled_dim=768, guidance_embeds=True, lora=True)
+    fm.init_synthetic_(tr, seed=seed, std=0.03, bias_std=0.02, norm_jitter=0.1)
+    return tr.eval()

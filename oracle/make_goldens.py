@@ -246,11 +246,115 @@ def gold_encoders():
     print("cs3_encoders.npz", len(out), "arrays")
 
 
+def gold_eeg_encoder():
+    """The reference EEGEncoder class (model.py:16-134; oracle S4 standing in for s4torch) -- the one encoder BASELINE
+    configs[1] runs. 33.5 M parameters re-derived by seed; the [1,512,4096] output kept as a strided sample + checksums."""
+    from refsrc.train import model as rm
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        torch.manual_seed(78)
+        enc = rm.EEGEncoder(device="cpu", dtype=torch.float32).eval()
+        x = torch.randn(2, 4, 4096, generator=g)
+        y = enc(x)
+        assert y.shape == (2, 512, 4096)
+        out["enc_eeg_x"] = t2n(x)
+        out["enc_eeg_y_sample"] = t2n(y[:, ::37, ::53])
+        out["enc_eeg_y_row0"] = t2n(y[:, 0, :256])
+        out["enc_eeg_y_sum"] = np.array([float(y.double().sum()), float(y.double().abs().sum())])
+        out["enc_eeg_seed"] = np.array([78, 1234])      # torch.manual_seed(78); both S4Model instances draw from Generator(1234)
+    np.savez_compressed(os.path.join(OUT, "cs3_eeg_encoder.npz"),
+                        **{k: np.asarray(v, dtype=np.float64 if k.endswith("_sum") else np.float32) for k, v in out.items()})
+    print("cs3_eeg_encoder.npz", len(out), "arrays")
+
+
+def gold_condition():
+    """Condition.encode (condition.py:106-138) + encode_images (pipeline_tools.py:7-30) through a duck-typed pipeline:
+    tokens, position ids (default subject delta, explicit delta, position_scale affine) and type ids."""
+    from refsrc.flux import condition as rc
+    from oracle import ducks
+    out = {}
+    pipe = ducks.DuckFluxPipeline(None)
+    cases = {"subject_default": dict(condition_type="subject", wh=(64, 48)),
+             "subject_delta": dict(condition_type="subject", wh=(64, 64), position_delta=[0, -32]),
+             "subject_delta_rc": dict(condition_type="subject", wh=(32, 64), position_delta=[3, -5]),
+             "subject_scale2": dict(condition_type="subject", wh=(64, 64), position_scale=2.0),
+             "fill_scale_half": dict(condition_type="fill", wh=(96, 64), position_delta=[0, 0], position_scale=0.5),
+             "cartoon_nodelta": dict(condition_type="cartoon", wh=(64, 64))}
+    for name, kw in cases.items():
+        kw = dict(kw)
+        w, h = kw.pop("wh")
+        c = rc.Condition(condition=ducks.DuckImage(w, h, seed=len(name)), **kw)
+        tokens, ids, type_id = c.encode(pipe)
+        out[f"{name}_tokens"], out[f"{name}_ids"], out[f"{name}_type"] = t2n(tokens), t2n(ids), t2n(type_id)
+        out[f"{name}_cfg"] = np.array([w, h, len(name), kw.get("position_scale", 1.0)] + list(kw.get("position_delta") or [np.nan, np.nan]))
+    try:
+        rc.Condition(condition_type="eeg+fnirs", condition=ducks.DuckImage(64, 64)).encode(pipe)
+        raise AssertionError("expected NotImplementedError")
+    except NotImplementedError:
+        pass
+    np.savez_compressed(os.path.join(OUT, "condition_ids.npz"), **{k: np.asarray(v, dtype=np.float32) for k, v in out.items()})
+    print("condition_ids.npz", len(out), "arrays")
+
+
+def gold_generate():
+    """The REAL generate() (src/flux/generate.py:72-394) on the tiny 2+2-block config, 4 steps, latents in / latents out,
+    driven with a duck-typed pipeline and a duck-typed OminiModel: sigma schedule, Euler stepping, the brain branch
+    (unsqueeze(0) -> spatial_pyramid_pooling -> encoders -> fuse_eeg / fuse_fnirs -> DUAN fusion or replacement), the
+    condition_scale -> c_factor hook and Condition.encode. Documented delta Q1: the reference hands the encoders
+    `signal.flatten(1)`, which its own encoder classes cannot consume ([B,C,L] permutes): the duck encoders un-flatten, i.e.
+    the golden pins generate() AS IF the encoders received [B,C,L] -- what the product (and OminiModel.step) does."""
+    from functools import partial
+    from refsrc.flux import condition as rc
+    from refsrc.flux import generate as rg
+    from refsrc.train import model as rm
+    from oracle import cs3 as ocs3
+    from oracle import ducks
+    tr = ducks.generate_transformer()
+    torch.manual_seed(0)
+    brain = ocs3.CS3DGF(seed=0).eval()        # the same construction the tests use: weights re-derivable from the seeds
+    real = {}
+    for n, C in (("duan_norm1", 512), ("duan_norm2", 1), ("duan_norm_prompt", 512), ("duan_norm_pooled", 1)):
+        real[n] = rm.DUAN(C).eval()            # the reference's own class, carrying the seeded weights
+        real[n].load_state_dict(getattr(brain, n).state_dict())
+    ns = types.SimpleNamespace(fusion1=brain.fusion1, fusion2=brain.fusion2, **real)
+    unflat = lambda enc, ch: (lambda x: enc(x.view(x.shape[0], ch, -1)))
+    model = types.SimpleNamespace(
+        eeg_projection=unflat(brain.eeg_projection, 4), ppg_projection=unflat(brain.ppg_projection, 4),
+        fnirs_projection=unflat(brain.fnirs_projection, 6), motion_projection=unflat(brain.motion_projection, 6),
+        fuse_eeg=partial(rm.OminiModel.fuse_eeg, ns), fuse_fnirs=partial(rm.OminiModel.fuse_fnirs, ns),
+        spatial_pyramid_pooling=partial(rm.OminiModel.spatial_pyramid_pooling, None),
+        eeg_fixed_length=4096, fnirs_fixed_length=512, ppg_fixed_length=256, motion_fixed_length=128, **real)
+    x = ducks.generate_inputs()
+    hw = 4
+    out = {"in_" + k: t2n(v) for k, v in x.items()}
+    with torch.no_grad():
+        for name, fuse_flag, use, cscale in ducks.generate_cases():
+            pipe = ducks.DuckFluxPipeline(tr)
+            cond = rc.Condition(condition_type="subject", condition=ducks.DuckImage(hw * 16, hw * 16, seed=5))
+            sig = {k: (x[k] if k in use else None) for k in ("eeg", "fnirs", "ppg", "motion")}
+            r = rg.generate(model, pipe, conditions=[cond], height=hw * 16, width=hw * 16, num_inference_steps=4,
+                            latents=x["lat"].clone(), prompt_embeds=x["pe"], pooled_prompt_embeds=x["pooled"], output_type="latent",
+                            model_config={}, default_lora=True, condition_scale=cscale, additional_condition1=sig["eeg"],
+                            additional_condition2=sig["fnirs"], additional_condition3=sig["ppg"], additional_condition4=sig["motion"],
+                            use_brain_condition=bool(use), fuse_flag=fuse_flag, return_dict=False)
+            out[f"gen_{name}"] = t2n(r[0])
+            assert not any(hasattr(m, "c_factor") for _, m in tr.named_modules())     # removed again on exit (generate.py:384-388)
+        out["sched_timesteps"], out["sched_sigmas"] = t2n(pipe.scheduler.timesteps), t2n(pipe.scheduler.sigmas)
+        # the condition tokens/ids generate() fed the transformer (from the duck VAE): handed to the product as Condition(latents=...)
+        tokens, ids, _ = rc.Condition(condition_type="subject", condition=ducks.DuckImage(hw * 16, hw * 16, seed=5)).encode(pipe)
+        out["cond_tokens"], out["cond_ids"] = t2n(tokens), t2n(ids)
+    assert np.array_equal(out["gen_plain"], out["gen_eeg_only"])       # the literal rule ignores a lone EEG (generate.py:252-255)
+    np.savez_compressed(os.path.join(OUT, "generate_tiny.npz"), **{k: np.asarray(v, dtype=np.float32) for k, v in out.items()})
+    print("generate_tiny.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"{REF} not found: goldens can only be regenerated in the build container"
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.set_num_threads(4)
-    gold_flux()
-    gold_cs3()
-    gold_encoders()
+    only = set(sys.argv[1:])
+    for fn in (gold_flux, gold_cs3, gold_encoders, gold_eeg_encoder, gold_condition, gold_generate):
+        if not only or fn.__name__ in only:
+            fn()

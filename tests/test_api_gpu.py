@@ -187,6 +187,37 @@ def test_generate_matches_oracle_loop():
     assert relerr(outs[(False, ("eeg",), "per_stream")].cpu(), outs[(False, (), "both")].cpu()) > 1e-3
 
 
+@pytest.mark.parametrize("case", [c[0] for c in __import__("oracle.ducks", fromlist=["x"]).generate_cases()])
+def test_generate_matches_the_reference_generate_goldens(case):
+    """The product's generate() vs goldens made by the reference's REAL generate() (src/flux/generate.py:72-394) driven through
+    a duck-typed pipeline / model (oracle/make_goldens.py::gold_generate): same call, same kwargs, the condition as an image
+    object through Condition.encode + encode_images (duck VAE), default reference replacement rule, DUAN fusion,
+    condition_scale -> c_factor. Documented delta Q1 (signals reach the encoders as [B,C,L]) is part of the golden."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ducks
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    G = load("generate_tiny.npz")
+    name, fuse_flag, use, cscale = next(c for c in ducks.generate_cases() if c[0] == case)
+    _, model = _mk_model(ducks.generate_transformer())
+    pipe = LxFluxPipeline(model.transformer, vae=ducks.DuckVAE(), image_processor=ducks.DuckImageProcessor())
+    hw = 4
+    cond = Condition(condition_type="subject", condition=ducks.DuckImage(hw * 16, hw * 16, seed=5))
+    sig = {k: (G["in_" + k].cuda() if k in use else None) for k in ("eeg", "fnirs", "ppg", "motion")}
+    out = generate(model, pipe, conditions=[cond], height=hw * 16, width=hw * 16, num_inference_steps=4, latents=G["in_lat"].cuda(),
+                   prompt_embeds=G["in_pe"].cuda(), pooled_prompt_embeds=G["in_pooled"].cuda(), output_type="latent", model_config={},
+                   default_lora=True, condition_scale=cscale, additional_condition1=sig["eeg"], additional_condition2=sig["fnirs"],
+                   additional_condition3=sig["ppg"], additional_condition4=sig["motion"], use_brain_condition=bool(use),
+                   fuse_flag=fuse_flag, return_dict=False)
+    assert isinstance(out, tuple)
+    assert relerr(out[0].cpu(), G[f"gen_{case}"]) < 3e-2
+    assert cond.position_delta == [0, -hw]                      # default subject delta, written back (condition.py:126-127)
+    assert model.transformer.c_factor is None                   # removed again on exit (generate.py:384-388)
+    assert torch.equal(pipe.scheduler.timesteps.cpu(), G["sched_timesteps"]) and torch.equal(pipe.scheduler.sigmas.cpu(), G["sched_sigmas"])
+
+
 def test_scheduler_and_latent_utils_match_oracle():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -66,6 +66,21 @@ def test_flat_encoders(name, cls):
         assert relerr(y, E[f"enc_{name}_y"]) < 5e-6
 
 
+def test_eeg_encoder_golden():
+    """The reference EEGEncoder class (the one encoder BASELINE configs[1] runs; oracle S4 standing in for s4torch) vs the
+    oracle EEGEncoder, same seeds -> same 33.5 M weights."""
+    E = load("cs3_eeg_encoder.npz")
+    seed, s4seed = [int(v) for v in E["enc_eeg_seed"]]
+    torch.manual_seed(seed)
+    enc = cs3.EEGEncoder(torch.Generator().manual_seed(s4seed), torch.Generator().manual_seed(s4seed)).eval()
+    with torch.no_grad():
+        y = enc(E["enc_eeg_x"])
+    assert y.shape == (2, 512, 4096)
+    assert relerr(y[:, ::37, ::53], E["enc_eeg_y_sample"]) < 5e-6
+    assert relerr(y[:, 0, :256], E["enc_eeg_y_row0"]) < 5e-6
+    assert abs(float(y.double().sum()) - float(E["enc_eeg_y_sum"][0])) < 1e-3 * float(E["enc_eeg_y_sum"][1])
+
+
 # ------------------------------------------------------------------ S4 self-consistency (parity unpinned)
 @pytest.mark.parametrize("H,N,L", [(4, 4, 256), (6, 6, 128), (16, 16, 512)])
 def test_s4_kernel_three_ways(H, N, L):

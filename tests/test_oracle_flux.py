@@ -3,6 +3,7 @@ produced by the REAL reference functions (oracle/make_goldens.py).  CPU only."""
 import pytest
 import torch
 
+from oracle import flux_modules as fm
 from oracle import flux_ref as fr
 from tests.helpers import load, relerr, tiny_transformer
 
@@ -107,3 +108,34 @@ def test_transformer_forward(G, tr):
 def test_transformer_forward_no_guidance(G):
     tr2 = tiny_transformer(seed=3, guidance_embeds=False)
     assert relerr(_fwd(tr2, G, guidance=False), G["fwd_noguidance_seed3"]) < TOL
+
+
+# ------------------------------------------------------------------ generate() (reference src/flux/generate.py:72-394)
+def _brain():
+    from oracle import cs3 as ocs3
+    torch.manual_seed(0)
+    return ocs3.CS3DGF(seed=0).eval()
+
+
+@pytest.mark.parametrize("case", [c[0] for c in __import__("oracle.ducks", fromlist=["x"]).generate_cases()])
+def test_generate_side_logic_against_the_real_generate(case):
+    """`oracle.flux_ref.denoise_loop` + `oracle.cs3.CS3DGF.brain_embeds` (what the GPU tests check the product's generate()
+    against) vs goldens made by the reference's REAL generate() through a duck-typed pipeline / model: sigma schedule, Euler
+    stepping, the brain branch with the literal replacement rule, DUAN fusion, condition_scale -> c_factor."""
+    from oracle import ducks
+    G = load("generate_tiny.npz")
+    name, fuse_flag, use, cscale = next(c for c in ducks.generate_cases() if c[0] == case)
+    tr, brain = ducks.generate_transformer(), _brain()
+    sig = {k: (G["in_" + k].unsqueeze(0) if k in use else None) for k in ("eeg", "fnirs", "ppg", "motion")}
+    with torch.no_grad():
+        pe, pooled = brain.brain_embeds(G["in_pe"], G["in_pooled"], sig["eeg"], sig["fnirs"], sig["ppg"], sig["motion"],
+                                        fuse_flag=fuse_flag, per_stream=False)
+        if cscale != 1.0:
+            for n, m in tr.named_modules():
+                if n.endswith(".attn"):
+                    m.c_factor = torch.ones(1, 1) * cscale
+        sch = fm.FlowMatchEulerDiscreteScheduler()
+        got = fr.denoise_loop(tr, sch, G["in_lat"], pe, pooled, torch.zeros(512, 3), fm.prepare_latent_image_ids(4, 4),
+                              G["cond_tokens"], G["cond_ids"], num_inference_steps=4)
+    assert relerr(got, G[f"gen_{case}"]) < 5e-6
+    assert torch.equal(sch.timesteps, G["sched_timesteps"]) and torch.equal(sch.sigmas, G["sched_sigmas"])
