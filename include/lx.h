@@ -55,8 +55,10 @@ enum {
   LX_EPI_STORE_F32 = 1,  /* C(fp32)  = acc + bias                           */
   LX_EPI_RESID_F32 = 2,  /* C(fp32) += gate[m / rows_per_batch, n] * (acc + bias)   (gate NULL => 1) */
   LX_EPI_GELU = 0x100,   /* OR-able flag: GELU(tanh) on columns n >= gelu_col_start */
-  LX_W_TILED = 0x200     /* OR-able flag: W is pre-tiled (see lx_tile_weight_layout): [N/256][K/64] blocks of 256x64,
+  LX_W_TILED = 0x200,    /* OR-able flag: W is pre-tiled (see lx_tile_weight_layout): [N/256][K/64] blocks of 256x64,
                             each stored as the swizzled LDS image the kernel consumes; needs N % 256 == 0, ldw == K */
+  LX_EPI_SPLIT_BF16 = 0x400 /* OR-able flag (with LX_EPI_STORE_BF16): also store bf16(x - bf16(x)) at column n + c_lo_off, so
+                            that a consumer GEMM with k_segs >= 2 sees x to 16 mantissa bits (precise mode) */
 };
 
 typedef struct lx_gemm_desc {
@@ -75,6 +77,13 @@ typedef struct lx_gemm_desc {
   int32_t gelu_col_start;
   int32_t lora_nsplit;       /* lora_t is the sum of this many K-split partial slabs (0/1 = a single slab) ... */
   int32_t lora_split_stride; /* ... spaced this many floats apart (as written by lx_lora_down) */
+  /* Precise mode ("split bf16": fp32-class products on the bf16 MFMA, for the reference's fp32 configuration,
+   * train/config/seed_512.yaml:2). k_segs = 0/1: plain. k_segs = 2: A = A_hi + A_lo with A_hi = bf16(a), A_lo = bf16(a - A_hi)
+   * stored a_lo_off columns after A_hi in the same rows; C accumulates A_hi W^T + A_lo W^T (exact for bf16-representable
+   * weights, which is what FLUX.1 checkpoints hold). k_segs = 3: W is [N, 2K] = [W_hi | W_lo] as well (ldw >= 2K) and
+   * A_hi W_lo^T is added: 3 of the 4 cross terms, relative error ~2^-16. One accumulation, one epilogue. */
+  int32_t k_segs, a_lo_off;
+  int32_t c_lo_off;          /* LX_EPI_SPLIT_BF16: column distance of the lo image of the output */
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4
@@ -198,6 +207,34 @@ int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_co
                          int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
                          float q_scale, float k_scale, float v_scale, void* stream);
 int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_descale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Precise mode -- fp32-class arithmetic for the reference's shipped fp32 configuration (train/config/seed_512.yaml:2):
+ * GEMMs as split-bf16 products on the bf16 MFMA (lx_gemm_desc.k_segs), everything between them in fp32. The producers of the
+ * hi/lo operand pairs and the fp32 attention live here; opt-in (model_config["precise"] / LxFluxTransformer(precise=True)).
+ * ------------------------------------------------------------------------------------------------ */
+/* dst(bf16)[m, k] = bf16(src[m, k]);  dst[m, lo_off + k] = bf16(src[m, k] - dst[m, k])  -- the operand pair of a k_segs >= 2 GEMM */
+int lx_split_bf16(const float* src, int lds, void* dst, int ldd, int lo_off, int M, int K, void* stream);
+/* lx_ln_modulate_segs with a split output: hi at column c, lo at column y_lo_off + c of Y (bf16, ldy >= y_lo_off + D) */
+int lx_ln_modulate_split_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int y_lo_off,
+                              int D, float eps, void* stream);
+/* lx_qkv_prep_segs on an fp32 [M, ld] buffer: per-head RMSNorm + RoPE of q (q_col) and k (k_col) in place, in fp32
+ * (block.py:38-41,60-67,74-78,92-99); v is left alone (the fp32 attention reads it row-major); vt_pos0 of the segments is ignored */
+int lx_qkv_prep_f32_segs(float* QKV, int ld, int q_col, int k_col, const lx_qkv_seg* seg, int n_seg, int n_batches, int H, float eps,
+                         void* stream);
+/* Joint attention (the lx_attn_fwd contract: up to 3 token segments, additive (query segment, key segment) bias, -INFINITY masks
+ * a pair) with fp32 q / k / v read from one [M, ld] buffer at q_col / k_col / v_col (head h at + h*128), exact fp32 products and
+ * accumulation on v_mfma_f32_32x32x2_f32, fp32 online softmax. O (bf16, ldo) gets the output as a hi/lo pair: hi at
+ * o_col + h*128 + d, lo o_lo_off columns further (o_lo_off = 0: hi only). */
+typedef struct lx_attn_f32_desc {
+  const float* QKV; int32_t ld, q_col, k_col, v_col;
+  void* O; int32_t ldo, o_col, o_lo_off;
+  int32_t B, H, n_seg;
+  int32_t seg_row0[3], seg_len[3];
+  float bias[3][3];
+  float scale;
+} lx_attn_f32_desc;
+int lx_attn_fwd_f32(const lx_attn_f32_desc* d, void* stream);
 
 /* x(fp32) += dsigma * v   (FlowMatchEulerDiscreteScheduler.step, generate.py:349); v is bf16 or fp32 */
 int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream);

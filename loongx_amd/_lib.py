@@ -16,7 +16,7 @@ import torch  # noqa: F401  (import order is load-bearing)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
-LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED = 0, 1, 2, 0x100, 0x200
+LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED, LX_EPI_SPLIT_BF16 = 0, 1, 2, 0x100, 0x200, 0x400
 LX_GEMM_MAX_GROUP = 4
 
 
@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ("rows_per_batch", C.c_int32), ("gate_ld", C.c_int32),
                 ("lora_r", C.c_int32), ("lora_ldt", C.c_int32), ("lora_mod_cols", C.c_int32),
                 ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32),
-                ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32)]
+                ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32),
+                ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -37,6 +38,14 @@ class AttnDesc(C.Structure):
                 ("q_col", C.c_int32), ("k_col", C.c_int32), ("o_col", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
                 ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
+                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float)]
+
+
+class AttnF32Desc(C.Structure):
+    _fields_ = [("QKV", C.c_void_p), ("ld", C.c_int32), ("q_col", C.c_int32), ("k_col", C.c_int32), ("v_col", C.c_int32),
+                ("O", C.c_void_p), ("ldo", C.c_int32), ("o_col", C.c_int32), ("o_lo_off", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
+                ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3),
                 ("bias", (C.c_float * 3) * 3), ("scale", C.c_float)]
 
 
@@ -71,6 +80,10 @@ _SIGS = {
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "lx_qkv_prep_fp8_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _P, _I, _P, _I, _F, _F, _F, _P]),
     "lx_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnDesc), _F, _F, _P]),
+    "lx_split_bf16": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "lx_ln_modulate_split_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _I, _F, _P]),
+    "lx_qkv_prep_f32_segs": (C.c_int, [_P, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P]),
+    "lx_attn_fwd_f32": (C.c_int, [C.POINTER(AttnF32Desc), _P]),
     "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),
     "lx_convert": (C.c_int, [_P, _I, _P, _I, _Z, _P]),
     "lx_s4_scan": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -160,7 +160,7 @@ __device__ __forceinline__ void lora_apply(const f32x4 (&u4)[2], const f32x4 (&t
 __device__ __forceinline__ bool lora_in_prologue(const lx_gemm_desc& P) { return P.lora_t != nullptr && P.lora_r <= 4 && P.lora_nsplit <= 4; }
 
 // Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
-template <int BM, int MI>
+template <int BM, int MI, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
                                               int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done, int i_begin = 0, int i_end = MI) {
   // [i_begin, i_end): the 32-row blocks of each wave's tile that this workgroup finishes (all of them, except in the pair kernel)
@@ -239,6 +239,20 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
           if (gelu0) { v0 = gelu_tanh4(v0); v1 = gelu_tanh4(v1); }
           u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
           *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
+          if constexpr (SPLIT) {
+            // precise mode (LX_EPI_SPLIT_BF16): the rounding residual x - bf16(x), itself rounded to bf16, goes c_lo_off columns
+            // further: hi + lo carries 16 mantissa bits of x to the consumer GEMM (which multiplies both, k_segs >= 2)
+            if (P.epilogue & LX_EPI_SPLIT_BF16) {
+              float r[8];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                r[c] = v0[c] - bf16_to_f32(f32_to_bf16(v0[c]));
+                r[4 + c] = v1[c] - bf16_to_f32(f32_to_bf16(v1[c]));
+              }
+              u32x4 ol = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
+              *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol + P.c_lo_off) = ol;
+            }
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -340,7 +354,7 @@ __device__ __forceinline__ void tile_coords(const lx_gemm_desc& P, const int loc
 // K tiles [kt0, kt1) of output tile (m0, n0) accumulated into acc (which the caller has cleared). `after_issue` runs between the
 // issue of the prologue's operand DMA and the wait for it. `smem` = the workgroup's LDS
 // buffer (gemm_lds_bytes<BM>() bytes, 1 KiB aligned). On return no wave reads the operand rings any more.
-template <int BM, class F>
+template <int BM, bool SPLIT = false, class F>
 __device__ __forceinline__ void gemm_mainloop(const lx_gemm_desc& P, const int m0, const int n0, const int tn, const int kt0, const int kt1,
                                               char* smem, f32x16 (&acc)[2][BM / 64], const int tid, F&& after_issue) {
   constexpr int MI = BM / 64;               // 32-row m-blocks per wave
@@ -396,21 +410,42 @@ __device__ __forceinline__ void gemm_mainloop(const lx_gemm_desc& P, const int m
       }
     }
   }
+  // Split-bf16 ("precise") problems run k_segs passes over K in ONE accumulation: segment 0 = A_hi x W_hi, 1 = A_lo x W_hi
+  // (A_lo lives a_lo_off columns after A_hi), 2 = A_hi x W_lo (W is then [N, 2K] = [W_hi | W_lo]). K-tile index t of the loop
+  // -> (segment, tile within the segment) -> source offsets; for !SPLIT the two maps below are the identity.
+  const int nk1 = K / BK;
+  const int kw_tiles = SPLIT && P.k_segs == 3 ? 2 * nk1 : nk1;      // K tiles per weight row block
   const __bf16* a_org = (const __bf16*)P.A + (size_t)m0 * P.lda;
-  const __bf16* w_org = w_tiled ? (const __bf16*)P.W + ((size_t)tn * (K / BK)) * (BN * BK) : (const __bf16*)P.W + (size_t)n0 * P.ldw;
+  const __bf16* w_org = w_tiled ? (const __bf16*)P.W + ((size_t)tn * kw_tiles) * (BN * BK) : (const __bf16*)P.W + (size_t)n0 * P.ldw;
   const lx_rsrc_t rs_a = lx_make_rsrc(a_org), rs_w = lx_make_rsrc(w_org);
   const int w_kstride_b = (w_tiled ? BN * BK : BK) * 2;       // bytes between consecutive K tiles of the W operand
+  auto a_soff = [&](int t) -> int {
+    if constexpr (!SPLIT) return t * (BK * 2);
+    else {
+      const int seg = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+      return (t - seg * nk1) * (BK * 2) + (seg == 1 ? P.a_lo_off * 2 : 0);
+    }
+  };
+  auto w_soff = [&](int t) -> int {
+    if constexpr (!SPLIT) return t * w_kstride_b;
+    else {
+      const int seg = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+      return (t - seg * nk1 + (seg == 2 ? nk1 : 0)) * w_kstride_b;
+    }
+  };
   auto stage_a = [&](int kt, int slot) {
     char* base = smem + slot * A_BYTES;
+    const int so = a_soff(kt0 + kt);
 #pragma unroll
     for (int j = 0; j < MI; ++j)
-      lx_buf_to_lds(rs_a, (lptr_t)(base + (j * 8 + wave) * 1024), aoff[j], (kt0 + kt) * (BK * 2));
+      lx_buf_to_lds(rs_a, (lptr_t)(base + (j * 8 + wave) * 1024), aoff[j], so);
   };
   auto stage_w = [&](int kt, int slot) {
     char* base = smem + W_BASE + slot * W_BYTES;
+    const int so = w_soff(kt0 + kt);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      lx_buf_to_lds(rs_w, (lptr_t)(base + (j * 8 + wave) * 1024), woff[j], (kt0 + kt) * w_kstride_b);
+      lx_buf_to_lds(rs_w, (lptr_t)(base + (j * 8 + wave) * 1024), woff[j], so);
   };
 
   // ---- fragment read offsets -----------------------------------------------------------------------
@@ -528,7 +563,7 @@ __device__ __forceinline__ void acc_clear(f32x16 (&acc)[2][MI]) {
 }
 
 // One whole output tile. `pid` = index of this workgroup among the launch's tiles of height BM.
-template <int BM>
+template <int BM, bool SPLIT = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, char* smem) {
   constexpr int MI = BM / 64;
   // ---- XCD-aware block -> tile map: each XCD (pid & 7) owns a contiguous run of the tile order ----
@@ -552,20 +587,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int pid, c
   const bool lora_early = lora_in_prologue(P);
   f32x4 u4[2], sv[MI][4];
   if (lora_early) lora_issue<MI>(P, n0, m0 + wm * (BM / 2), n0 + wn * 64, l31, 0, 0, u4, sv);
-  gemm_mainloop<BM>(P, m0, n0, tn, 0, P.K / BK, smem, acc, tid, [&]() {
+  const int nkt = SPLIT ? (P.K / BK) * max(P.k_segs, 1) : P.K / BK;
+  gemm_mainloop<BM, SPLIT>(P, m0, n0, tn, 0, nkt, smem, acc, tid, [&]() {
     if (lora_early) {
       f32x4 t4[MI];
       lora_sum<MI>(P, 0, sv, t4);
       lora_apply<MI>(u4, t4, lhi, acc);
     }
   });
-  gemm_epilogue<BM, MI>(P, acc, smem, m0, n0, args.m_base[g], wave, wm, wn, lane, l31, lhi, lora_early);
+  gemm_epilogue<BM, MI, SPLIT>(P, acc, smem, m0, n0, args.m_base[g], wave, wm, wn, lane, l31, lhi, lora_early);
 }
 
 template <int BM>
 __global__ __launch_bounds__(NTHREADS) void lx_gemm_kernel(const GemmArgs args) {
   __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<BM>()];
   gemm_tile<BM>(args, blockIdx.x, smem);
+}
+
+// Precise mode: the same tile with the split-bf16 K map and the hi/lo output split (separate kernels, so that the bf16 fast
+// path above keeps its exact instruction stream).
+template <int BM>
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_split_kernel(const GemmArgs args) {
+  __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<BM>()];
+  gemm_tile<BM, true>(args, blockIdx.x, smem);
 }
 
 // Mixed-height launch: `big` holds full rounds of 256-row tiles, `tail` the remaining rows as 128-row tiles, in ONE grid
@@ -623,7 +667,7 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
   const bool lora_early = lora_in_prologue(P);              // the LoRA term enters once: through workgroup 0 of the pair
   f32x4 u4[2], sv[MI][4];
   if (lora_early && half == 0) lora_issue<MI>(P, n0, m0 + wm * (BM / 2), n0 + wn * 64, l31, 0, 0, u4, sv);
-  gemm_mainloop<BM>(P, m0, n0, tn, half ? kmid : 0, half ? nkt : kmid, smem, acc, tid, [&]() {
+  gemm_mainloop<BM, false>(P, m0, n0, tn, half ? kmid : 0, half ? nkt : kmid, smem, acc, tid, [&]() {
     if (lora_early && half == 0) {
       f32x4 t4[MI];
       lora_sum<MI>(P, 0, sv, t4);
@@ -738,10 +782,13 @@ static lx_gemm_desc sub_rows(const lx_gemm_desc& p, int r0, int rows) {   // row
   return q;
 }
 
-static int launch_plan(const GemmArgs& a, int bm, hipStream_t s) {
+static int launch_plan(const GemmArgs& a, int bm, hipStream_t s, bool split = false) {
   if (a.n == 0) return LX_OK;
   const int t = a.tile_start[a.n];
-  if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, a);
+  if (split) {
+    if (bm == 256) hipLaunchKernelGGL(lx_gemm_split_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL(lx_gemm_split_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, a);
+  } else if (bm == 256) hipLaunchKernelGGL(lx_gemm_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL(lx_gemm_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, a);
   LX_LAUNCH_CHECK("lx_gemm_bf16");
   return LX_OK;
@@ -781,8 +828,16 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
   long t256 = 0, t128 = 0;
   int kmax = 0;
+  bool split = false;
   for (int i = 0; i < n; ++i) {
     const lx_gemm_desc& p = problems[i];
+    LX_CHECK_ARG(p.k_segs >= 0 && p.k_segs <= 3, "lx_gemm_bf16[%d]: k_segs=%d must be 0..3", i, p.k_segs);
+    const int segs = p.k_segs > 1 ? p.k_segs : 1;
+    if (segs > 1 || (p.epilogue & LX_EPI_SPLIT_BF16)) split = true;
+    if (segs > 1) LX_CHECK_ARG(p.a_lo_off >= p.K && p.a_lo_off % 8 == 0 && p.lda >= p.a_lo_off + p.K, "lx_gemm_bf16[%d]: a_lo_off=%d needs K <= a_lo_off, a_lo_off + K <= lda, multiple of 8", i, p.a_lo_off);
+    if (segs == 3) LX_CHECK_ARG(p.ldw >= 2 * p.K, "lx_gemm_bf16[%d]: k_segs = 3 reads W as [N, 2K] = [W_hi | W_lo]: ldw=%d < 2K", i, p.ldw);
+    if (p.epilogue & LX_EPI_SPLIT_BF16) LX_CHECK_ARG((p.epilogue & 0xff) == LX_EPI_STORE_BF16 && p.c_lo_off >= p.N && p.c_lo_off % 8 == 0 && p.ldc >= p.c_lo_off + p.N,
+                                                     "lx_gemm_bf16[%d]: LX_EPI_SPLIT_BF16 needs a bf16 store and N <= c_lo_off, c_lo_off + N <= ldc, multiple of 8", i);
     LX_CHECK_ARG(p.A && p.W && p.C, "lx_gemm_bf16[%d]: NULL operand", i);
     LX_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "lx_gemm_bf16[%d]: bad shape M=%d N=%d K=%d", i, p.M, p.N, p.K);
     LX_CHECK_ARG(p.K % BK == 0, "lx_gemm_bf16[%d]: K=%d must be a multiple of %d", i, p.K, BK);
@@ -793,7 +848,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const int epi = p.epilogue & 0xff;
     LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && epi <= LX_EPI_RESID_F32, "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
     LX_CHECK_ARG(p.rows_per_batch > 0, "lx_gemm_bf16[%d]: rows_per_batch must be > 0", i);
-    if (p.epilogue & LX_W_TILED) LX_CHECK_ARG(p.N % BN == 0 && p.ldw == p.K, "lx_gemm_bf16[%d]: LX_W_TILED needs N %% 256 == 0 and ldw == K", i);
+    if (p.epilogue & LX_W_TILED) LX_CHECK_ARG(p.N % BN == 0 && p.ldw == (segs == 3 ? 2 * p.K : p.K), "lx_gemm_bf16[%d]: LX_W_TILED needs N %% 256 == 0 and ldw == K (2K with k_segs = 3)", i);
     if (p.gate) LX_CHECK_ARG(p.gate_ld >= p.N && p.gate_ld % 4 == 0, "lx_gemm_bf16[%d]: gate_ld=%d", i, p.gate_ld);
     if (p.lora_t) {
       LX_CHECK_ARG(p.lora_up && p.lora_r >= 1 && p.lora_r <= 16, "lx_gemm_bf16[%d]: LoRA needs lora_up and 1 <= r <= 16", i);
@@ -802,9 +857,20 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     if (p.bias) LX_CHECK_ARG(((uintptr_t)p.bias & 15) == 0, "lx_gemm_bf16[%d]: bias must be 16-byte aligned", i);
     t256 += tiles_of(p, 256);
     t128 += tiles_of(p, 128);
-    kmax = p.K > kmax ? p.K : kmax;
+    kmax = p.K * segs > kmax ? p.K * segs : kmax;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (split) {   // precise mode: all 256-row tiles or all 128-row tiles (no mixed / pair plans)
+    const int ncu = device_cus() > 0 ? device_cus() : 256;
+    const double ca = (double)((t256 + ncu - 1) / ncu) * round_us(256, kmax), cb = (double)((t128 + ncu - 1) / ncu) * round_us(128, kmax);
+    const int bm = gemm_env().bm ? gemm_env().bm : (cb < ca ? 128 : 256);
+    GemmArgs all;
+    all.n = 0;
+    all.tile_start[0] = 0;
+    for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+    for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, bm);
+    return launch_plan(all, bm, s, true);
+  }
   const int NCU = device_cus() > 0 ? device_cus() : 256;   // one workgroup per CU: a launch runs in rounds of NCU tiles
   const GemmEnv& env = gemm_env();
   const int forced = env.bm;      // 256 | 128 | 0 = plan

@@ -52,6 +52,10 @@ class DiTEngine:
         # that do not depend on the batch size, i.e. data-parallel shards equal the single-GPU batch bit for bit.
         self.pair_plan = os.environ.get("LX_PAIR_PLAN", "1") != "0"
         self.lora_scale = 1.0            # lora_controller.enable_lora / set_lora_scale drive this (0 = adapters off everywhere)
+        # Precise mode (model_config["precise"], default `precise_default`): fp32-class arithmetic for the reference's shipped
+        # fp32 configuration -- split-bf16 MFMA GEMMs (2 or 3 K-segments), fp32 q/k/v, fp32 attention (csrc/precise.hip).
+        self.precise_default = False
+        self.precise = False
         self._gemm_ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------------------------ workspace
@@ -96,6 +100,22 @@ class DiTEngine:
         self.graphs = {}
         self.shape = (B, T, N, C)
         self.cond_ready = False
+        self.XN2 = self.Y32 = self.YA = self.lat2 = None          # precise-mode buffers, allocated by _setup_precise()
+
+    def _setup_precise(self) -> None:
+        """XN2 bf16 [M, 2D] = [hi | lo] of the AdaLN-normalised stream;  Y32 fp32 [M, 3D] = [k | v | q];
+        YA bf16 [M, 10D] = [attn_hi | mlp_hi | attn_lo | mlp_lo]: the attention output / MLP hidden pairs ([attn | mlp] stays
+        ONE contiguous K = 5D operand, its lo image 5D columns further)."""
+        if self.XN2 is not None:
+            return
+        if not self.w.precise_ready:
+            raise ValueError("precise mode needs weights packed with precise=True (pack_state_dict / LxFluxTransformer.from_state_dict): "
+                             "the bf16 rounding residuals of the weights were not kept")
+        D, dev, bf16 = self.cfg.inner_dim, self.device, torch.bfloat16
+        self.XN2 = torch.zeros(self.M, 2 * D, dtype=bf16, device=dev)
+        self.Y32 = torch.zeros(self.M, 3 * D, dtype=torch.float32, device=dev)
+        self.YA = torch.zeros(self.M, 10 * D, dtype=bf16, device=dev)
+        self.lat2 = torch.zeros(self.B * self.N, 2 * self.cfg.in_channels, dtype=bf16, device=dev)
 
     def set_lora_scale(self, s: float) -> None:
         """Multiplier on every adapter term (reference lora_controller.py: scale_layer). Changes what the captured step graphs
@@ -157,8 +177,16 @@ class DiTEngine:
 
     # ------------------------------------------------------------------------------------------ helpers
     def _lin_skinny(self, x, name, out, act_in=0, act_out=0, accumulate=False):
-        ops.linear_skinny(x, self.w.t[name + ".w"], self.w.t[name + ".b"], out, act_in=act_in, act_out=act_out,
-                          accumulate=accumulate)
+        lo = self.w.t.get(name + ".w_lo") if self.precise else None
+        if lo is None:
+            ops.linear_skinny(x, self.w.t[name + ".w"], self.w.t[name + ".b"], out, act_in=act_in, act_out=act_out,
+                              accumulate=accumulate)
+            return
+        # precise mode, weight not bf16-representable: a second pass over its rounding residual, activation afterwards
+        ops.linear_skinny(x, self.w.t[name + ".w"], self.w.t[name + ".b"], out, act_in=act_in, accumulate=accumulate)
+        ops.linear_skinny(x, lo, None, out, act_in=act_in, accumulate=True)
+        if act_out == 1:
+            torch.nn.functional.silu(out, inplace=True)
 
     def _time_text_embed(self, t1000: torch.Tensor, out: torch.Tensor, base: torch.Tensor) -> None:
         """out = base + timestep_embedder(sinusoid(t1000))   (CombinedTimestep[Guidance]TextProjEmbeddings)."""
@@ -172,12 +200,16 @@ class DiTEngine:
         w = self.w
         if not lora_only:
             ops.linear_skinny(temb, w.t["mod.w"], w.t["mod.b"], out, act_in=1)
+            if self.precise and "mod.w_lo" in w.t:
+                ops.linear_skinny(temb, w.t["mod.w_lo"], None, out, act_in=1, accumulate=True)
         if lora and "mod.lora_down" in w.t and self.lora_scale != 0.0:
             cfg, r, D = self.cfg, self.cfg.lora_r, self.cfg.inner_dim
             nb = cfg.num_layers + cfg.num_single_layers
             rows = temb.shape[0]
             tm = self.tmod[:, : nb * r] if rows == self.B else torch.zeros(rows, nb * r, dtype=torch.float32, device=self.device)
             ops.linear_skinny(temb, w.t["mod.lora_down"], None, tm, act_in=1)
+            if self.precise and "mod.lora_down_lo" in w.t:
+                ops.linear_skinny(temb, w.t["mod.lora_down_lo"], None, tm, act_in=1, accumulate=True)
             if self.lora_scale != 1.0:
                 tm.mul_(self.lora_scale)
             for idx in range(nb):
@@ -221,6 +253,10 @@ class DiTEngine:
         ops.gemm([ops.gemm_desc(torch.cat([hi, lo], 0).contiguous(), self.w.t["mod.w"], acc2, epilogue=LX_EPI_STORE_F32)])
         mods_all = acc2[: n * B]
         mods_all += acc2[n * B:]
+        if self.precise and "mod.w_lo" in self.w.t:          # + silu(temb)_hi . W_lo^T: the third cross term
+            acc3 = torch.empty(n * B, cfg.n_mod, dtype=f32, device=dev)
+            ops.gemm([ops.gemm_desc(hi.contiguous(), self.w.t["mod.w_lo"], acc3, epilogue=LX_EPI_STORE_F32)])
+            mods_all += acc3
         mods_all += self.w.t["mod.b"]
         if self.latent_lora and "mod.lora_down" in self.w.t:
             self._compute_mods(temb_all, mods_all, lora=True, lora_only=True)
@@ -259,15 +295,23 @@ class DiTEngine:
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))
+        self.precise = bool(self.model_config.get("precise", self.precise_default))
+        if self.precise:
+            self._setup_precise()
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
         # context_embedder(prompt_embeds) -> cached text rows
-        pe = prompt_embeds.to(device=dev, dtype=bf16).reshape(B * T, -1).contiguous()
-        ops.gemm([ops.gemm_desc(pe, w.t["context_embedder.w"], self.X_txt_init, bias=w.t["context_embedder.b"],
-                                epilogue=LX_EPI_STORE_F32)])
+        if self.precise:
+            self._embed_p(prompt_embeds.reshape(B * T, -1), "context_embedder", self.X_txt_init, lora=False)
+            if C:
+                self._embed_p(condition_latents.reshape(B * C, -1), "x_embedder", self.X_cond_init, lora=True)
+        else:
+            pe = prompt_embeds.to(device=dev, dtype=bf16).reshape(B * T, -1).contiguous()
+            ops.gemm([ops.gemm_desc(pe, w.t["context_embedder.w"], self.X_txt_init, bias=w.t["context_embedder.b"],
+                                    epilogue=LX_EPI_STORE_F32)])
         # x_embedder(condition_latents) with LoRA active -> cached condition rows
-        if C:
+        if C and not self.precise:
             cl = condition_latents.to(device=dev, dtype=bf16).reshape(B * C, -1).contiguous()
             lo = w.lora.get("x_embedder") if self.lora_scale != 0.0 else None
             tl = None
@@ -409,6 +453,8 @@ class DiTEngine:
 
     # ------------------------------------------------------------------------------------------ blocks
     def double_block(self, i: int) -> None:
+        if self.precise:
+            return self._double_block_p(i)
         cfg, w = self.cfg, self.w
         D = cfg.inner_dim
         b = cfg.mod_base_double(i)
@@ -437,6 +483,8 @@ class DiTEngine:
         proj_out run on the image tokens, transformer.py:243-252). The text and condition rows then still need their keys and
         values (the image queries attend to them) but neither queries, MLP branch nor output projection: 145 + 145 of the
         block's 580 GFLOP of GEMM work are skipped, with bit-identical image rows."""
+        if self.precise:
+            return self._single_block_p(j, image_out_only)
         cfg, w = self.cfg, self.w
         D = cfg.inner_dim
         b = cfg.mod_base_single(j)
@@ -451,10 +499,174 @@ class DiTEngine:
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)
 
+    # ------------------------------------------------------------------------------------------ precise mode
+    def _desc_p(self, A2: torch.Tensor, name: str, Cbuf: torch.Tensor, *, K: int, a_lo_off: int, w_rows: Optional[slice] = None, **kw):
+        """GEMM descriptor of a split-bf16 launch: A2 holds the hi image in columns [0, K) and the lo image a_lo_off columns
+        further; the weight is [W_hi | W_lo] (3 K-segments) when it has a rounding residual, else W (2 segments)."""
+        w2 = self.w.t.get(name + ".w2")
+        W = w2 if w2 is not None else self.w.t[name + ".w"]
+        if w_rows is not None:
+            tiled = getattr(W, "lx_tiled", False)
+            W = W[w_rows]
+            if tiled:
+                W.lx_tiled = True            # row blocks of 256 are contiguous in the tiled image
+        return ops.gemm_desc(A2, W, Cbuf, K=K, N=W.shape[0], k_segs=3 if w2 is not None else 2, a_lo_off=a_lo_off, **kw)
+
+    def _lora_t_p(self, A2: torch.Tensor, name: str, K: int, a_lo_off: int, r0: int, n: int):
+        """t = x A_down^T for rows [r0, r0+n) with x = hi + lo: one slab per cross term (the consumer GEMM adds them).
+        Returns (Lora, number of slabs) or (None, 0)."""
+        lo = self.w.lora.get(name)
+        if lo is None or self.lora_scale == 0.0:
+            return None, 0
+        R = lo.down.shape[0]
+        terms = [(A2[r0:r0 + n, :K], lo.down), (A2[r0:r0 + n, a_lo_off:a_lo_off + K], lo.down)]
+        if lo.down_lo is not None:
+            terms.append((A2[r0:r0 + n, :K], lo.down_lo))
+        for s_, (x, a) in enumerate(terms):
+            ops.lora_down(x, a, self.TLs[s_, r0:r0 + n, :R])
+        if self.lora_scale != 1.0:
+            self.TLs[: len(terms), r0:r0 + n, :R].mul_(self.lora_scale)
+        return lo, len(terms)
+
+    def _embed_p(self, x32: torch.Tensor, name: str, out: torch.Tensor, lora: bool, pair: Optional[torch.Tensor] = None) -> None:
+        """out(fp32) = Linear_name(x32) with x as a hi/lo pair (context_embedder / x_embedder)."""
+        x32 = x32.to(device=self.device, dtype=torch.float32).contiguous()
+        rows, K = x32.shape
+        if pair is None:
+            pair = torch.empty(rows, 2 * K, dtype=torch.bfloat16, device=self.device)
+        ops.split_bf16(x32, pair, K)
+        kw = {}
+        if lora:
+            lo, ns = self._lora_t_p(pair, name, K, K, 0, rows) if rows <= self.TLs.shape[1] else (None, 0)
+            if lo is not None:
+                kw = dict(lora_t=self.TL[:rows], lora_up=lo.up, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0))
+        ops.gemm([self._desc_p(pair, name, out, K=K, a_lo_off=K, bias=self.w.t[name + ".b"], epilogue=LX_EPI_STORE_F32, **kw)])
+
+    def _ln_p(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
+        row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
+        segs = []
+        for s_, L in self._streams():
+            mods = self.cmods if s_ == "cond" else self.mods
+            b0 = base_by_stream[s_]
+            segs.append((row0[s_], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
+        ops.ln_modulate_split_segs(self.X, segs, self.XN2, self.mods.stride(0), self.cfg.inner_dim)
+
+    def _gemm_streams_p(self, A2: torch.Tensor, K: int, a_lo_off: int, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
+                        c_lo_off: int = 0, w_rows: Optional[slice] = None, t_col0: int = 0, gate_off: Optional[Dict[str, int]] = None,
+                        lora_mod_cols: int = 0, lora_toff_max: int = 0, gelu: bool = False, only: Optional[Sequence[str]] = None,
+                        lora_done=None):
+        """The precise twin of _gemm_streams: one grouped split-bf16 launch over the token streams. `w_rows`: row range of the
+        (fused) weight this launch evaluates, `t_col0`: first column of the LoRA slab that belongs to it. Returns the
+        (Lora, slabs, first row) of the LoRA down-projection it computed (or was handed in `lora_done`) for a sibling launch."""
+        w = self.w
+        row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
+        if lora_done is not None:
+            lo, ns, lr0 = lora_done
+        elif (self.C == 0 and not self.latent_lora) or (only is not None and "cond" not in only and not self.latent_lora):
+            lo, ns, lr0 = None, 0, 0
+        else:
+            lr0, n = self._lora_rows(txt is None)
+            lo, ns = self._lora_t_p(A2, main, K, a_lo_off, lr0, n)
+        probs = []
+        for s_, L in self._streams():
+            if only is not None and s_ not in only:
+                continue
+            name = txt if (s_ == "txt" and txt is not None) else main
+            a, c = self.rows(A2, s_), self.rows(Cbuf, s_)
+            bias = w.t[name + ".b"]
+            kw = dict(bias=bias[w_rows] if w_rows is not None else bias, epilogue=epilogue | (LX_EPI_GELU if gelu else 0), rows_per_batch=L,
+                      c_lo_off=c_lo_off)
+            if gate_off is not None:
+                mods = self.cmods if s_ == "cond" else self.mods
+                kw["gate"] = mods[:, gate_off[s_]:]
+            if lo is not None and name == main and row0[s_] >= lr0 and (s_ == "cond" or (s_ == "img" and self.latent_lora) or
+                                                                         (s_ == "txt" and self.latent_lora and txt is None)):
+                up = lo.up[w_rows] if w_rows is not None else lo.up
+                kw.update(lora_t=self.TL[row0[s_]:row0[s_] + a.shape[0], t_col0:], lora_up=up, lora_mod_cols=lora_mod_cols,
+                          lora_toff_max=lora_toff_max, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0))
+            probs.append(self._desc_p(a, name, c, K=K, a_lo_off=a_lo_off, w_rows=w_rows, **kw))
+        ops.gemm(probs)
+        return lo, ns, lr0
+
+    def _attention_p(self, wq, wk, wq_txt, wk_txt) -> None:
+        """fp32 q / k / v in Y32 = [k | v | q]: per-head RMSNorm + RoPE in fp32, fp32 attention, output pair into YA's attn columns."""
+        D, H, B = self.cfg.inner_dim, self.cfg.num_attention_heads, self.B
+        seg_row0, seg_len, qsegs = [], [], []
+        off = 0
+        streams = self._streams()
+        bias = [[0.0] * 3 for _ in range(3)]
+        for qi, (qs, _) in enumerate(streams):
+            for ki, (ks, _) in enumerate(streams):
+                bias[qi][ki] = self.attn_bias[qs][ks]
+        for s_, L in streams:
+            row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s_]
+            if s_ == "cond":
+                cos, sin = self.cos_cond, self.sin_cond
+            elif self.cos_main is None:
+                cos = sin = None
+            else:
+                cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
+                off += L
+            qsegs.append((row0, L, 0, wq_txt if s_ == "txt" else wq, wk_txt if s_ == "txt" else wk, cos, sin))
+            seg_row0.append(row0); seg_len.append(L)
+        ops.qkv_prep_f32_segs(self.Y32, 2 * D, 0, qsegs, B, H)
+        ops.attn_fwd_f32(self.Y32, self.YA, q_col=2 * D, k_col=0, v_col=D, o_col=0, o_lo_off=5 * D, B=B, H=H, seg_row0=seg_row0,
+                         seg_len=seg_len, bias=bias)
+
+    def _double_block_p(self, i: int) -> None:
+        cfg, w = self.cfg, self.w
+        D = cfg.inner_dim
+        b = cfg.mod_base_double(i)
+        base = {"img": b, "cond": b, "txt": b + 6 * D}
+        p = f"d{i}"
+        self._ln_p(base, 0, D)
+        self._gemm_streams_p(self.XN2, D, D, self.Y32, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_F32, lora_mod_cols=D, lora_toff_max=2)
+        self._attention_p(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+        gate = {s_: base[s_] + 2 * D for s_ in base}
+        lora = self._gemm_streams_p(self.YA, D, 5 * D, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
+        if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
+            lo, ns, _ = lora
+            a = self.rows(self.YA, "cond")
+            kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
+            ops.gemm([self._desc_p(a, p + ".out", self.rows(self.X, "img"), K=D, a_lo_off=5 * D, bias=w.t[p + ".out.b"],
+                                   epilogue=LX_EPI_RESID_F32, rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)])
+        self._ln_p(base, 3 * D, 4 * D)
+        Ym = self.YA[:, D:]                                                                   # mlp hidden pair: hi at [D, 5D), lo 5D further
+        self._gemm_streams_p(self.XN2, D, D, Ym, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16, c_lo_off=5 * D, gelu=True)
+        gate = {s_: base[s_] + 5 * D for s_ in base}
+        self._gemm_streams_p(Ym, 4 * D, 5 * D, self.X, p + ".ff2", p + ".ff2_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
+
+    def _single_block_p(self, j: int, image_out_only: bool = False) -> None:
+        cfg, w = self.cfg, self.w
+        D, r = cfg.inner_dim, cfg.lora_r
+        b = cfg.mod_base_single(j)
+        base = {"img": b, "cond": b, "txt": b}
+        p = f"s{j}"
+        self._ln_p(base, 0, D)
+        # the fused [k | v | q | mlp] weight in two launches: q/k/v stay fp32 (Y32), the MLP hidden becomes a GELU'd bf16 pair
+        lora = self._gemm_streams_p(self.XN2, D, D, self.Y32, p + ".fused", None, epilogue=LX_EPI_STORE_F32, w_rows=slice(0, 3 * D),
+                                    lora_mod_cols=D, lora_toff_max=2)
+        only = ("img",) if image_out_only else None
+        self._gemm_streams_p(self.XN2, D, D, self.YA[:, D:], p + ".fused", None, epilogue=LX_EPI_STORE_BF16, c_lo_off=5 * D, gelu=True,
+                             w_rows=slice(3 * D, 7 * D), t_col0=3 * r, only=only, lora_done=lora)
+        self._attention_p(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
+        gate = {s_: b + 2 * D for s_ in base}
+        self._gemm_streams_p(self.YA, 5 * D, 5 * D, self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate, only=only)
+
     # ------------------------------------------------------------------------------------------ one step
     def embed_step_inputs(self, latents: torch.Tensor, timestep: torch.Tensor, mods_ready: bool = False) -> None:
         """x_embedder(latents), reset text/condition rows, temb(t) and every image/text modulation vector."""
         w, cfg = self.w, self.cfg
+        if self.precise:
+            self._embed_p(latents.reshape(self.B * self.N, -1), "x_embedder", self.rows(self.X, "img"), lora=self.latent_lora, pair=self.lat2)
+            self.rows(self.X, "txt").copy_(self.X_txt_init)
+            if self.C:
+                self.rows(self.X, "cond").copy_(self.X_cond_init)
+            if not mods_ready:
+                torch.mul(timestep.to(device=self.device, dtype=torch.float32), 1000.0, out=self.t1000)
+                self._time_text_embed(self.t1000, self.temb, self.temb_base)
+                self._compute_mods(self.temb, self.mods, lora=self.latent_lora)
+            return
         ops.convert(self.lat16, latents.reshape(self.B * self.N, -1).contiguous())
         lo = w.lora.get("x_embedder") if (self.latent_lora and self.lora_scale != 0.0) else None
         tl = None
@@ -478,6 +690,12 @@ class DiTEngine:
         """norm_out (AdaLayerNormContinuous: chunk order scale, shift) + proj_out on the image rows."""
         cfg, w = self.cfg, self.w
         D, o = cfg.inner_dim, cfg.mod_base_out
+        if self.precise:
+            ops.ln_modulate_split_segs(self.X, [(self.r_img, self.B * self.N, self.N, self.mods[:, o + D:], self.mods[:, o:])], self.XN2,
+                                       self.mods.stride(0), D)
+            ops.gemm([self._desc_p(self.rows(self.XN2, "img"), "proj_out", self.out, K=D, a_lo_off=D, bias=w.t["proj_out.b"],
+                                   epilogue=LX_EPI_STORE_F32)])
+            return self.out.view(self.B, self.N, cfg.in_channels)
         ops.ln_modulate(self.rows(self.X, "img"), self.mods[:, o + D:], self.mods[:, o:], self.rows(self.XN, "img"),
                         rows_per_batch=self.N, mod_ld=self.mods.stride(0))
         ops.gemm([ops.gemm_desc(self.rows(self.XN, "img"), w.t["proj_out.w"], self.out, bias=w.t["proj_out.b"],
@@ -516,7 +734,7 @@ class DiTEngine:
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan)
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise)
         g = self.graphs.get(key)
         if g is None:
             if not self._warmed:                                  # lazy code-object loads must not happen inside capture
@@ -576,6 +794,9 @@ class DiTEngine:
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))
+        self.precise = bool(self.model_config.get("precise", self.precise_default))
+        if self.precise:
+            self._setup_precise()
         self.attn_bias = self._attn_bias()
         f32 = torch.float32
         if rope_main is not None:

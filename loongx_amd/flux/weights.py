@@ -73,18 +73,31 @@ class FluxConfig:
 
 
 class Lora:
-    """A_down [n_mod*r, K] bf16 (rows stacked per fused module), B_up [N, r] fp32 (already times alpha/r)."""
-    __slots__ = ("down", "up")
+    """A_down [n_mod*r, K] bf16 (rows stacked per fused module), B_up [N, r] fp32 (already times alpha/r).
+    down_lo: bf16(A - bf16(A)) when the model was packed for precise mode and A is not bf16-representable, else None."""
+    __slots__ = ("down", "up", "down_lo")
 
-    def __init__(self, down: torch.Tensor, up: torch.Tensor):
-        self.down, self.up = down, up
+    def __init__(self, down: torch.Tensor, up: torch.Tensor, down_lo: Optional[torch.Tensor] = None):
+        self.down, self.up, self.down_lo = down, up, down_lo
+
+
+def _hi_lo(w32: torch.Tensor):
+    """fp32 -> (bf16 hi, bf16 lo or None): w = hi + lo to 16 mantissa bits; lo is None when w is bf16-representable."""
+    hi = w32.to(torch.bfloat16)
+    lo = (w32 - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), (lo.contiguous() if bool(lo.any()) else None)
 
 
 @dataclass
 class PackedWeights:
+    """t[name + ".w"]: the bf16 weight (GEMM weights pre-tiled). Packed with precise=True, weights that are NOT
+    bf16-representable also get their rounding residual: GEMM weights as t[name + ".w2"] = [W_hi | W_lo] ([N, 2K], the operand
+    of a k_segs = 3 GEMM), weight-streaming ones as t[name + ".w_lo"]. bf16-representable weights (FLUX.1 checkpoints, the
+    synthetic weights) need neither: precise mode then costs 2 K-segments instead of 3."""
     cfg: FluxConfig
     t: Dict[str, torch.Tensor] = field(default_factory=dict)     # name -> tensor
     lora: Dict[str, Lora] = field(default_factory=dict)          # name -> Lora (absent => no adapter)
+    precise_ready: bool = False                                   # every weight is bf16-exact or carries its residual
 
     def nbytes(self) -> int:
         n = sum(v.numel() * v.element_size() for v in self.t.values())
@@ -130,23 +143,25 @@ def _sd_lora(sd, name: str):
 
 
 def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_scale: float = 1.0,
-                    prefix: str = "") -> PackedWeights:
-    """sd: diffusers FluxTransformer2DModel names (optionally under `prefix`, e.g. 'transformer.')."""
+                    prefix: str = "", precise: bool = False) -> PackedWeights:
+    """sd: diffusers FluxTransformer2DModel names (optionally under `prefix`, e.g. 'transformer.').
+    precise=True keeps the bf16 rounding residual of every weight that has one (see PackedWeights)."""
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     pw = PackedWeights(cfg)
+    pw.precise_ready = bool(precise)
     D = cfg.inner_dim
     ranks: Dict[str, int] = {}
     groups: Dict[str, int] = {}
 
-    def W(names: List[str]) -> torch.Tensor:
+    def W32(names: List[str]) -> torch.Tensor:
         ws = []
         for n in names:
             w = _sd_get(sd, n, "weight")
             if w is None:
                 raise KeyError(f"missing weight for '{n}' in state_dict")
             ws.append(w.float())
-        return torch.cat(ws, 0).to(device=device, dtype=torch.bfloat16).contiguous()
+        return torch.cat(ws, 0).to(device=device).contiguous()
 
     def Bv(names: List[str], sizes: List[int]) -> torch.Tensor:
         bs = []
@@ -164,12 +179,18 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
         for n, p in zip(names, parts):
             ranks[n] = p[0].shape[0]
         groups[names[0]] = len(names)
-        down = torch.cat([p[0].float() for p in parts], 0).to(device=device, dtype=torch.bfloat16).contiguous()
+        down, down_lo = _hi_lo(torch.cat([p[0].float() for p in parts], 0).to(device))
         up = torch.cat([p[1].float() * lora_scale for p in parts], 0).to(device=device, dtype=torch.float32).contiguous()
-        return Lora(down, up)
+        return Lora(down, up, down_lo if precise else None)
 
     def put(name, w_names, out_sizes):
-        pw.t[name + ".w"] = _maybe_tile(name, W(w_names))
+        hi, lo = _hi_lo(W32(w_names))
+        pw.t[name + ".w"] = _maybe_tile(name, hi)
+        if precise and lo is not None:
+            if name.startswith("tte."):                    # weight-streaming linears: a second accumulate pass over the residual
+                pw.t[name + ".w_lo"] = lo
+            else:                                          # GEMM weights: [W_hi | W_lo], the operand of a k_segs = 3 launch
+                pw.t[name + ".w2"] = _maybe_tile(name, torch.cat([hi, lo], 1).contiguous())
         pw.t[name + ".b"] = Bv(w_names, out_sizes)
         l = Lr(w_names)
         if l is not None:
@@ -202,14 +223,18 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], cfg: FluxConfig, device, lora_s
         mod_w.append(_sd_get(sd, p + "norm.linear", "weight").float()); mod_b.append(_sd_get(sd, p + "norm.linear", "bias").float())
         mod_lora.append(_sd_lora(sd, p + "norm.linear"))
     mod_w.append(sd["norm_out.linear.weight"].float()); mod_b.append(sd["norm_out.linear.bias"].float())
-    pw.t["mod.w"] = torch.cat(mod_w, 0).to(device=device, dtype=torch.bfloat16).contiguous()
+    pw.t["mod.w"], mlo = _hi_lo(torch.cat(mod_w, 0).to(device))
+    if precise and mlo is not None:
+        pw.t["mod.w_lo"] = mlo
     pw.t["mod.b"] = torch.cat(mod_b, 0).to(device=device, dtype=torch.float32).contiguous()
     if any(m is not None for m in mod_lora):
         if any(m is None for m in mod_lora):
             raise ValueError("LoRA must cover every norm1.linear / norm.linear or none")
         for idx, m in enumerate(mod_lora):
             ranks[f"mod.{idx}"] = m[0].shape[0]
-        pw.t["mod.lora_down"] = torch.cat([m[0].float() for m in mod_lora], 0).to(device=device, dtype=torch.bfloat16).contiguous()
+        pw.t["mod.lora_down"], dlo = _hi_lo(torch.cat([m[0].float() for m in mod_lora], 0).to(device))
+        if precise and dlo is not None:
+            pw.t["mod.lora_down_lo"] = dlo
         for idx, m in enumerate(mod_lora):
             pw.t[f"mod.lora_up.{idx}"] = (m[1].float() * lora_scale).to(device).contiguous()
     put("x_embedder", ["x_embedder"], [D])
@@ -311,9 +336,11 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
 
 
 def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True) -> PackedWeights:
-    """Random weights of the fused layout generated on the GPU (full FLUX.1-dev scale = 23.8 GB bf16)."""
+    """Random weights of the fused layout generated on the GPU (full FLUX.1-dev scale = 23.8 GB bf16). Drawn in bf16, hence
+    bf16-representable: precise mode needs no residuals for them."""
     g = torch.Generator(device=device).manual_seed(seed)
     pw = PackedWeights(cfg)
+    pw.precise_ready = True
     D, r = cfg.inner_dim, cfg.lora_r
 
     def rn(*shape, dtype=torch.bfloat16, s=std):

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_W_TILED, AttnDesc, GemmDesc, check, lib)
+from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_W_TILED, AttnDesc, GemmDesc, check, lib)
 
 
 def _stream() -> int:
@@ -47,8 +47,11 @@ def tile_weight(W: torch.Tensor) -> torch.Tensor:
 
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
               gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
-              gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0) -> GemmDesc:
-    """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome)."""
+              gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0, k_segs=0, a_lo_off=0,
+              c_lo_off=0) -> GemmDesc:
+    """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome).
+    Precise mode: k_segs = 2 | 3 with A's lo image a_lo_off columns after the hi image (pass K explicitly: A then has more than K
+    columns) and, for 3, W = [N, 2K] = [W_hi | W_lo] (pass N, K); c_lo_off != 0 adds LX_EPI_SPLIT_BF16 (hi/lo output pair)."""
     _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
     d = GemmDesc()
     d.A, d.W, d.C = A.data_ptr(), W.data_ptr(), C_.data_ptr()
@@ -65,6 +68,9 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         d.lora_r, d.lora_ldt = lora_up.shape[1], lora_t.stride(0)
     d.lora_mod_cols, d.lora_toff_max = lora_mod_cols, lora_toff_max
     d.lora_nsplit, d.lora_split_stride = lora_nsplit, lora_split_stride
+    d.k_segs, d.a_lo_off, d.c_lo_off = k_segs, a_lo_off, c_lo_off
+    if c_lo_off:
+        epilogue |= LX_EPI_SPLIT_BF16
     if getattr(W, "lx_tiled", False):
         epilogue |= LX_W_TILED
     d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
@@ -262,6 +268,57 @@ def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bia
         e.record()
         return
     check(lib.lx_attn_fwd_fp8(*args), "lx_attn_fwd_fp8")
+
+
+# ---- precise mode (include/lx.h "Precise mode") -----------------------------------------------------------------------
+def split_bf16(src: torch.Tensor, dst: torch.Tensor, lo_off: int) -> None:
+    """src fp32 [M,K] -> dst bf16 [M, >= lo_off + K]: hi at column k, lo at lo_off + k."""
+    _req(src, torch.float32, "src"); _req(dst, torch.bfloat16, "dst")
+    check(lib.lx_split_bf16(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), lo_off, src.shape[0], src.shape[1], _stream()),
+          "lx_split_bf16")
+
+
+def ln_modulate_split_segs(X, segs, Y, mod_ld, y_lo_off, eps=1e-6) -> None:
+    n = len(segs)
+    arr = (L.LnSeg * n)()
+    for i, (row0, n_rows, rpb, sh, sc) in enumerate(segs):
+        arr[i].row0, arr[i].n_rows, arr[i].rows_per_batch = row0, n_rows, rpb
+        arr[i].shift, arr[i].scale = sh.data_ptr(), sc.data_ptr()
+    check(lib.lx_ln_modulate_split_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, Y.data_ptr(), Y.stride(0), y_lo_off, X.shape[1], eps,
+                                        _stream()), "lx_ln_modulate_split_segs")
+
+
+def qkv_prep_f32_segs(QKV, q_col, k_col, segs, n_batches, H, eps=1e-6) -> None:
+    """segs as in qkv_prep_segs (the vt_pos0 entry is ignored); QKV fp32 [M, ld], q / k normalised + rotated in place."""
+    _req(QKV, torch.float32, "QKV")
+    n = len(segs)
+    arr = (L.QkvSeg * n)()
+    for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
+        arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, 0
+        arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
+    check(lib.lx_qkv_prep_f32_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, arr, n, n_batches, H, eps, _stream()), "lx_qkv_prep_f32_segs")
+
+
+def attn_fwd_f32(QKV, O, *, q_col, k_col, v_col, o_col, o_lo_off, B, H, seg_row0, seg_len, bias=None, scale=None) -> None:
+    _req(QKV, torch.float32, "QKV"); _req(O, torch.bfloat16, "O")
+    d = L.AttnF32Desc()
+    d.QKV, d.ld, d.q_col, d.k_col, d.v_col = QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col
+    d.O, d.ldo, d.o_col, d.o_lo_off = O.data_ptr(), O.stride(0), o_col, o_lo_off
+    d.B, d.H, d.n_seg = B, H, len(seg_len)
+    for i in range(len(seg_len)):
+        d.seg_row0[i], d.seg_len[i] = seg_row0[i], seg_len[i]
+    for i in range(3):
+        for j in range(3):
+            d.bias[i][j] = 0.0 if bias is None else float(bias[i][j])
+    d.scale = (1.0 / math.sqrt(128.0)) if scale is None else scale
+    if TIMER is not None and TIMER.active:
+        S = sum(seg_len)
+        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        s.record()
+        check(lib.lx_attn_fwd_f32(C.byref(d), _stream()), "lx_attn_fwd_f32")
+        e.record()
+        return
+    check(lib.lx_attn_fwd_f32(C.byref(d), _stream()), "lx_attn_fwd_f32")
 
 
 def euler_step(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> None:
