@@ -279,6 +279,23 @@ int lx_duan_fwd(const float* x, const float* c, const float* gw1, const float* g
                 const float* mw1, const float* mb1, const float* mw2, const float* mb2, float* y,
                 int B, int C, int L, int Hd, float eps, int keep_k, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FLUX VAE (diffusers AutoencoderKL; reference call sites src/flux/generate.py:375-380 decode, src/flux/pipeline_tools.py:7-30
+ * encode) -- SURVEY 8f.3, either side of the denoise loop. Convolutions run as implicit GEMMs on lx_gemm_bf16 (im2col rows x
+ * [Cout, 9 Cin] weights); these are the NHWC row kernels around them. bf16 activations, fp32 statistics.
+ * ------------------------------------------------------------------------------------------------ */
+/* y(bf16)[b,p,c] = act(GroupNorm_G(x)[b,p,c] * gamma[c] + beta[c]); x: [B, P, C] fp32 or bf16, statistics per (b, group) over
+ * P pixels x C/G channels in fp32, deterministic (no atomics); silu != 0: act = SiLU. ws: lx_groupnorm_workspace_bytes(). */
+size_t lx_groupnorm_workspace_bytes(int B, int P, int G);
+int lx_groupnorm_silu(const void* x, int x_is_bf16, int B, int P, int C, int G, const float* gamma, const float* beta, float eps,
+                      int silu, void* y, void* ws, size_t ws_bytes, void* stream);
+/* im2col for a 3x3 convolution over NHWC bf16 x[B,H,W,C]: out[(b,yo,xo), (dy*3+dx)*C + c], rows of Kpad >= 9C elements (zero
+ * padded). mode 0: stride 1 / pad 1; mode 1: stride 2 / pad (0,1,0,1) (Downsample2D, padding=0); mode 2: nearest 2x upsample
+ * folded into the gather, then stride 1 / pad 1 (Upsample2D + conv). */
+int lx_im2col3x3(const void* x, int B, int H, int W, int C, int mode, void* out, int Kpad, void* stream);
+/* P(bf16)[m, :] = softmax(scale * S(fp32)[m, :]) -- the single-head mid-block attention of the VAE */
+int lx_softmax_rows(const float* S, int lds, float scale, void* P, int ldp, int M, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,10 @@ _SIGS = {
     "lx_ln_modulate_split_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _I, _F, _P]),
     "lx_qkv_prep_f32_segs": (C.c_int, [_P, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P]),
     "lx_attn_fwd_f32": (C.c_int, [C.POINTER(AttnF32Desc), _P]),
+    "lx_groupnorm_workspace_bytes": (_Z, [_I, _I, _I]),
+    "lx_groupnorm_silu": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _Z, _P]),
+    "lx_im2col3x3": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "lx_softmax_rows": (C.c_int, [_P, _I, _F, _P, _I, _I, _I, _P]),
     "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),
     "lx_convert": (C.c_int, [_P, _I, _P, _I, _Z, _P]),
     "lx_s4_scan": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

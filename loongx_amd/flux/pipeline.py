@@ -81,8 +81,14 @@ class LxFluxPipeline:
     default_sample_size = 64
 
     def __init__(self, transformer, scheduler=None, vae=None, text_encoder=None, image_processor=None):
+        """vae: an `LxAutoencoderKL` (loongx_amd/vae.py) or any object with its encode / decode / config surface;
+        text_encoder: a callable (prompt, prompt_2, max_sequence_length) -> (prompt_embeds, pooled), e.g. `FluxTextEncoders`;
+        image_processor defaults to the diffusers-0.31 `VaeImageProcessor(vae_scale_factor=16)` when a VAE is given."""
         self.transformer = transformer
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+        if vae is not None and image_processor is None:
+            from ..vae import VaeImageProcessor
+            image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
         self.vae, self.text_encoder, self.image_processor = vae, text_encoder, image_processor
         self.device = transformer.device
         self.dtype = torch.float32
@@ -103,6 +109,58 @@ class LxFluxPipeline:
 
     def to(self, *a, **k):
         return self
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda", dtype=torch.bfloat16, flux_config=None, lora_scale: float = 1.0,
+                        load_vae: bool = True, load_text_encoders: bool = True):
+        """A LOCAL diffusers-format FLUX.1 directory (the reference passes a hub id to FluxPipeline.from_pretrained,
+        src/train/model.py:399-401; the box has no hub access): `transformer/` (safetensors, sharded or single) is packed for the
+        MI355X engine; `vae/` becomes an `LxAutoencoderKL`; `text_encoder*/` + `tokenizer*/` a `FluxTextEncoders` (transformers on
+        ROCm). Missing optional parts leave the corresponding slot empty. dtype float32 selects the engine's precise mode."""
+        import json
+        import os
+        from safetensors.torch import load_file
+        from .transformer import LxFluxTransformer
+        from .weights import FluxConfig
+
+        def load_dir(d):
+            idx = [f for f in os.listdir(d) if f.endswith(".safetensors.index.json")]
+            if idx:
+                files = sorted(set(json.load(open(os.path.join(d, idx[0])))["weight_map"].values()))
+            else:
+                files = sorted(f for f in os.listdir(d) if f.endswith(".safetensors"))
+            if not files:
+                raise FileNotFoundError(f"no .safetensors weights in {d}")
+            sd = {}
+            for f in files:
+                sd.update(load_file(os.path.join(d, f)))
+            return sd
+
+        tdir = os.path.join(path, "transformer")
+        if not os.path.isdir(tdir):
+            raise FileNotFoundError(f"{path}: no transformer/ directory (expected a diffusers-format FLUX.1 checkpoint)")
+        cfg = flux_config
+        cj = os.path.join(tdir, "config.json")
+        if cfg is None and os.path.isfile(cj):
+            c = json.load(open(cj))
+            cfg = FluxConfig(num_layers=c.get("num_layers", 19), num_single_layers=c.get("num_single_layers", 38),
+                             num_attention_heads=c.get("num_attention_heads", 24), attention_head_dim=c.get("attention_head_dim", 128),
+                             in_channels=c.get("in_channels", 64), joint_attention_dim=c.get("joint_attention_dim", 4096),
+                             pooled_projection_dim=c.get("pooled_projection_dim", 768), guidance_embeds=c.get("guidance_embeds", True),
+                             axes_dims_rope=tuple(c.get("axes_dims_rope", (16, 56, 56))))
+        tr = LxFluxTransformer.from_state_dict(load_dir(tdir), cfg or FluxConfig(), device, lora_scale, precise=dtype == torch.float32)
+        vae = text = None
+        vdir = os.path.join(path, "vae")
+        if load_vae and os.path.isdir(vdir):
+            from ..vae import LxAutoencoderKL
+            vc = json.load(open(os.path.join(vdir, "config.json"))) if os.path.isfile(os.path.join(vdir, "config.json")) else {}
+            keep = ("in_channels", "out_channels", "latent_channels", "block_out_channels", "layers_per_block", "norm_num_groups",
+                    "scaling_factor", "shift_factor")
+            vae = LxAutoencoderKL(load_dir(vdir), {k: vc[k] for k in keep if k in vc}, device)
+        if load_text_encoders and all(os.path.isdir(os.path.join(path, d)) for d in ("text_encoder", "tokenizer", "text_encoder_2", "tokenizer_2")):
+            from .text import FluxTextEncoders
+            text = FluxTextEncoders.from_pretrained(path, device, dtype)
+        return cls(tr, vae=vae, text_encoder=text)
 
     def load_lora_weights(self, path: str, weight_name: str = "pytorch_lora_weights.safetensors", lora_scale: float = 1.0, **kwargs):
         """diffusers `FluxPipeline.load_lora_weights` for the transformer (model.py:472): `path` is the directory the

@@ -332,6 +332,29 @@ def convert(dst: torch.Tensor, src: torch.Tensor) -> None:
                          dst.numel(), _stream()), "lx_convert")
 
 
+# ---- VAE row kernels (include/lx.h "FLUX VAE") ------------------------------------------------------------------------
+def groupnorm_silu(x: torch.Tensor, gamma, beta, y: torch.Tensor, groups: int = 32, eps: float = 1e-6, silu: bool = True) -> None:
+    """x [B, P, C] fp32|bf16 (contiguous) -> y bf16 [B, P, C]."""
+    B, P, Cc = x.shape
+    _req(y, torch.bfloat16, "y")
+    nb = lib.lx_groupnorm_workspace_bytes(B, P, groups)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib.lx_groupnorm_silu(x.data_ptr(), int(x.dtype == torch.bfloat16), B, P, Cc, groups, gamma.data_ptr(), beta.data_ptr(), eps,
+                                int(silu), y.data_ptr(), ws.data_ptr(), nb, _stream()), "lx_groupnorm_silu")
+
+
+def im2col3x3(x: torch.Tensor, out: torch.Tensor, mode: int = 0) -> None:
+    """x bf16 [B,H,W,C] (contiguous) -> out bf16 [B*Ho*Wo, Kpad]."""
+    _req(x, torch.bfloat16, "x"); _req(out, torch.bfloat16, "out")
+    B, H, W, Cc = x.shape
+    check(lib.lx_im2col3x3(x.data_ptr(), B, H, W, Cc, mode, out.data_ptr(), out.shape[1], _stream()), "lx_im2col3x3")
+
+
+def softmax_rows(S: torch.Tensor, P: torch.Tensor, scale: float) -> None:
+    _req(S, torch.float32, "S"); _req(P, torch.bfloat16, "P")
+    check(lib.lx_softmax_rows(S.data_ptr(), S.stride(0), scale, P.data_ptr(), P.stride(0), S.shape[0], S.shape[1], _stream()), "lx_softmax_rows")
+
+
 # ---- CS3 / DGF -------------------------------------------------------------------------------------------
 def s4_scan(u, lam, w, D, y) -> None:
     B, H, Lq = u.shape

@@ -26,6 +26,44 @@ def _cplx(t: torch.Tensor) -> np.ndarray:
     return a[..., 0] + 1j * a[..., 1]
 
 
+def resolve_s4_block_keys(sd: Dict[str, torch.Tensor], prefix: str, d_model: int) -> Dict[str, str]:
+    """Names of one S4 block's tensors inside a checkpoint: -> {lam, p, q, B, Ct, D, log_step, lin_w, lin_b, ln_g, ln_b}.
+
+    s4torch is neither pinned nor listed by the reference (src/train/model.py:14 imports it; no requirements file names it) and
+    is absent offline, so the exact attribute names of its S4Block / S4Layer cannot be checked here. The names this repo's
+    oracle uses (`s4._lambda_`, `s4._p`, `s4._q`, `s4._B`, `s4._Ct`, `s4.D`, `s4.log_step`, `linear.*`, `norm.*`) are tried first;
+    otherwise the tensors are identified structurally: the S4 parameters by their name stem under any `s4`-like sub-module
+    (with or without the leading underscore), the block's channel mixer as the only [d_model, d_model] matrix outside it (e.g.
+    `pipeline.<i>.weight`), and the LayerNorm as the [d_model] weight/bias pair whose name contains `norm`. Ambiguity raises
+    with the candidate keys listed."""
+    keys = [k[len(prefix):] for k in sd if k.startswith(prefix)]
+    if not keys:
+        raise KeyError(f"no tensors under '{prefix}' in the state dict")
+    out: Dict[str, str] = {}
+
+    def pick(role, cands):
+        cands = sorted(set(cands))
+        if len(cands) != 1:
+            raise KeyError(f"cannot identify the S4 block tensor '{role}' under '{prefix}': candidates {cands or 'none'}; "
+                           f"keys present: {sorted(keys)}")
+        out[role] = prefix + cands[0]
+
+    def stem(k):          # last path component without leading / trailing underscores
+        return k.split(".")[-1].strip("_").lower()
+
+    for role, names in (("lam", ("lambda",)), ("p", ("p",)), ("q", ("q",)), ("B", ("b",)), ("Ct", ("ct", "c_tilde", "ctilde")),
+                        ("D", ("d",)), ("log_step", ("log_step", "logstep"))):
+        pick(role, [k for k in keys if stem(k) in names and "." in k and not k.split(".")[-2].startswith(("norm", "linear", "pipeline"))])
+    s4_keys = {out[r][len(prefix):] for r in out}
+    mats = [k for k in keys if k not in s4_keys and sd[prefix + k].dim() == 2 and tuple(sd[prefix + k].shape) == (d_model, d_model)]
+    pick("lin_w", mats)
+    lw = out["lin_w"][len(prefix):]
+    pick("lin_b", [k for k in keys if k == lw[: -len("weight")] + "bias"])
+    pick("ln_g", [k for k in keys if k.endswith("weight") and "norm" in k.lower() and sd[prefix + k].dim() == 1])
+    pick("ln_b", [k for k in keys if k.endswith("bias") and "norm" in k.lower() and sd[prefix + k].dim() == 1])
+    return out
+
+
 class S4Model:
     """s4torch.S4Model(d_input, d_model, d_output, n_blocks, n, l_max) -- channel-major evaluation.
     y = enc(u); per block: y = LN(Linear(GELU(S4(y))) + y); out = dec(y)."""
@@ -38,17 +76,19 @@ class S4Model:
         self.d_in, self.d_model, self.d_out = self.enc_w.shape[1], self.enc_w.shape[0], self.dec_w.shape[0]
         self.blocks = []
         for i in range(n_blocks):
-            b = f"blocks.{i}."
-            lam, p, q = _cplx(g(b + "s4._lambda_"))[0], _cplx(g(b + "s4._p")), _cplx(g(b + "s4._q"))
-            B, Ct = _cplx(g(b + "s4._B")), _cplx(g(b + "s4._Ct"))
-            step = np.exp(g(b + "s4.log_step").detach().cpu().double().numpy())
+            kk = resolve_s4_block_keys(sd, f"{prefix}blocks.{i}.", self.d_model)
+            n = sd[kk["p"]].shape[-2]
+            lam = _cplx(sd[kk["lam"]]).reshape(-1, n)[0]                  # stored [1, n, 2] (or with more leading singleton dims)
+            p, q = _cplx(sd[kk["p"]]).reshape(n), _cplx(sd[kk["q"]]).reshape(n)
+            B, Ct = _cplx(sd[kk["B"]]).reshape(self.d_model, n), _cplx(sd[kk["Ct"]]).reshape(self.d_model, n)
+            step = np.exp(sd[kk["log_step"]].detach().cpu().double().numpy().reshape(-1))
             lam_bar, w = s4_params.modal_form(lam, p, q, B, Ct, step, l_max)
             blk = dict(
                 lam=torch.from_numpy(np.stack([lam_bar.real, lam_bar.imag], -1)).to(device).contiguous(),
                 w=torch.from_numpy(np.stack([w.real, w.imag], -1)).to(device).contiguous(),
-                D=_f32(g(b + "s4.D").reshape(-1), device),
-                lin_w=_f32(g(b + "linear.weight"), device), lin_b=_f32(g(b + "linear.bias"), device),
-                ln_g=_f32(g(b + "norm.weight"), device), ln_b=_f32(g(b + "norm.bias"), device))
+                D=_f32(sd[kk["D"]].reshape(-1), device),
+                lin_w=_f32(sd[kk["lin_w"]], device), lin_b=_f32(sd[kk["lin_b"]], device),
+                ln_g=_f32(sd[kk["ln_g"]], device), ln_b=_f32(sd[kk["ln_b"]], device))
             if use_conv:
                 blk["K"] = torch.from_numpy(s4_params.kernel_from_modes(lam_bar, w, l_max)).float().to(device).contiguous()
             self.blocks.append(blk)
@@ -323,44 +363,138 @@ def synthetic_cs3_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
 
 
 class OminiModel(CS3DGF):
-    """Inference surface of the reference's `OminiModel` (model.py:376-511, 731-779) that `generate()` and
+    """Inference surface of the reference's `OminiModel` (src/train/model.py:376-511, 731-779) that `generate()` and
     `inference.py` consume: `.flux_pipe`, `.transformer`, `.model_config`, `.device`, the four `*_projection` encoders,
-    `fuse_eeg` / `fuse_fnirs`, the DUAN instances and `spatial_pyramid_pooling`.  Training (LoRA init, optimizers,
-    `training_step`) is out of scope.  Weights come from a Lightning-style full state_dict (inference.py:46-53:
-    `transformer.*` + the brain-side modules) or are synthetic."""
+    `fuse_eeg` / `fuse_fnirs`, the DUAN instances, `spatial_pyramid_pooling`, `load_lora`, `load_state_dict`, `.to`, `.eval`.
+    Training (LoRA init, optimizers, `training_step`) is out of scope.
 
-    def __init__(self, flux_pipe, cs3_state_dict: Dict[str, torch.Tensor], model_config: Optional[dict] = None, device="cuda",
-                 use_brain_condition: bool = True, fuse_flag: bool = True):
-        super().__init__(cs3_state_dict, device)
-        self.flux_pipe = flux_pipe
-        self.transformer = flux_pipe.transformer
+    Same constructor keywords as the reference (model.py:377-389):
+
+        OminiModel(flux_pipe_id=..., lora_path=None, lora_config=None, device="cuda", dtype=torch.bfloat16, model_config={},
+                   optimizer_config=None, gradient_checkpointing=False, use_brain_condition=True, fuse_flag=True)
+
+    `flux_pipe_id`: a local diffusers-format FLUX.1 directory (there is no hub access on the box; `transformer/`, and when
+    present `vae/`, `text_encoder*/`, `tokenizer*/`, are loaded by `LxFluxPipeline.from_pretrained`), or None / "synthetic":
+    the transformer and the brain-side modules are then created by `load_state_dict` from a full LoongX checkpoint
+    (inference.py:46-53: keys `transformer.<diffusers names, optionally PEFT-wrapped>` + `eeg_projection.*`, `fusion1.*`,
+    `duan_norm1.*` ...). `dtype=torch.float32` (the reference's shipped config, train/config/seed_512.yaml:2) selects the
+    engine's precise mode; bfloat16 the bf16 MFMA mode. `lora_config` supplies the adapter scale alpha / r.
+    (An `LxFluxPipeline` object and a state dict may also be passed positionally -- the form the tests and bench.py use.)"""
+
+    def __init__(self, flux_pipe_id=None, lora_path=None, lora_config: Optional[dict] = None, device="cuda",
+                 dtype: torch.dtype = torch.bfloat16, model_config: Optional[dict] = None, optimizer_config: Optional[dict] = None,
+                 gradient_checkpointing: bool = False, use_brain_condition: bool = True, fuse_flag: bool = True, *,
+                 flux_config=None):
+        # back-compatible positional form: OminiModel(flux_pipe, cs3_state_dict, model_config, device)
+        pipe_obj = flux_pipe_id if hasattr(flux_pipe_id, "transformer") else None
+        cs3_sd = lora_path if isinstance(lora_path, dict) else None
+        if pipe_obj is not None:
+            if isinstance(lora_config, dict) and model_config is None and "r" not in lora_config and "lora_alpha" not in lora_config:
+                model_config, lora_config = lora_config, None
+            lora_path = None
+        self.device = torch.device(device if not (device == "cuda" and not torch.cuda.is_available()) else "cpu")
+        self._dtype = dtype
+        self.precise = dtype == torch.float32
         self.model_config = dict(model_config or {})
+        self.optimizer_config = optimizer_config
+        self.lora_config = dict(lora_config or {})
+        self.lora_scale = float(self.lora_config.get("lora_alpha", 4)) / float(self.lora_config.get("r", 4)) if self.lora_config else 1.0
         self.use_brain_condition, self.fuse_flag = use_brain_condition, fuse_flag
+        self.eeg_fixed_length, self.fnirs_fixed_length, self.ppg_fixed_length, self.motion_fixed_length = 4096, 512, 256, 128
+        self.flux_config = flux_config
+        self.flux_pipe = self.transformer = None
+        self._brain_ready = False
+        if pipe_obj is not None:
+            self._set_pipe(pipe_obj)
+        elif flux_pipe_id not in (None, "", "synthetic"):
+            from ..flux.pipeline import LxFluxPipeline
+            self._set_pipe(LxFluxPipeline.from_pretrained(flux_pipe_id, device=self.device, dtype=dtype, flux_config=flux_config,
+                                                          lora_scale=self.lora_scale))
+        if cs3_sd is not None:
+            self._build_brain(cs3_sd)
+        if isinstance(lora_path, str) and lora_path:
+            self.load_lora(lora_path)
 
-    @classmethod
-    def from_state_dict(cls, state_dict: Dict[str, torch.Tensor], flux_config=None, model_config=None, device="cuda",
-                        lora_scale: float = 1.0):
-        """state_dict in the reference's checkpoint naming: `transformer.<diffusers names>` + `eeg_projection.*` ... """
+    # ---- construction helpers ---------------------------------------------------------------------------------
+    def _set_pipe(self, pipe) -> None:
+        self.flux_pipe = pipe
+        self.transformer = pipe.transformer
+        if self.precise and hasattr(self.transformer, "engine"):
+            self.transformer.engine.precise_default = True
+
+    def _build_brain(self, sd: Dict[str, torch.Tensor]) -> None:
+        CS3DGF.__init__(self, sd, self.device)
+        self._brain_ready = True
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """A full LoongX checkpoint in the reference's naming (what `torch.load(ckpt)["state_dict"]` holds, inference.py:46-53):
+        `transformer.*` (diffusers FluxTransformer2DModel names, PEFT-wrapped where LoRA is attached) rebuilds the packed DiT
+        weights, everything else the CS3 encoders / DGF modules. With strict=True keys that belong to neither raise."""
         from ..flux.pipeline import LxFluxPipeline
         from ..flux.transformer import LxFluxTransformer
         from ..flux.weights import FluxConfig
-        tr = LxFluxTransformer.from_state_dict(state_dict, flux_config or FluxConfig(), device, lora_scale, prefix="transformer.")
-        return cls(LxFluxPipeline(tr), state_dict, model_config, device)
+        sd = state_dict
+        tkeys = [k for k in sd if k.startswith("transformer.")]
+        if tkeys:
+            tr = LxFluxTransformer.from_state_dict(sd, self.flux_config or FluxConfig(), self.device, self.lora_scale,
+                                                   prefix="transformer.", precise=self.precise)
+            if self.flux_pipe is None:
+                self._set_pipe(LxFluxPipeline(tr))
+            else:                                            # keep the pipeline's VAE / text encoders, swap the transformer
+                self.flux_pipe.transformer = tr
+                self._set_pipe(self.flux_pipe)
+        elif self.flux_pipe is None:
+            raise KeyError("load_state_dict: no 'transformer.*' keys and no pipeline was constructed (flux_pipe_id=None)")
+        brain_prefixes = ("eeg_projection.", "ppg_projection.", "fnirs_projection.", "motion_projection.", "fusion1.", "fusion2.",
+                          "fusion3.", "fusion4.", "duan_norm1.", "duan_norm2.", "duan_norm_prompt.", "duan_norm_pooled.")
+        if any(k.startswith(brain_prefixes) for k in sd):
+            self._build_brain(sd)
+        elif strict and not self._brain_ready:
+            raise KeyError("load_state_dict: the checkpoint holds none of the brain-side modules (eeg_projection.*, fusion1.*, duan_norm1.* ...)")
+        if strict:
+            unknown = [k for k in sd if not k.startswith(("transformer.",) + brain_prefixes)]
+            if unknown:
+                raise KeyError(f"load_state_dict: unexpected keys {unknown[:5]}{' ...' if len(unknown) > 5 else ''}")
+        return self
+
+    def state_dict_keys_expected(self):
+        """(documentation helper) the top-level prefixes load_state_dict understands."""
+        return ("transformer.", "eeg_projection.", "ppg_projection.", "fnirs_projection.", "motion_projection.", "fusion1..4.",
+                "duan_norm1.", "duan_norm2.", "duan_norm_prompt.", "duan_norm_pooled.")
 
     @classmethod
-    def synthetic(cls, flux_config=None, model_config=None, device="cuda", seed: int = 0):
+    def from_state_dict(cls, state_dict: Dict[str, torch.Tensor], flux_config=None, model_config=None, device="cuda",
+                        lora_scale: float = 1.0, dtype: torch.dtype = torch.bfloat16):
+        """state_dict in the reference's checkpoint naming: `transformer.<diffusers names>` + `eeg_projection.*` ... """
+        m = cls(None, device=device, dtype=dtype, model_config=model_config, flux_config=flux_config)
+        m.lora_scale = lora_scale
+        return m.load_state_dict(state_dict)
+
+    @classmethod
+    def synthetic(cls, flux_config=None, model_config=None, device="cuda", seed: int = 0, dtype: torch.dtype = torch.bfloat16):
         from ..flux.pipeline import LxFluxPipeline
         from ..flux.transformer import LxFluxTransformer
-        tr = LxFluxTransformer.synthetic(flux_config, device, seed)
-        return cls(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device)
+        tr = LxFluxTransformer.synthetic(flux_config, device, seed, precise=dtype == torch.float32)
+        return cls(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device, dtype=dtype)
 
     def load_lora(self, checkpoint_path: str):
         """model.py:463-477: load LoRA weights from a checkpoint directory into the pipeline's transformer."""
-        self.flux_pipe.load_lora_weights(checkpoint_path)
+        self.flux_pipe.load_lora_weights(checkpoint_path, lora_scale=self.lora_scale)
         return self
+
+    @property
+    def dtype(self):
+        return self._dtype
 
     def eval(self):
         return self
 
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("training is outside the MI355X denoise hot path (SURVEY 2.1)")
+        return self
+
     def to(self, *a, **k):
+        """The weights live where the constructor put them (one MI355X per process); `.to("cuda")` / `.to(dtype)` are accepted
+        for call-site compatibility (inference.py:55-56) and change nothing."""
         return self

@@ -1,0 +1,120 @@
+"""FLUX VAE on MI355X (loongx_amd/vae.py + csrc/vae.hip) vs torch / the oracle AutoencoderKL restatement (oracle/vae.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae as ovae  # noqa: E402
+from tests.helpers import relerr  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from loongx_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("C,P,bf16", [(128, 64 * 64, False), (256, 300, True), (512, 4096, False), (512, 64, True)])
+def test_groupnorm_silu(ops, C, P, bf16):
+    B = 2
+    x = rnd(B, P, C, seed=1, scale=2.0) + 0.5
+    if bf16:
+        x = x.to(torch.bfloat16)
+    g, b = rnd(C, seed=2) * 0.2 + 1.0, rnd(C, seed=3) * 0.2
+    for silu in (True, False):
+        y = torch.empty(B, P, C, dtype=torch.bfloat16, device=DEV)
+        ops.groupnorm_silu(x, g, b, y, 32, 1e-6, silu)
+        ref = F.group_norm(x.float().permute(0, 2, 1), 32, g, b, 1e-6)
+        ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+        assert relerr(y.float(), ref) < 4e-3
+    y2 = torch.empty_like(y)
+    ops.groupnorm_silu(x, g, b, y2, 32, 1e-6, False)
+    assert torch.equal(y, y2)                                   # deterministic: no atomics in the statistics
+
+
+@pytest.mark.parametrize("C,mode", [(16, 0), (128, 0), (3, 0), (128, 1), (64, 2)])
+def test_im2col_conv_equals_conv2d(ops, C, mode):
+    """im2col + GEMM == F.conv2d for the three gather modes (pad-1, the encoder's stride-2 (0,1,0,1) downsample, the decoder's
+    nearest-2x-upsample + conv)."""
+    B, H, W, Co = 2, 12, 10, 32
+    x = rnd(B, C, H, W, seed=4).to(torch.bfloat16)
+    w = rnd(Co, C, 3, 3, seed=5, scale=0.1).to(torch.bfloat16)
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode == 2 else (H, W))
+    Kp = (9 * C + 63) // 64 * 64
+    cols = torch.full((B * Ho * Wo, Kp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.im2col3x3(x.permute(0, 2, 3, 1).contiguous(), cols, mode)
+    Wm = torch.zeros(Co, Kp, dtype=torch.bfloat16, device=DEV)
+    Wm[:, : 9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    out = torch.empty(B * Ho * Wo, Co, dtype=torch.float32, device=DEV)
+    ops.gemm([ops.gemm_desc(cols, Wm, out, epilogue=ops.LX_EPI_STORE_F32)])
+    xf, wf = x.float(), w.float()
+    if mode == 1:
+        ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), wf, stride=2)
+    elif mode == 2:
+        ref = F.conv2d(F.interpolate(xf, scale_factor=2.0, mode="nearest"), wf, padding=1)
+    else:
+        ref = F.conv2d(xf, wf, padding=1)
+    assert relerr(out.view(B, Ho, Wo, Co).permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_softmax_rows(ops):
+    S = rnd(200, 4096, seed=6, scale=3.0)
+    P = torch.empty(200, 4096, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_rows(S, P, 0.25)
+    assert relerr(P.float(), torch.softmax(S * 0.25, -1)) < 4e-3
+
+
+def _pair(cfg, seed):
+    from loongx_amd.vae import LxAutoencoderKL
+    ref = ovae.init_synthetic_(ovae.AutoencoderKL(**cfg), seed)
+    return ref, LxAutoencoderKL(ref.state_dict(), cfg, DEV)
+
+
+SMALL = dict(in_channels=3, out_channels=3, latent_channels=16, block_out_channels=(128, 256), layers_per_block=1, norm_num_groups=32)
+
+
+@pytest.mark.parametrize("cfg,hw", [(SMALL, 32), (dict(), 64)])
+def test_vae_encode_decode_vs_oracle(ops, cfg, hw):
+    """Whole encoder and decoder (resnets, down / up samplers, mid-block attention, output heads) vs the fp32 oracle; the second
+    case is the full FLUX.1 VAE shape (128, 256, 512, 512) x 2 layers, 84 M parameters."""
+    ref, lx = _pair(cfg, seed=3)
+    nd = len(ref.config.block_out_channels) - 1
+    img = torch.rand(2, 3, hw, hw, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    with torch.no_grad():
+        want = ref.encode(img).latent_dist
+    got = lx.encode(img.to(DEV)).latent_dist
+    assert got.mean.shape == (2, 16, hw >> nd, hw >> nd)
+    assert relerr(got.mean.cpu(), want.mean) < 2e-2 and relerr(got.std.cpu(), want.std) < 2e-2
+    noise = torch.randn(want.mean.shape, generator=torch.Generator().manual_seed(2))
+    assert relerr(got.sample(noise=noise.to(DEV)).cpu(), want.sample(noise=noise)) < 2e-2
+    z = torch.randn(2, 16, hw >> nd, hw >> nd, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        wimg = ref.decode(z, return_dict=False)[0]
+    gimg = lx.decode(z.to(DEV), return_dict=False)[0]
+    assert gimg.shape == (2, 3, hw, hw) and gimg.dtype == torch.float32
+    assert relerr(gimg.cpu(), wimg) < 2e-2
+    assert torch.equal(gimg, lx.decode(z.to(DEV)).sample)        # deterministic
+
+
+def test_image_processor_roundtrip():
+    from PIL import Image
+    import numpy as np
+    from loongx_amd.vae import VaeImageProcessor
+    ip = VaeImageProcessor(vae_scale_factor=16)
+    a = (np.random.default_rng(0).random((50, 70, 3)) * 255).astype("uint8")
+    x = ip.preprocess(Image.fromarray(a))
+    assert x.shape == (1, 3, 48, 64) and float(x.min()) >= -1 and float(x.max()) <= 1           # floored to multiples of 16
+    b = (np.random.default_rng(1).random((64, 32, 3)) * 255).astype("uint8")
+    x = ip.preprocess(Image.fromarray(b))
+    back = ip.postprocess(x, "pil")[0]
+    assert np.array_equal(np.asarray(back), b)
+    assert ip.postprocess(x, "pt").shape == (1, 3, 64, 32) and ip.postprocess(x, "latent") is x
