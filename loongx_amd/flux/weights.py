@@ -57,6 +57,24 @@ class FluxConfig:
     def inner_dim(self) -> int:
         return self.num_attention_heads * self.attention_head_dim
 
+    @classmethod
+    def from_state_dict(cls, sd, prefix: str = "", axes_dims_rope=(16, 56, 56), attention_head_dim: int = 128) -> "FluxConfig":
+        """Read the architecture off a diffusers FluxTransformer2DModel state dict (block counts, widths, guidance embedder)."""
+        def w(name):
+            for k in (f"{prefix}{name}.weight", f"{prefix}{name}.base_layer.weight"):
+                if k in sd:
+                    return sd[k]
+            raise KeyError(f"'{prefix}{name}.weight' not in the state dict")
+        pat_d, pat_s = re.compile(re.escape(prefix) + r"transformer_blocks\.(\d+)\."), re.compile(re.escape(prefix) + r"single_transformer_blocks\.(\d+)\.")
+        nd = max((int(m.group(1)) for m in map(pat_d.match, sd) if m), default=-1) + 1
+        ns = max((int(m.group(1)) for m in map(pat_s.match, sd) if m), default=-1) + 1
+        xe = w("x_embedder")
+        return cls(num_layers=nd, num_single_layers=ns, num_attention_heads=xe.shape[0] // attention_head_dim,
+                   attention_head_dim=attention_head_dim, in_channels=xe.shape[1], joint_attention_dim=w("context_embedder").shape[1],
+                   pooled_projection_dim=w("time_text_embed.text_embedder.linear_1").shape[1],
+                   guidance_embeds=any(k.startswith(prefix + "time_text_embed.guidance_embedder.") for k in sd),
+                   axes_dims_rope=tuple(axes_dims_rope))
+
     @property
     def n_mod(self) -> int:
         return (12 * self.num_layers + 3 * self.num_single_layers + 2) * self.inner_dim

@@ -434,10 +434,16 @@ class OminiModel(CS3DGF):
         from ..flux.transformer import LxFluxTransformer
         from ..flux.weights import FluxConfig
         sd = state_dict
+        brain_prefixes = ("eeg_projection.", "ppg_projection.", "fnirs_projection.", "motion_projection.", "fusion1.", "fusion2.",
+                          "fusion3.", "fusion4.", "duan_norm1.", "duan_norm2.", "duan_norm_prompt.", "duan_norm_pooled.")
+        if strict:                                           # before anything is rebuilt
+            unknown = [k for k in sd if not k.startswith(("transformer.",) + brain_prefixes)]
+            if unknown:
+                raise KeyError(f"load_state_dict: unexpected keys {unknown[:5]}{' ...' if len(unknown) > 5 else ''}")
         tkeys = [k for k in sd if k.startswith("transformer.")]
         if tkeys:
-            tr = LxFluxTransformer.from_state_dict(sd, self.flux_config or FluxConfig(), self.device, self.lora_scale,
-                                                   prefix="transformer.", precise=self.precise)
+            cfg = self.flux_config or FluxConfig.from_state_dict(sd, "transformer.")
+            tr = LxFluxTransformer.from_state_dict(sd, cfg, self.device, self.lora_scale, prefix="transformer.", precise=self.precise)
             if self.flux_pipe is None:
                 self._set_pipe(LxFluxPipeline(tr))
             else:                                            # keep the pipeline's VAE / text encoders, swap the transformer
@@ -445,16 +451,10 @@ class OminiModel(CS3DGF):
                 self._set_pipe(self.flux_pipe)
         elif self.flux_pipe is None:
             raise KeyError("load_state_dict: no 'transformer.*' keys and no pipeline was constructed (flux_pipe_id=None)")
-        brain_prefixes = ("eeg_projection.", "ppg_projection.", "fnirs_projection.", "motion_projection.", "fusion1.", "fusion2.",
-                          "fusion3.", "fusion4.", "duan_norm1.", "duan_norm2.", "duan_norm_prompt.", "duan_norm_pooled.")
         if any(k.startswith(brain_prefixes) for k in sd):
             self._build_brain(sd)
         elif strict and not self._brain_ready:
             raise KeyError("load_state_dict: the checkpoint holds none of the brain-side modules (eeg_projection.*, fusion1.*, duan_norm1.* ...)")
-        if strict:
-            unknown = [k for k in sd if not k.startswith(("transformer.",) + brain_prefixes)]
-            if unknown:
-                raise KeyError(f"load_state_dict: unexpected keys {unknown[:5]}{' ...' if len(unknown) > 5 else ''}")
         return self
 
     def state_dict_keys_expected(self):
