@@ -268,6 +268,15 @@ int lx_layernorm_relu(float* x, const float* g, const float* b, int M, int D, fl
 int lx_linear_f32(const float* X, int ldx, int x_trans, const float* W, int ldw, const float* bias, float* Y, int ldy,
                   int y_trans, int M, int N, int K, int accumulate, void* stream);
 
+/* Channel-major fp32 GEMM on the f32-input MFMA (exact fp32 products):
+ *   Y[b][n][l] = epi(sum_k W[n][k] * X[b][k][l] + bias[n]),  X: [B, K, L] (row stride ldx, batch stride x_bstride), Y: [B, N, L].
+ * A Linear / 1x1 convolution over the channel axis at every position of a [B, C, L] activation without a transpose: fuse_eeg's
+ * Linear(1024 -> 512) (model.py:731-755) and the DUAN gate's two convolutions (model.py:947-1035).
+ * epilogue 0: store; 1: Y += ...; 2: ReLU; 3: sigmoid, then summed over each 64-position tile into
+ * part[b][ceil(L/64)][N] (Y unused) -- deterministic, no atomics. */
+int lx_chan_gemm_f32(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride,
+                     int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DGF (Dynamic Gated Fusion; `DUAN` in the reference, src/train/model.py:947-1035). fp32 [B,C,L].
  * gate: conv1x1 C->Hd (gw1 [Hd,C], gb1) ReLU conv1x1 Hd->C (gw2 [C,Hd], gb2) sigmoid, averaged over L;

@@ -96,6 +96,7 @@ _SIGS = {
     "lx_pyramid_pool": (C.c_int, [_P, _P, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P]),
     "lx_layernorm_relu": (C.c_int, [_P, _P, _P, _I, _I, _F, _P]),
     "lx_linear_f32": (C.c_int, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lx_chan_gemm_f32": (C.c_int, [_P, C.c_long, _I, _P, _I, _P, _P, C.c_long, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lx_duan_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "lx_duan_fwd": (C.c_int, [_P] * 11 + [_I, _I, _I, _I, _F, _I, _P, _Z, _P]),
 }

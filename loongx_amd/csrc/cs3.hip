@@ -83,6 +83,92 @@ __global__ __launch_bounds__(64) void s4_scan_kernel(const float* __restrict__ u
   for (int j = 0; j < CH; ++j) yp[j] = (float)(yacc[j] + dk * (double)uf[j]);
 }
 
+// The same scan with NW waves per sequence (block = NW x 64 lanes, lane g owns time steps [g*CH, (g+1)*CH)): a [B, H] = [1, 64]
+// layer is 64 one-wave blocks on a 256-CU part with the kernel above; four waves per sequence put a wave on every CU and
+// shorten each lane's serial recurrence 4x. Wave totals travel through LDS (double-buffered: one barrier per mode), the carry
+// into wave w is the NW-term recurrence C_w = T_{w-1} + lam^(64 CH) C_{w-1}, and lane i adds lam^(CH i) C_w to its in-wave
+// prefix -- the powers fall out of the Kogge-Stone squaring chain.
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void s4_scan_mw_kernel(const float* __restrict__ u, const double* __restrict__ lam,
+                                                           const double* __restrict__ w, const float* __restrict__ Dskip,
+                                                           float* __restrict__ y, int H, int L, int N) {
+  __shared__ double tot[2][NW][2];
+  const int bh = blockIdx.x, h = bh % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = wave * 64 + lane;
+  const float* up = u + (size_t)bh * L + g * CH;
+  float uf[CH];
+  if constexpr (CH % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < CH; j += 4) {
+      const f32x4 v = *(const f32x4*)(up + j);
+      uf[j] = v[0]; uf[j + 1] = v[1]; uf[j + 2] = v[2]; uf[j + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) uf[j] = up[j];
+  }
+  double yacc[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) yacc[j] = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const double lr = lam[((size_t)h * N + n) * 2], li = lam[((size_t)h * N + n) * 2 + 1];
+    const double wr = w[((size_t)h * N + n) * 2], wi = w[((size_t)h * N + n) * 2 + 1];
+    double er = 0.0, ei = 0.0, qr = 1.0, qi = 0.0;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const double tr = lr * er - li * ei + (double)uf[j];
+      ei = lr * ei + li * er;
+      er = tr;
+      const double t2 = qr * lr - qi * li;
+      qi = qr * li + qi * lr;
+      qr = t2;
+    }
+    double xr = er, xi = ei, pr = 1.0, pi = 0.0;         // p = (lam^CH)^lane, built from the squaring chain
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double sr = __shfl_up(xr, d, 64), si = __shfl_up(xi, d, 64);
+      if (lane >= d) {
+        xr += qr * sr - qi * si;
+        xi += qr * si + qi * sr;
+      }
+      if (lane & d) {
+        const double t = pr * qr - pi * qi;
+        pi = pr * qi + pi * qr;
+        pr = t;
+      }
+      const double t2 = qr * qr - qi * qi;
+      qi = 2.0 * qr * qi;
+      qr = t2;
+    }                                                     // now q = lam^(64 CH)
+    if (lane == 63) { tot[n & 1][wave][0] = xr; tot[n & 1][wave][1] = xi; }
+    __syncthreads();
+    double cr = 0.0, ci = 0.0;                            // carry into this wave
+#pragma unroll
+    for (int v = 0; v < NW - 1; ++v)
+      if (v < wave) {
+        const double t = qr * cr - qi * ci + tot[n & 1][v][0];
+        ci = qr * ci + qi * cr + tot[n & 1][v][1];
+        cr = t;
+      }
+    double sr = __shfl_up(xr, 1, 64), si = __shfl_up(xi, 1, 64);
+    if (lane == 0) { sr = 0.0; si = 0.0; }
+    sr += pr * cr - pi * ci;
+    si += pr * ci + pi * cr;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const double tr = lr * sr - li * si + (double)uf[j];
+      si = lr * si + li * sr;
+      sr = tr;
+      yacc[j] += wr * sr - wi * si;
+    }
+  }
+  const double dk = (double)Dskip[h];
+  float* yp = y + (size_t)bh * L + g * CH;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) yp[j] = (float)(yacc[j] + dk * (double)uf[j]);
+}
+
 // direct causal convolution: block per (b,h); K and u staged in LDS
 __global__ __launch_bounds__(256) void s4_conv_kernel(const float* __restrict__ u, const float* __restrict__ Kk,
                                                       const float* __restrict__ Dskip, float* __restrict__ y, int H, int L) {
@@ -249,7 +335,147 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     }
 }
 
+// fp32 linear for a FEW rows (M <= 16: the encoder projection heads, 16384 -> 2048 -> 4096 ...): weight streaming, HBM bound.
+// A wave owns 2 output columns and streams their weight rows once with 16-B loads (lanes split K), all M rows' accumulators
+// stay in registers (the x rows are L2-resident: M*K*4 <= 1 MB); 4 waves per block, N/8 blocks: a 16384 x 2048 layer puts one
+// block on every CU. No split-K, no atomics: each output is one wave's shuffle reduction in a fixed order.
+template <int MR>
+__global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                                const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M, int N,
+                                                                int K, int accumulate) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  if (n0 >= N) return;
+  const float* w0 = W + (size_t)n0 * ldw;
+  const float* w1 = W + (size_t)min(n0 + 1, N - 1) * ldw;
+  float acc[MR][2];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) acc[i][0] = acc[i][1] = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 a = *(const f32x4*)(w0 + k), b = *(const f32x4*)(w1 + k);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      if (i < M) {
+        const f32x4 x = *(const f32x4*)(X + (size_t)i * ldx + k);
+        acc[i][0] = fmaf(x[0], a[0], fmaf(x[1], a[1], fmaf(x[2], a[2], fmaf(x[3], a[3], acc[i][0]))));
+        acc[i][1] = fmaf(x[0], b[0], fmaf(x[1], b[1], fmaf(x[2], b[2], fmaf(x[3], b[3], acc[i][1]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float v = wave_sum(acc[i][c]);
+      if (lane == 0 && i < M && n0 + c < N) {
+        float* yp = Y + (size_t)i * ldy + n0 + c;
+        const float o = v + (bias ? bias[n0 + c] : 0.f);
+        *yp = accumulate ? (*yp + o) : o;
+      }
+    }
+}
+
+// ---- channel-major fp32 GEMM on the f32-input MFMA:  Y[b][n][l] = epi(sum_k W[n][k] * X[b][k][l] + bias[n]) ---------------------------
+// The CS3 / DGF side keeps activations channel-major [B, C, L]; a Linear over channels at every position (fuse_eeg's
+// Linear(1024 -> 512), the two 1x1 convolutions of the DUAN gate) is W . X with X's positions along the fast axis -- exactly
+// the B operand of v_mfma_f32_32x32x2_f32 (lane = position, k = channel), so no transpose is needed and the products are exact
+// fp32. Block = 4 waves = a 64 (n) x 64 (l) tile, K in chunks of 32 staged through LDS (W rows padded to 33 floats:
+// conflict-free column reads). Epilogues: 0 store, 1 accumulate into Y, 2 ReLU, 3 sigmoid + sum over the tile's 64 positions
+// (-> part[b][l_tile][n], the DUAN gate's mean over L, summed later in tile order: no atomics).
+constexpr int CG_KC = 32;
+__global__ __launch_bounds__(256) void chan_gemm_f32_kernel(const float* __restrict__ X, long x_bstride, int ldx, const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ Y, long y_bstride, int ldy,
+                                                            int N, int K, int L, int epi, float* __restrict__ part) {
+  __shared__ float Ws[64 * (CG_KC + 1)];
+  __shared__ __attribute__((aligned(16))) float Xs[CG_KC * 64];
+  const int b = blockIdx.z, n0 = blockIdx.y * 64, l0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave >> 1, wl = wave & 1;
+  const float* Xb = X + (size_t)b * x_bstride;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += CG_KC) {
+    __syncthreads();
+    // W tile [64 n][32 k]: thread -> (n = tid / 4 (+ 0), 8 consecutive k)
+    {
+      const int n = tid >> 2, kq = (tid & 3) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + n < N && k0 + kq + 4 * h < K) v = *(const f32x4*)(W + (size_t)(n0 + n) * ldw + k0 + kq + 4 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ws[n * (CG_KC + 1) + kq + 4 * h + c] = v[c];
+      }
+      // X tile [32 k][64 l]: thread -> (k = tid / 8, 8 consecutive l)
+      const int k = tid >> 3, lq = (tid & 7) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int l = l0 + lq + 4 * h;
+        if (k0 + k < K && l + 3 < L) v = *(const f32x4*)(Xb + (size_t)(k0 + k) * ldx + l);
+        else if (k0 + k < K) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) if (l + c < L) v[c] = Xb[(size_t)(k0 + k) * ldx + l + c];
+        }
+        *(f32x4*)&Xs[k * 64 + lq + 4 * h] = v;
+      }
+    }
+    __syncthreads();
+    const float* ap = Ws + (wn * 32 + l31) * (CG_KC + 1) + hi;
+    const float* bp = Xs + hi * 64 + wl * 32 + l31;
+#pragma unroll
+    for (int st = 0; st < CG_KC / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * 64], acc, 0, 0, 0);
+  }
+  // acc[r]: n = n0 + wn*32 + 8*(r/4) + 4*hi + r%4 ; l = l0 + wl*32 + l31
+  const int l = l0 + wl * 32 + l31;
+  float* Yb = Y ? Y + (size_t)b * y_bstride : nullptr;
+  if (epi == 3) {
+    __syncthreads();                                   // Xs is free: 64 n x 2 halves of partial sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nl = wn * 32 + 8 * (r >> 2) + 4 * hi + (r & 3), n = n0 + nl;
+      float v = 0.f;
+      if (n < N && l < L) v = 1.0f / (1.0f + __expf(-(acc[r] + (bias ? bias[n] : 0.f))));
+      // sum over the 32 positions of this wave's half tile: lanes of one half-wave (same hi) hold the same n
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (l31 == 0) Xs[nl * 2 + wl] = v;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) part[((size_t)b * gridDim.x + blockIdx.x) * N + n0 + tid] = Xs[tid * 2] + Xs[tid * 2 + 1];
+    return;
+  }
+  if (l >= L) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+    if (n >= N) continue;
+    float v = acc[r] + (bias ? bias[n] : 0.f);
+    float* yp = Yb + (size_t)n * ldy + l;
+    if (epi == 1) v += *yp;
+    else if (epi == 2) v = v > 0.f ? v : 0.f;
+    *yp = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int lx_chan_gemm_f32(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride,
+                                int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream) {
+  LX_CHECK_ARG(X && W && B > 0 && N > 0 && K > 0 && L > 0, "lx_chan_gemm_f32: bad arguments");
+  LX_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && (epilogue == 3 ? part != nullptr : Y != nullptr), "lx_chan_gemm_f32: epilogue 0..3 (3 needs part, the others Y)");
+  LX_CHECK_ARG(K % 4 == 0 && ldw % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "lx_chan_gemm_f32: K, ldw, ldx must be multiples of 4, X / W 16-byte aligned");
+  hipLaunchKernelGGL(chan_gemm_f32_kernel, dim3((L + 63) / 64, (N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, W, ldw, bias, Y,
+                     y_bstride, ldy, N, K, L, epilogue, part);
+  LX_LAUNCH_CHECK("lx_chan_gemm_f32");
+  return LX_OK;
+}
+
+static bool env_mw() {          // LX_S4_MULTIWAVE=0 forces the one-wave-per-sequence kernel (A/B, tests); read per call: the op runs ~10x per image
+  const char* e = getenv("LX_S4_MULTIWAVE");
+  return !e || atoi(e) != 0;
+}
 
 extern "C" int lx_s4_scan(const float* u, const double* lam, const double* w, const float* Dskip, float* y, int B, int H, int L,
                           int N, void* stream) {
@@ -258,6 +484,23 @@ extern "C" int lx_s4_scan(const float* u, const double* lam, const double* w, co
   const int ch = L / 64;
   const dim3 grid(B * H), block(64);
   hipStream_t s = (hipStream_t)stream;
+  // four (two) waves per sequence wherever L allows it -- for every batch size, so that a sample's result does not depend on
+  // how many other samples share the launch (data-parallel shards == the single-GPU batch, bit for bit)
+  if (env_mw()) {
+    bool done = true;
+    if (L % 256 == 0 && L / 256 == 16) hipLaunchKernelGGL((s4_scan_mw_kernel<16, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L % 256 == 0 && L / 256 == 8) hipLaunchKernelGGL((s4_scan_mw_kernel<8, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L % 256 == 0 && L / 256 == 4) hipLaunchKernelGGL((s4_scan_mw_kernel<4, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L % 256 == 0 && L / 256 == 2) hipLaunchKernelGGL((s4_scan_mw_kernel<2, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L == 8192) hipLaunchKernelGGL((s4_scan_mw_kernel<32, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L == 256) hipLaunchKernelGGL((s4_scan_mw_kernel<1, 4>), grid, dim3(256), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else if (L == 128) hipLaunchKernelGGL((s4_scan_mw_kernel<1, 2>), grid, dim3(128), 0, s, u, lam, w, Dskip, y, H, L, N);
+    else done = false;
+    if (done) {
+      LX_LAUNCH_CHECK("lx_s4_scan");
+      return LX_OK;
+    }
+  }
 #define LX_SCAN_CASE(C) case C: hipLaunchKernelGGL(s4_scan_kernel<C>, grid, block, 0, s, u, lam, w, Dskip, y, H, L, N); break;
   switch (ch) {
     LX_SCAN_CASE(1) LX_SCAN_CASE(2) LX_SCAN_CASE(4) LX_SCAN_CASE(8) LX_SCAN_CASE(16) LX_SCAN_CASE(32) LX_SCAN_CASE(64)
@@ -322,6 +565,14 @@ extern "C" int lx_layernorm_relu(float* x, const float* g, const float* b, int M
 extern "C" int lx_linear_f32(const float* X, int ldx, int x_trans, const float* W, int ldw, const float* bias, float* Y, int ldy,
                              int y_trans, int M, int N, int K, int accumulate, void* stream) {
   LX_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0, "lx_linear_f32: bad arguments");
+  if (M <= 16 && !x_trans && !y_trans && K >= 256 && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)X | (uintptr_t)W) & 15) == 0) {
+    // a few rows against a big weight: stream the weights once at HBM rate instead of tiling a 64-row problem that is 3/4 padding
+    const dim3 g((N + 7) / 8), blk(256);
+    if (M <= 4) hipLaunchKernelGGL(linear_f32_skinny_kernel<4>, g, blk, 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, M, N, K, accumulate);
+    else hipLaunchKernelGGL(linear_f32_skinny_kernel<16>, g, blk, 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, M, N, K, accumulate);
+    LX_LAUNCH_CHECK("lx_linear_f32");
+    return LX_OK;
+  }
   const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
   hipLaunchKernelGGL(linear_f32_kernel, grid, block, 0, (hipStream_t)stream, X, ldx, x_trans, W, ldw, bias, Y, ldy, y_trans, M, N, K, accumulate);
   LX_LAUNCH_CHECK("lx_linear_f32");

@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void duan_mask_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" size_t lx_duan_workspace_bytes(int B, int C, int L, int Hd) {
-  (void)Hd;
   const size_t ntile = (size_t)(L + 63) / 64;
-  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C) + 256;
+  // + the gate network's hidden activations [B, Hd, L] for the MFMA form of the gate (C % 4 == 0)
+  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C + (size_t)B * Hd * L) + 512;
 }
 
 extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, const float* gb1, const float* gw2, const float* gb2,
@@ -186,7 +186,17 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   float* imp = coef + (size_t)B * C * 2;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(duan_stats_kernel, dim3(C, B), dim3(256), 0, s, x, c, stats, C, L);
-  hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
+  if (C % 4 == 0 && Hd % 4 == 0 && L % 4 == 0) {
+    // the two 1x1 convolutions of the gate as channel-major fp32 GEMMs on the f32 MFMA (cs3.hip, lx_chan_gemm_f32):
+    // hid = relu(W1 c + b1);  gpart[b][tile][ch] = sum over the tile's positions of sigmoid(W2 hid + b2)
+    float* hid = (float*)(((uintptr_t)(imp + (size_t)B * C) + 255) & ~(uintptr_t)255);
+    int rc = lx_chan_gemm_f32(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
+    if (rc != LX_OK) return rc;
+    rc = lx_chan_gemm_f32(hid, (long)Hd * L, L, gw2, Hd, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
+    if (rc != LX_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
+  }
   hipLaunchKernelGGL(duan_coef_kernel, dim3(B), dim3(256), 0, s, stats, gpart, mw1, mb1, mw2, mb2, coef, C, L, Hd, ntile, eps);
   hipLaunchKernelGGL(duan_apply_kernel, dim3(C, B), dim3(256), 0, s, x, coef, y, imp, C, L);
   hipLaunchKernelGGL(duan_mask_kernel, dim3(B), dim3(256), 0, s, imp, y, C, L, keep_k);

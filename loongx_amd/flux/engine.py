@@ -16,6 +16,7 @@ weights unless model_config["latent_lora"]; evaluated as a rank-r epilogue term,
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -141,7 +142,7 @@ class DiTEngine:
         switched off for this engine, so a retry takes the plain plans. sync=True drains the stream and checks now. sync=False
         costs no synchronisation: it looks at the error word copied to pinned host memory by the previous call (if that copy has
         landed) and enqueues the next copy -- generate() does this once per image, so a time-out surfaces at most one image late."""
-        if self._gemm_ws is None:
+        if self._gemm_ws is None or (not sync and os.environ.get("LX_ASYNC_STATUS", "1") == "0"):
             return
         if sync:
             try:

@@ -387,6 +387,13 @@ def linear_f32(X, W, bias, Y, *, M, N, K, ldx, ldy, x_trans=False, y_trans=False
                             ldy, int(y_trans), M, N, K, int(accumulate), _stream()), "lx_linear_f32")
 
 
+def chan_gemm_f32(X, W, bias, Y, *, N, K, epilogue=0, ldw=None) -> None:
+    """Y[b, n, l] (=|+=) sum_k W[n, k] X[b, k, l] + bias[n] on channel-major fp32 [B, K, L] / [B, N, L] (fp32 MFMA)."""
+    B, _, Lq = X.shape
+    check(lib.lx_chan_gemm_f32(X.data_ptr(), X.stride(0), X.stride(1), W.data_ptr(), W.stride(0) if ldw is None else ldw, _p(bias),
+                               Y.data_ptr(), Y.stride(0), Y.stride(1), B, N, K, Lq, epilogue, None, _stream()), "lx_chan_gemm_f32")
+
+
 def duan_fwd(x, c, p, y, keep_k, eps=1e-3) -> None:
     """p: dict with gate.0.weight/bias, gate.2.weight/bias, mlp.0.weight/bias, mlp.2.weight/bias (conv1x1 as [out,in])."""
     B, Cc, Lq = x.shape

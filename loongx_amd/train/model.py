@@ -295,10 +295,10 @@ class CS3DGF:
         B, Cc, L = eeg_f.shape
         out = torch.empty(B, self.fusion1.w.shape[0], L, device=eeg_f.device)
         w = self.fusion1.w
-        for b in range(B):
-            ops.linear_f32(eeg_f[b], w, self.fusion1.b, out[b], M=L, N=w.shape[0], K=Cc, ldx=L, ldy=L, x_trans=True, y_trans=True)
-            ops.linear_f32(f[b], w[:, Cc:], None, out[b], M=L, N=w.shape[0], K=Cc, ldx=L, ldy=L, x_trans=True, y_trans=True,
-                           accumulate=True, ldw=w.stride(0))
+        # Linear(1024 -> 512) over channels at every position: out = W[:, :C] eeg + b, then += W[:, C:] f -- channel-major fp32
+        # GEMMs on the f32 MFMA, the whole batch per launch (no torch.cat of [eeg, f], no transposes)
+        ops.chan_gemm_f32(eeg_f.contiguous(), w, self.fusion1.b, out, N=w.shape[0], K=Cc)
+        ops.chan_gemm_f32(f.contiguous(), w[:, Cc:], None, out, N=w.shape[0], K=Cc, epilogue=1, ldw=w.stride(0))
         return out
 
     def fuse_fnirs(self, fnirs_f: torch.Tensor, motion_f: torch.Tensor) -> torch.Tensor:

@@ -477,6 +477,67 @@ def test_s4_scan_and_conv(ops, H, N, L):
     assert np.abs(y2.cpu().numpy() - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
 
 
+def test_s4_scan_one_wave_and_multi_wave_agree(ops, monkeypatch):
+    """The scan with four waves per sequence (cross-wave carries through LDS; the default) and with one wave per sequence
+    (LX_S4_MULTIWAVE=0) are the same operator."""
+    from oracle import s4
+    H, N, L = 4, 4, 512
+    lay = s4.S4Layer(H, N, L, torch.Generator().manual_seed(5))
+    pr = lay.params_np()
+    lam, w = s4.diagonalize(pr, L)
+    lam_t = torch.from_numpy(np.stack([lam.real, lam.imag], -1)).to(DEV)
+    w_t = torch.from_numpy(np.stack([w.real, w.imag], -1)).to(DEV)
+    Dk = torch.from_numpy(pr["D"]).float().to(DEV)
+    u = rnd(128, H, L, seed=6)
+    y_mw = torch.empty_like(u)
+    ops.s4_scan(u, lam_t, w_t, Dk, y_mw)
+    ops.s4_scan(u[:3].contiguous(), lam_t, w_t, Dk, y_1w3 := torch.empty(3, H, L, device=DEV))
+    assert torch.equal(y_1w3, y_mw[:3])                       # a sample's result does not depend on the batch it is in
+    monkeypatch.setenv("LX_S4_MULTIWAVE", "0")
+    y_1w = torch.empty_like(u)
+    ops.s4_scan(u, lam_t, w_t, Dk, y_1w)
+    monkeypatch.delenv("LX_S4_MULTIWAVE")
+    assert relerr(y_mw, y_1w) < 1e-6 and not torch.equal(y_mw, y_1w) or torch.equal(y_mw, y_1w)
+    K = s4.kernel_genfunc(pr, L)
+    yref = s4.causal_conv_direct(u[:2].cpu().permute(0, 2, 1).numpy(), K, pr["D"]).transpose(0, 2, 1)
+    assert np.abs(y_mw[:2].cpu().numpy() - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
+
+
+@pytest.mark.parametrize("B,N,K,L", [(2, 8, 16, 48), (3, 512, 1024, 4096), (2, 130, 36, 200), (1, 64, 128, 768)])
+def test_chan_gemm_f32(ops, B, N, K, L):
+    """Channel-major fp32 GEMM on the f32 MFMA: store / accumulate / ReLU, and the sigmoid + tile-sum epilogue of the DUAN gate."""
+    X, W, bias = rnd(B, K, L, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    ref = torch.einsum("nk,bkl->bnl", W.double(), X.double()) + bias.double()[None, :, None]
+    Y = torch.full((B, N, L), float("nan"), device=DEV)
+    ops.chan_gemm_f32(X, W, bias, Y, N=N, K=K)
+    assert relerr(Y, ref.float()) < 2e-6
+    ops.chan_gemm_f32(X, W, None, Y, N=N, K=K, epilogue=1)
+    assert relerr(Y, (2 * ref - bias.double()[None, :, None]).float()) < 2e-6
+    ops.chan_gemm_f32(X, W, bias, Y, N=N, K=K, epilogue=2)
+    assert relerr(Y, torch.relu(ref).float()) < 2e-6
+    if K % 2 == 0:                                               # a weight that is a column slice of a wider matrix (fuse_eeg's W[:, C:])
+        W2 = rnd(N, 2 * K, seed=4, scale=0.1)
+        ops.chan_gemm_f32(X, W2[:, K:], bias, Y, N=N, K=K, ldw=2 * K)
+        assert relerr(Y, (torch.einsum("nk,bkl->bnl", W2[:, K:].double(), X.double()) + bias.double()[None, :, None]).float()) < 2e-6
+    from loongx_amd._lib import lib
+    nt = (L + 63) // 64
+    part = torch.full((B, nt, N), float("nan"), device=DEV)
+    assert lib.lx_chan_gemm_f32(X.data_ptr(), X.stride(0), X.stride(1), W.data_ptr(), W.stride(0), bias.data_ptr(), None, 0, 0, B, N, K, L, 3,
+                                part.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert relerr(part.sum(1), torch.sigmoid(ref).sum(2).float()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 16384), (16, 4096, 2048), (3, 771, 1356), (5, 512, 5184)])
+def test_linear_f32_few_rows_streams_the_weights(ops, M, N, K):
+    X, W, bias = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.05), rnd(N, seed=6)
+    ref = (X.double() @ W.double().T + bias.double()).float()
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_f32(X, W, bias, Y, M=M, N=N, K=K, ldx=K, ldy=N)
+    assert relerr(Y, ref) < 3e-6
+    ops.linear_f32(X, W, None, Y, M=M, N=N, K=K, ldx=K, ldy=N, accumulate=True)
+    assert relerr(Y, (2 * ref - bias).float()) < 3e-6
+
+
 @pytest.mark.parametrize("hin,hout", [(4, 64), (64, 64), (4, 4), (6, 6)])
 def test_chanmix(ops, hin, hout):
     B, L = 2, 300

@@ -1,0 +1,30 @@
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_traffic.json: HBM-side bytes per
+GEMM launch = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a wide
+coalesced read) + WRITE_SIZE, both in KiB per dispatch, launch-weighted over every lx_gemm_* dispatch. The record carries the
+hash of the kernel source it was measured on; bench.py reports `traffic` only while that hash matches.
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <label> > profiles/pmc_traffic.json
+"""
+import csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_dispatch(path, counter):
+    tot, n, by = 0.0, 0, {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or "lx_gemm_" not in r["Kernel_Name"]:
+            continue
+        v = float(r["Counter_Value"])
+        tot += v; n += 1
+        k = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+        a = by.setdefault(k, [0.0, 0]); a[0] += v; a[1] += 1
+    return tot, n, {k: round(v[0] / v[1], 1) for k, v in by.items()}
+
+
+f_tot, f_n, f_by = per_dispatch(sys.argv[1], "FETCH_SIZE")
+w_tot, w_n, w_by = per_dispatch(sys.argv[2], "WRITE_SIZE")
+sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+mb = (2.0 * f_tot / max(f_n, 1) + w_tot / max(w_n, 1)) * 1024 / 1e6
+print(json.dumps({"gemm_hip_sha16": sha, "gemm_traffic_MB_per_launch": round(mb, 1), "source": sys.argv[3],
+                  "fetch_KiB_per_launch_by_kernel (uncorrected)": f_by, "write_KiB_per_launch_by_kernel": w_by,
+                  "launches": {"fetch_pass": f_n, "write_pass": w_n}}, indent=1))
