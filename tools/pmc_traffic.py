@@ -2,21 +2,21 @@
 GEMM launch = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a wide
 coalesced read) + WRITE_SIZE, both in KiB per dispatch, launch-weighted over every lx_gemm_* dispatch. The record carries the
 hash of the kernel source it was measured on; bench.py reports `traffic` only while that hash matches.
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <label> > profiles/pmc_traffic.json
+    python tools/pmc_traffic.py <fetch p_results.db> <write p_results.db> <label> > profiles/pmc_traffic.json
 """
-import csv, hashlib, json, os, sys
+import hashlib, json, os, re, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_dispatch(path, counter):
+    c = sqlite3.connect(path)
     tot, n, by = 0.0, 0, {}
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or "lx_gemm_" not in r["Kernel_Name"]:
+    for name, v in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        if "lx_gemm_" not in name:
             continue
-        v = float(r["Counter_Value"])
         tot += v; n += 1
-        k = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+        k = re.search(r"lx_gemm_\w+(<[^>]*>)?", name).group(0)
         a = by.setdefault(k, [0.0, 0]); a[0] += v; a[1] += 1
     return tot, n, {k: round(v[0] / v[1], 1) for k, v in by.items()}
 
