@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (N=1 only; ~1 min on the GPU)")
     ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32 attention)")
+    ap.add_argument("--hw", type=int, default=32, help="packed latent grid side: 32 = 512x512 (the metric's config), 64 = 1024x1024 (configs[4])")
+    ap.add_argument("--fp8", action="store_true", help="model_config attn_fp8 / gemm_fp8: the e4m3 MFMA paths of BASELINE configs[4]")
+    ap.add_argument("--modalities", type=str, default="eeg", help="eeg (configs[1]) | all (EEG+fNIRS+PPG+motion, CS3+DGF fuse: configs[2]/[3])")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(a.gpus))
@@ -150,21 +153,31 @@ def main():
     torch.cuda.synchronize()
     t_bcast = time.time() - t1
     t_weights = time.time() - t0
-    model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), {"union_cond_attn": True}, dev)
+    mc = {"union_cond_attn": True}
+    if a.precise:
+        mc["precise"] = True
+    if a.fp8:
+        mc.update(attn_fp8=True, gemm_fp8=True)
+    model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
 
-    B, hw = a.batch, 32
+    B, hw = a.batch, a.hw
     N = hw * hw
+    allmod = a.modalities == "all"
     g = torch.Generator(device=dev).manual_seed(1234 + rank)     # every rank edits different images
     def batch():
         return dict(lat=torch.randn(B, N, 64, device=dev, generator=g), cond=torch.randn(B, N, 64, device=dev, generator=g),
                     pe=torch.randn(B, T_TXT, 4096, device=dev, generator=g) * 0.1, pooled=torch.randn(B, 768, device=dev, generator=g),
-                    eeg=torch.randn(B, 4, 4096, device=dev, generator=g))
+                    eeg=torch.randn(B, 4, 4096, device=dev, generator=g), fnirs=torch.randn(B, 6, 512, device=dev, generator=g),
+                    ppg=torch.randn(B, 4, 256, device=dev, generator=g), motion=torch.randn(B, 6, 128, device=dev, generator=g))
     def run(x):
         c = Condition("subject", latents=x["cond"], latent_hw=(hw, hw), position_delta=[0, -hw])
-        return generate(model, model.flux_pipe, conditions=[c], height=512, width=512, num_inference_steps=STEPS, latents=x["lat"],
+        sig = dict(additional_condition1=x["eeg"])
+        if allmod:           # configs[2]/[3]: all four modalities, CS3 encoders + DGF fusion into the text embeddings
+            sig.update(additional_condition2=x["fnirs"], additional_condition3=x["ppg"], additional_condition4=x["motion"])
+        return generate(model, model.flux_pipe, conditions=[c], height=16 * hw, width=16 * hw, num_inference_steps=STEPS, latents=x["lat"],
                         prompt_embeds=x["pe"], pooled_prompt_embeds=x["pooled"], output_type="latent", model_config=model.model_config,
-                        default_lora=True, additional_condition1=x["eeg"], use_brain_condition=True, fuse_flag=False,
-                        brain_replace="per_stream").images      # EEG-only conditioning (configs[1]) needs the per-stream rule
+                        default_lora=True, use_brain_condition=True, fuse_flag=allmod,
+                        brain_replace="per_stream", **sig).images      # EEG-only conditioning (configs[1]) needs the per-stream rule
 
     batches = [batch() for _ in range(a.warmup + a.steps)]
     for i in range(a.warmup):
@@ -195,11 +208,14 @@ def main():
         images = world * B * a.steps
         value = images / (elapsed_ms / 1e3)
         fpi = flops_per_image(N, N)
-        res = {"metric": "edited images/s @512x512, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
+        res = {"metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed_ms / a.steps, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: EEG-only CS3 conditioning, 512x512 edit (512 txt + 1024 img + 1024 cond "
-                                      "tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, D=3072), LoRA r=4 on the condition stream",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16 x2 split (fp32-class)" if a.precise else ("fp8 e4m3 MFMA operands" if a.fp8 else "bf16"), "data": "synthetic",
+               "config": {"workload": (f"BASELINE configs[{1 if not allmod else (2 if B == 1 else 3)}]: " if hw == 32 and not a.fp8 else "BASELINE configs[4] shape: ") +
+                                      ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
+                                      f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, "
+                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 paths" if a.fp8 else ""),
                           "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
                           "rccl_ranks": world, "weight_broadcast_GB": round(moved / 1e9, 2), "weight_broadcast_s": round(t_bcast, 2),
                           "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)},
@@ -228,7 +244,7 @@ def main():
                                              "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / a.steps), 3)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-        if world == 1 and not a.no_parity:
+        if world == 1 and not a.no_parity and hw == 32:
             del model, pw, batches, out
             torch.cuda.empty_cache()
             try:
