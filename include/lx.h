@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 100 /* 0.1.0 */
+#define LX_VERSION 200 /* 0.2.0: + caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {
   LX_OK = 0,
@@ -57,8 +57,12 @@ enum {
   LX_EPI_GELU = 0x100,   /* OR-able flag: GELU(tanh) on columns n >= gelu_col_start */
   LX_W_TILED = 0x200,    /* OR-able flag: W is pre-tiled (see lx_tile_weight_layout): [N/256][K/64] blocks of 256x64,
                             each stored as the swizzled LDS image the kernel consumes; needs N % 256 == 0, ldw == K */
-  LX_EPI_SPLIT_BF16 = 0x400 /* OR-able flag (with LX_EPI_STORE_BF16): also store bf16(x - bf16(x)) at column n + c_lo_off, so
+  LX_EPI_SPLIT_BF16 = 0x400, /* OR-able flag (with LX_EPI_STORE_BF16): also store bf16(x - bf16(x)) at column n + c_lo_off, so
                             that a consumer GEMM with k_segs >= 2 sees x to 16 mantissa bits (precise mode) */
+  LX_EPI_STORE_FP8 = 3,  /* (fp8 GEMMs only) C(e4m3 bytes) = act(acc * col_scale + bias) * out_scale, saturated to +-448 */
+  LX_OPERANDS_FP8 = 0x800 /* OR-able flag: A and W are OCP e4m3 bytes (lda / ldw in bytes, K %% 128 == 0), products on the
+                            64-deep f8f6f4 MFMA at twice the bf16 rate; acc[m,n] *= col_scale[n] before everything else.
+                            BASELINE configs[4]; opt-in (model_config["gemm_fp8"]). Every problem of a launch must carry it. */
 };
 
 typedef struct lx_gemm_desc {
@@ -84,6 +88,8 @@ typedef struct lx_gemm_desc {
    * A_hi W_lo^T is added: 3 of the 4 cross terms, relative error ~2^-16. One accumulation, one epilogue. */
   int32_t k_segs, a_lo_off;
   int32_t c_lo_off;          /* LX_EPI_SPLIT_BF16: column distance of the lo image of the output */
+  float out_scale;           /* LX_EPI_STORE_FP8: multiplier applied before the e4m3 rounding */
+  const float* col_scale;    /* LX_OPERANDS_FP8: [N] fp32, 1 / (activation scale * weight scale of row n); NULL => 1 */
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4
@@ -235,6 +241,19 @@ typedef struct lx_attn_f32_desc {
   float scale;
 } lx_attn_f32_desc;
 int lx_attn_fwd_f32(const lx_attn_f32_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp8 GEMM path (LX_OPERANDS_FP8; BASELINE configs[4], opt-in model_config["gemm_fp8"]): producers of the e4m3 operand images.
+ * The reference has no fp8 path; the contract is "the bf16 result within the measured fp8 tolerance" (tests/test_fp8_gpu.py).
+ * ------------------------------------------------------------------------------------------------ */
+/* lx_ln_modulate_segs writing the bf16 operand Y (may be NULL) AND its e4m3 image Y8[m, c] = e4m3(y * y8_scale) (ldy8 in bytes) */
+int lx_ln_modulate_fp8_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, void* Y8, int ldy8,
+                            float y8_scale, int D, float eps, void* stream);
+/* dst(e4m3)[m, k] = src(bf16 | fp32)[m, k] * scale, saturated to +-448 */
+int lx_convert_fp8(const void* src, int src_is_bf16, int lds, void* dst, int ldd, float scale, int M, int K, void* stream);
+/* lx_lora_down with an e4m3 activation image: T_s = x_descale * X8[M, K_s] . Adown[R, K_s]^T (Adown bf16) */
+int lx_lora_down_fp8(const void* X8, int ldx, float x_descale, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                     int split_stride, void* stream);
 
 /* x(fp32) += dsigma * v   (FlowMatchEulerDiscreteScheduler.step, generate.py:349); v is bf16 or fp32 */
 int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream);

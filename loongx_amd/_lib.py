@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
 LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED, LX_EPI_SPLIT_BF16 = 0, 1, 2, 0x100, 0x200, 0x400
+LX_EPI_STORE_FP8, LX_OPERANDS_FP8 = 3, 0x800
 LX_GEMM_MAX_GROUP = 4
 
 
@@ -29,7 +30,8 @@ class GemmDesc(C.Structure):
                 ("lora_r", C.c_int32), ("lora_ldt", C.c_int32), ("lora_mod_cols", C.c_int32),
                 ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32),
                 ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32),
-                ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32)]
+                ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32), ("out_scale", C.c_float),
+                ("col_scale", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -88,6 +90,9 @@ _SIGS = {
     "lx_groupnorm_silu": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _Z, _P]),
     "lx_im2col3x3": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "lx_softmax_rows": (C.c_int, [_P, _I, _F, _P, _I, _I, _I, _P]),
+    "lx_ln_modulate_fp8_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _P, _I, _F, _I, _F, _P]),
+    "lx_convert_fp8": (C.c_int, [_P, _I, _I, _P, _I, _F, _I, _I, _P]),
+    "lx_lora_down_fp8": (C.c_int, [_P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lx_euler_step": (C.c_int, [_P, _P, _I, _F, _Z, _P]),
     "lx_convert": (C.c_int, [_P, _I, _P, _I, _Z, _P]),
     "lx_s4_scan": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

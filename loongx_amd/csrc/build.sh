@@ -8,7 +8,7 @@ OBJ="$HERE/../lib/obj"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@")
-SRCS=(api gemm attn rowops precise vae cs3 dgf)
+SRCS=(api gemm attn rowops precise fp8 vae cs3 dgf)
 pids=()
 for s in "${SRCS[@]}"; do
   if [[ ! -f "$OBJ/$s.o" || "$HERE/$s.hip" -nt "$OBJ/$s.o" || "$HERE/common.h" -nt "$OBJ/$s.o" || "$HERE/../../include/lx.h" -nt "$OBJ/$s.o" ]]; then

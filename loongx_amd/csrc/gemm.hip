@@ -160,7 +160,14 @@ __device__ __forceinline__ void lora_apply(const f32x4 (&u4)[2], const f32x4 (&t
 __device__ __forceinline__ bool lora_in_prologue(const lx_gemm_desc& P) { return P.lora_t != nullptr && P.lora_r <= 4 && P.lora_nsplit <= 4; }
 
 // Shared epilogue: LoRA MFMA step, LDS transpose, coalesced bias / GELU / gate / residual / store.
-template <int BM, int MI, bool SPLIT = false>
+__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(c), clamp_e4m3(d), w, true);
+  return (uint32_t)w;
+}
+
+template <int BM, int MI, bool SPLIT = false, bool FP8 = false>
 __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
                                               int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done, int i_begin = 0, int i_end = MI) {
   // [i_begin, i_end): the 32-row blocks of each wave's tile that this workgroup finishes (all of them, except in the pair kernel)
@@ -196,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   __syncthreads();                                   // every wave is done with the operand tiles
   constexpr int EP_LD = 68;                          // fp32 row stride of the patch (64 + 4 pad)
   float* patch = (float*)smem + wave * (32 * EP_LD);
-  const bool bf16_out = epi == LX_EPI_STORE_BF16;
+  const bool bf16_out = epi == LX_EPI_STORE_BF16 || (FP8 && epi == LX_EPI_STORE_FP8);      // the 8-columns-per-lane store shape
   const int c8 = (lane & 7) * 8, c4 = (lane & 15) * 4;
   const int ncol = nw0 + (bf16_out ? c8 : c4);       // first of this lane's 8 (bf16 store) or 4 (fp32 paths) columns
   const bool col_ok = ncol < N;
@@ -208,7 +215,15 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
   // The loads above sit under a condition, and hipcc's wait-count pass then re-waits vmcnt(0) at every later use of their
   // registers -- which, inside the store loops below, means waiting for the previous store after all. Wait here, once, and
   // hand the values on through an empty asm so that they are no longer "results of a load" to the compiler.
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias0), "+v"(bias1)::"memory");
+  // fp8 GEMMs: the accumulators are in units of 1 / (activation scale x weight-row scale): per-column de-scale first
+  f32x4 cs0 = {1.f, 1.f, 1.f, 1.f}, cs1 = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (FP8) {
+    if (P.col_scale && col_ok) {
+      cs0 = *(const f32x4*)(P.col_scale + ncol);
+      if (bf16_out) cs1 = *(const f32x4*)(P.col_scale + ncol + 4);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias0), "+v"(bias1), "+v"(cs0), "+v"(cs1)::"memory");
   const bool gelu0 = do_gelu && ncol >= P.gelu_col_start;      // gelu_col_start is a multiple of 8: one answer per lane
   auto to_patch = [&](int i) {
 #pragma unroll
@@ -234,9 +249,21 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
         f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
         if (m < M && col_ok) {
+          if constexpr (FP8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v0[c] *= cs0[c]; v1[c] *= cs1[c]; }
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) { v0[c] += bias0[c]; v1[c] += bias1[c]; }
           if (gelu0) { v0 = gelu_tanh4(v0); v1 = gelu_tanh4(v1); }
+          if constexpr (FP8) {
+            if (epi == LX_EPI_STORE_FP8) {        // e4m3 output (x out_scale): the A operand of the next fp8 GEMM
+              const float os = P.out_scale;
+              *(u32x2*)((uint8_t*)P.C + (size_t)m * P.ldc + ncol) = u32x2{pack_fp8x4(v0[0] * os, v0[1] * os, v0[2] * os, v0[3] * os),
+                                                                          pack_fp8x4(v1[0] * os, v1[1] * os, v1[2] * os, v1[3] * os)};
+              continue;
+            }
+          }
           u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
           *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
           if constexpr (SPLIT) {
@@ -287,6 +314,10 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         const int row = t * 4 + (lane >> 4), m = mb + row;
         f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
         if (m < M && col_ok) {
+          if constexpr (FP8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= cs0[c];
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += bias0[c];
           if (gelu0) v = gelu_tanh4(v);
@@ -314,6 +345,10 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         const int row = t * 4 + (lane >> 4), m = mb + row;
         f32x4 v = *(const f32x4*)(patch + row * EP_LD + c4);
         if (m < M && col_ok) {
+          if constexpr (FP8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= cs0[c];
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += bias0[c];
           if (gelu0) v = gelu_tanh4(v);
@@ -612,6 +647,193 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_split_kernel(const GemmArgs 
   gemm_tile<BM, true>(args, blockIdx.x, smem);
 }
 
+// ---- fp8 (OCP e4m3) GEMM: BASELINE configs[4] ("fp8 MFMA ... path") ---------------------------------------------------------
+// A [M, K] and W [N, K] are e4m3 BYTES (values pre-multiplied by an activation scale / per-row weight scales); the products run on
+// v_mfma_f32_32x32x64_f8f6f4 (64-deep, twice the bf16 rate), fp32 accumulate; the epilogue multiplies column n by col_scale[n]
+// (= 1 / (activation scale x weight scale of row n)) before bias / GELU / gate / residual, and can emit e4m3 again for the next
+// GEMM (LX_EPI_STORE_FP8 x out_scale). A K tile is 128 elements = 128 B per row: the LDS image, the XOR swizzle, the
+// buffer-addressed LDS-DMA staging, the rings, the barrier / counted-vmcnt protocol and the role split are byte for byte those of the
+// bf16 loop; what changes is the fragment shape (the lane's 32 bytes = 16-B slots 4 ks + 2 g, + 1 of its row: two ds_read_b128) and
+// the step count (two 64-deep k steps per tile instead of four 16-deep ones). Operand convention: lane (row = lane % 32, g =
+// lane / 32) supplies 32 bytes, byte p of group g is k = 32 g + p on both operands (tools/ubench/fp8_mfma).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, class F>
+__device__ __forceinline__ void gemm_mainloop_fp8(const lx_gemm_desc& P, const int m0, const int n0, const int tn, const int kt0, const int kt1,
+                                                  char* smem, f32x16 (&acc)[2][BM / 64], const int tid, F&& after_issue) {
+  constexpr int MI = BM / 64;
+  constexpr int KB = 128;                   // bytes (= elements) per row of a K tile
+  constexpr int A_BYTES = BM * KB;
+  constexpr int W_BYTES = BN * KB;
+  constexpr int NSA = BM == 128 ? 3 : 2;
+  constexpr int NSW = BM == 128 ? 3 : 2;
+  constexpr int W_BASE = NSA * A_BYTES;
+  constexpr int WAIT_STEADY = BM == 128 ? MI + 4 : 0;
+  static_assert(W_BASE + NSW * W_BYTES == gemm_lds_bytes<BM>(), "fp8 rings must have the bf16 rings' geometry");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int M = P.M, N = P.N, K = P.K;
+  const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
+  uint32_t aoff[MI], woff[4];
+  {
+    const int rsub = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int row = (j * 8 + wave) * 8 + rsub;
+      const int lslot = pslot ^ ((row >> 1) & 7);
+      aoff[j] = (uint32_t)((min(m0 + row, M - 1) - m0) * P.lda + lslot * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (w_tiled) {
+        woff[j] = (uint32_t)((j * 8 + wave) * 1024 + lane * 16);
+      } else {
+        const int row = (j * 8 + wave) * 8 + rsub;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        woff[j] = (uint32_t)((min(n0 + row, N - 1) - n0) * P.ldw + lslot * 16);
+      }
+    }
+  }
+  const uint8_t* a_org = (const uint8_t*)P.A + (size_t)m0 * P.lda;
+  const uint8_t* w_org = w_tiled ? (const uint8_t*)P.W + ((size_t)tn * (K / KB)) * (BN * KB) : (const uint8_t*)P.W + (size_t)n0 * P.ldw;
+  const lx_rsrc_t rs_a = lx_make_rsrc(a_org), rs_w = lx_make_rsrc(w_org);
+  const int w_kstride_b = w_tiled ? BN * KB : KB;
+  auto stage_a = [&](int kt, int slot) {
+    char* base = smem + slot * A_BYTES;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) lx_buf_to_lds(rs_a, (lptr_t)(base + (j * 8 + wave) * 1024), aoff[j], (kt0 + kt) * KB);
+  };
+  auto stage_w = [&](int kt, int slot) {
+    char* base = smem + W_BASE + slot * W_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lx_buf_to_lds(rs_w, (lptr_t)(base + (j * 8 + wave) * 1024), woff[j], (kt0 + kt) * w_kstride_b);
+  };
+  const int sw = (l31 >> 1) & 7;
+  int slot_off[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) slot_off[ks][h] = ((ks * 4 + lhi * 2 + h) ^ sw) * 16;
+  const int a_row_off = (wm * (BM / 2) + l31) * 128;
+  const int w_row_off = (wn * 64 + l31) * 128;
+  auto frag = [&](const char* p, int ks) {
+    const u32x4 lo = *(const u32x4*)(p + slot_off[ks][0]), hi = *(const u32x4*)(p + slot_off[ks][1]);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto load_frags = [&](int sa, int sw_, int ks, i32x8 (&wf)[2], i32x8 (&xf)[MI]) {
+    const char* pa = smem + sa * A_BYTES + a_row_off;
+    const char* pw = smem + W_BASE + sw_ * W_BYTES + w_row_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wf[j] = frag(pw + j * 32 * 128, ks);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = frag(pa + i * 32 * 128, ks);
+  };
+  auto mma_j = [&](int j, const i32x8 (&wf)[2], const i32x8 (&xf)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], xf[i], acc[j][i], 0, 0, 0, 0, 0, 0);
+  };
+  const int nkt = kt1 - kt0;
+  i32x8 wfA[2], xfA[MI], wfB[2], xfB[MI];
+  {
+    stage_a(0, 0);
+    stage_w(0, 0);
+    if (nkt > 1) { stage_a(1, 1); stage_w(1, 1); }
+    if (nkt > 2) { if constexpr (NSA > 2) stage_a(2, 2); if constexpr (NSW > 2) stage_w(2, 2); }
+    after_issue();
+    if (nkt > 2 && NSW > 2) {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  load_frags(0, 0, 0, wfA, xfA);
+#define LX_STEP8(CUR_W, CUR_X, NEXT_STMT)           \
+  __builtin_amdgcn_s_setprio(1);                    \
+  mma_j(0, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_s_setprio(0);                    \
+  __builtin_amdgcn_sched_barrier(0);                \
+  NEXT_STMT;                                        \
+  __builtin_amdgcn_sched_barrier(0);                \
+  __builtin_amdgcn_s_setprio(1);                    \
+  mma_j(1, CUR_W, CUR_X);                           \
+  __builtin_amdgcn_s_setprio(0);                    \
+  __builtin_amdgcn_sched_barrier(0);
+  int ca = 0, cw = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int na = ca + 1 == NSA ? 0 : ca + 1;
+    const int nw = cw + 1 == NSW ? 0 : cw + 1;
+    LX_STEP8(wfA, xfA, load_frags(ca, cw, 1, wfB, xfB))
+    if (kt + 2 < nkt && WAIT_STEADY > 0) {
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 0) {
+      if (kt + NSA < nkt) stage_a(kt + NSA, ca);
+      if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LX_STEP8(wfB, xfB, if (kt + 1 < nkt) load_frags(na, nw, 0, wfA, xfA))
+    if (wm == 1) {
+      if (kt + NSA < nkt) stage_a(kt + NSA, ca);
+      if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ca = na;
+    cw = nw;
+  }
+#undef LX_STEP8
+}
+
+template <int BM>
+__global__ __launch_bounds__(NTHREADS) void lx_gemm_fp8_kernel(const GemmArgs args) {
+  __shared__ __attribute__((aligned(1024))) char smem[gemm_lds_bytes<BM>()];
+  constexpr int MI = BM / 64;
+  const int pid = blockIdx.x;
+  const int total = args.tile_start[MAX_SUB];
+  int lid;
+  {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, inx = pid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  }
+  const int g = tile_group(args, lid);
+  const lx_gemm_desc P = args.p[g];
+  int tm, tn;
+  tile_coords<BM>(P, lid - args.tile_start[g], tm, tn);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 acc[2][MI];
+  acc_clear<MI>(acc);
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bool lora_early = lora_in_prologue(P);
+  f32x4 u4[2], sv[MI][4];
+  if (lora_early) lora_issue<MI>(P, n0, m0 + wm * (BM / 2), n0 + wn * 64, l31, 0, 0, u4, sv);
+  // The LoRA term is NOT in the accumulator's units (acc * col_scale): pre-divide the up rows by col_scale so that one scale fits all
+  gemm_mainloop_fp8<BM>(P, m0, n0, tn, 0, P.K / 128, smem, acc, tid, [&]() {
+    if (lora_early) {
+      f32x4 t4[MI];
+      lora_sum<MI>(P, 0, sv, t4);
+      if (P.col_scale) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float inv = 1.0f / P.col_scale[min(n0 + wn * 64 + j * 32 + l31, P.N - 1)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u4[j][e] *= inv;
+        }
+      }
+      lora_apply<MI>(u4, t4, lhi, acc);
+    }
+  });
+  gemm_epilogue<BM, MI, false, true>(P, acc, smem, m0, n0, args.m_base[g], wave, wm, wn, lane, l31, lhi, lora_early);
+}
+
 // Mixed-height launch: `big` holds full rounds of 256-row tiles, `tail` the remaining rows as 128-row tiles, in ONE grid
 // [big tiles | padding to a multiple of 8 | tail tiles]. Launched one after the other, the tail (e.g. 168 tiles on 256 CUs) only
 // starts when the last big round has drained everywhere; in one grid a CU that finishes its last big tile picks up a tail tile
@@ -828,9 +1050,17 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
   long t256 = 0, t128 = 0;
   int kmax = 0;
-  bool split = false;
+  bool split = false, fp8 = false;
+  for (int i = 0; i < n; ++i) fp8 = fp8 || (problems[i].epilogue & LX_OPERANDS_FP8) != 0;
   for (int i = 0; i < n; ++i) {
     const lx_gemm_desc& p = problems[i];
+    if (fp8) {
+      LX_CHECK_ARG((p.epilogue & LX_OPERANDS_FP8) != 0 && p.k_segs <= 1 && !(p.epilogue & LX_EPI_SPLIT_BF16), "lx_gemm_bf16[%d]: LX_OPERANDS_FP8 must be set on every problem of a launch and excludes the split-bf16 mode", i);
+      LX_CHECK_ARG(p.K % 128 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0, "lx_gemm_bf16[%d]: fp8 operands need K %% 128 == 0 and lda / ldw %% 16 == 0 (K=%d)", i, p.K);
+      if (p.col_scale) LX_CHECK_ARG(((uintptr_t)p.col_scale & 15) == 0, "lx_gemm_bf16[%d]: col_scale must be 16-byte aligned", i);
+      if (p.lora_t) LX_CHECK_ARG(p.lora_r <= 4 && p.lora_nsplit <= 4, "lx_gemm_bf16[%d]: the fp8 path applies LoRA in the tile prologue only (rank <= 4, <= 4 slabs)", i);
+      if ((p.epilogue & 0xff) == LX_EPI_STORE_FP8) LX_CHECK_ARG(p.out_scale > 0.f && p.ldc % 8 == 0, "lx_gemm_bf16[%d]: LX_EPI_STORE_FP8 needs out_scale > 0 and ldc %% 8 == 0", i);
+    }
     LX_CHECK_ARG(p.k_segs >= 0 && p.k_segs <= 3, "lx_gemm_bf16[%d]: k_segs=%d must be 0..3", i, p.k_segs);
     const int segs = p.k_segs > 1 ? p.k_segs : 1;
     if (segs > 1 || (p.epilogue & LX_EPI_SPLIT_BF16)) split = true;
@@ -846,7 +1076,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     LX_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "lx_gemm_bf16[%d]: operands must be 16-byte aligned", i);
     LX_CHECK_ARG(p.ldc % 8 == 0 && p.ldc >= p.N, "lx_gemm_bf16[%d]: ldc=%d must be >= N and a multiple of 8", i, p.ldc);
     const int epi = p.epilogue & 0xff;
-    LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && epi <= LX_EPI_RESID_F32, "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
+    LX_CHECK_ARG(epi >= LX_EPI_STORE_BF16 && (epi <= LX_EPI_RESID_F32 || (fp8 && epi == LX_EPI_STORE_FP8)), "lx_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
     LX_CHECK_ARG(p.rows_per_batch > 0, "lx_gemm_bf16[%d]: rows_per_batch must be > 0", i);
     if (p.epilogue & LX_W_TILED) LX_CHECK_ARG(p.N % BN == 0 && p.ldw == (segs == 3 ? 2 * p.K : p.K), "lx_gemm_bf16[%d]: LX_W_TILED needs N %% 256 == 0 and ldw == K (2K with k_segs = 3)", i);
     if (p.gate) LX_CHECK_ARG(p.gate_ld >= p.N && p.gate_ld % 4 == 0, "lx_gemm_bf16[%d]: gate_ld=%d", i, p.gate_ld);
@@ -860,6 +1090,21 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     kmax = p.K * segs > kmax ? p.K * segs : kmax;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (fp8) {     // e4m3 operands: all 256-row tiles or all 128-row tiles
+    const int ncu = device_cus() > 0 ? device_cus() : 256;
+    const double ca = (double)((t256 + ncu - 1) / ncu) * round_us(256, kmax / 4), cb = (double)((t128 + ncu - 1) / ncu) * round_us(128, kmax / 4);
+    const int bm = gemm_env().bm ? gemm_env().bm : (cb < ca ? 128 : 256);
+    GemmArgs all;
+    all.n = 0;
+    all.tile_start[0] = 0;
+    for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+    for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, bm);
+    const int t = all.tile_start[all.n];
+    if (bm == 256) hipLaunchKernelGGL(lx_gemm_fp8_kernel<256>, dim3(t), dim3(NTHREADS), 0, s, all);
+    else hipLaunchKernelGGL(lx_gemm_fp8_kernel<128>, dim3(t), dim3(NTHREADS), 0, s, all);
+    LX_LAUNCH_CHECK("lx_gemm_bf16 (fp8)");
+    return LX_OK;
+  }
   if (split) {   // precise mode: all 256-row tiles or all 128-row tiles (no mixed / pair plans)
     const int ncu = device_cus() > 0 ? device_cus() : 256;
     const double ca = (double)((t256 + ncu - 1) / ncu) * round_us(256, kmax), cb = (double)((t128 + ncu - 1) / ncu) * round_us(128, kmax);

@@ -57,6 +57,9 @@ class DiTEngine:
         # fp32 configuration -- split-bf16 MFMA GEMMs (2 or 3 K-segments), fp32 q/k/v, fp32 attention (csrc/precise.hip).
         self.precise_default = False
         self.precise = False
+        # fp8 GEMM path (model_config["gemm_fp8"]; BASELINE configs[4]): e4m3 operand images on the 64-deep f8f6f4 MFMA
+        self.gemm_fp8 = False
+        self.w8: Dict[str, torch.Tensor] = {}          # name -> tiled e4m3 weight / name + ".rs" -> row de-scale, built on first use
         self._gemm_ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------------------------ workspace
@@ -102,6 +105,7 @@ class DiTEngine:
         self.shape = (B, T, N, C)
         self.cond_ready = False
         self.XN2 = self.Y32 = self.YA = self.lat2 = None          # precise-mode buffers, allocated by _setup_precise()
+        self.XN8 = self.Y8 = None                                  # fp8-GEMM operand images, allocated by _setup_fp8()
 
     def _setup_precise(self) -> None:
         """XN2 bf16 [M, 2D] = [hi | lo] of the AdaLN-normalised stream;  Y32 fp32 [M, 3D] = [k | v | q];
@@ -299,6 +303,9 @@ class DiTEngine:
         self.precise = bool(self.model_config.get("precise", self.precise_default))
         if self.precise:
             self._setup_precise()
+        self.gemm_fp8 = bool(self.model_config.get("gemm_fp8", False)) and not self.precise
+        if self.gemm_fp8:
+            self._setup_fp8()
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
@@ -456,6 +463,8 @@ class DiTEngine:
     def double_block(self, i: int) -> None:
         if self.precise:
             return self._double_block_p(i)
+        if self.gemm_fp8:
+            return self._double_block_8(i)
         cfg, w = self.cfg, self.w
         D = cfg.inner_dim
         b = cfg.mod_base_double(i)
@@ -486,6 +495,8 @@ class DiTEngine:
         block's 580 GFLOP of GEMM work are skipped, with bit-identical image rows."""
         if self.precise:
             return self._single_block_p(j, image_out_only)
+        if self.gemm_fp8:
+            return self._single_block_8(j, image_out_only)
         cfg, w = self.cfg, self.w
         D = cfg.inner_dim
         b = cfg.mod_base_single(j)
@@ -499,6 +510,140 @@ class DiTEngine:
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)
+
+    # ------------------------------------------------------------------------------------------ fp8 GEMM path
+    S_X8, S_Y8 = 16.0, 16.0      # fixed activation scales of the e4m3 images: AdaLN-normalised operand / attention output + MLP hidden
+
+    def _setup_fp8(self) -> None:
+        """XN8 u8 [M, D]: e4m3(XN * S_X8);  Y8 u8 [M, 5D] = [attn | mlp]: e4m3(attention output | MLP hidden, * S_Y8) -- again ONE
+        contiguous K = 5D operand for the single block's proj_out. Block weights are quantised once (per-output-row scale) from
+        the packed bf16 weights and kept as tiled e4m3 images (+11.9 GB)."""
+        if self.XN8 is None:
+            D = self.cfg.inner_dim
+            self.XN8 = torch.zeros(self.M, D, dtype=torch.uint8, device=self.device)
+            self.Y8 = torch.zeros(self.M, 5 * D, dtype=torch.uint8, device=self.device)
+        if self.w8:
+            return
+        names = []
+        for i in range(self.cfg.num_layers):
+            names += [f"d{i}.{n}" for n in ("qkv", "qkv_txt", "out", "out_txt", "ff1", "ff1_txt", "ff2", "ff2_txt")]
+        for j in range(self.cfg.num_single_layers):
+            names += [f"s{j}.fused", f"s{j}.out"]
+        for n in names:
+            W = self.w.t[n + ".w"]
+            W = ops.untile_weight(W) if getattr(W, "lx_tiled", False) else W
+            W8, rs = ops.quantize_weight_fp8(W)
+            self.w8[n] = ops.tile_weight(W8) if (W8.shape[0] % 256 == 0 and W8.shape[1] % 128 == 0) else W8
+            self.w8[n + ".rs"] = rs
+
+    def _cs(self, name: str, act_scale: float, rows: Optional[slice] = None) -> torch.Tensor:
+        """col_scale of an fp8 GEMM: 1 / (activation scale x weight-row scale), cached per (weight, activation scale)."""
+        key = f"{name}.cs{act_scale:g}"
+        t = self.w8.get(key)
+        if t is None:
+            t = self.w8[key] = (self.w8[name + ".rs"] / act_scale).contiguous()
+        return t if rows is None else t[rows]
+
+    def _gemm_streams_8(self, A8: torch.Tensor, act_scale: float, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
+                        w_rows: Optional[slice] = None, t_col0: int = 0, gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0,
+                        lora_toff_max: int = 0, gelu: bool = False, only: Optional[Sequence[str]] = None, lora=None, out_scale: float = 0.0):
+        """One grouped fp8 launch over the token streams (the fp8 twin of _gemm_streams). `lora` = (Lora, first row) of a
+        down-projection already in the TL slabs (computed by the caller from whichever image of the operand it has)."""
+        w = self.w
+        row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
+        lo, lr0 = lora if lora is not None else (None, 0)
+        probs = []
+        for s_, L in self._streams():
+            if only is not None and s_ not in only:
+                continue
+            name = txt if (s_ == "txt" and txt is not None) else main
+            a, c = self.rows(A8, s_), self.rows(Cbuf, s_)
+            W8, bias = self.w8[name], w.t[name + ".b"]
+            if w_rows is not None:
+                tiled = getattr(W8, "lx_tiled", False)
+                W8, bias = W8[w_rows], bias[w_rows]
+                if tiled:
+                    W8.lx_tiled = True
+            kw = dict(bias=bias, epilogue=epilogue | (LX_EPI_GELU if gelu else 0), rows_per_batch=L, fp8=True, col_scale=self._cs(name, act_scale, w_rows),
+                      out_scale=out_scale)
+            if gate_off is not None:
+                mods = self.cmods if s_ == "cond" else self.mods
+                kw["gate"] = mods[:, gate_off[s_]:]
+            if lo is not None and name == main and row0[s_] >= lr0 and (s_ == "cond" or (s_ == "img" and self.latent_lora) or
+                                                                         (s_ == "txt" and self.latent_lora and txt is None)):
+                up = lo.up[w_rows] if w_rows is not None else lo.up
+                kw.update(lora_t=self.TL[row0[s_]:row0[s_] + a.shape[0], t_col0:], lora_up=up, lora_mod_cols=lora_mod_cols,
+                          lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
+            probs.append(ops.gemm_desc(a, W8, c, **kw))
+        ops.gemm(probs)
+
+    def _lora_t8(self, X8: torch.Tensor, act_scale: float, name: str, include_txt: bool = False):
+        """LoRA down-projection from an e4m3 operand image (the MLP hidden / [attn | mlp] exist only as fp8 in this mode)."""
+        lo = self.w.lora.get(name)
+        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0:
+            return None
+        r0, n = self._lora_rows(include_txt)
+        t = self.TL[r0:r0 + n, : lo.down.shape[0]]
+        ops.lora_down_fp8(X8[r0:r0 + n], self.lora_scale / act_scale, lo.down, t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
+        return lo, r0
+
+    def _ln8(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
+        row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
+        segs = []
+        for s_, L in self._streams():
+            mods = self.cmods if s_ == "cond" else self.mods
+            b0 = base_by_stream[s_]
+            segs.append((row0[s_], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
+        ops.ln_modulate_fp8_segs(self.X, segs, self.XN, self.XN8, self.mods.stride(0), self.S_X8)
+
+    def _lora_pair(self, A: torch.Tensor, name: str, include_txt: bool = False):
+        lo, r0 = self._lora_t(A, name, include_txt=include_txt)
+        return None if lo is None else (lo, r0)
+
+    def _double_block_8(self, i: int) -> None:
+        cfg, w = self.cfg, self.w
+        D = cfg.inner_dim
+        b = cfg.mod_base_double(i)
+        base = {"img": b, "cond": b, "txt": b + 6 * D}
+        p = f"d{i}"
+        Y, Y8 = self.Y, self.Y8
+        self._ln8(base, 0, D)                                                             # XN (bf16, for the LoRA down) + XN8
+        self._gemm_streams_8(self.XN8, self.S_X8, Y[:, : 3 * D], p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D,
+                             lora_toff_max=2, lora=self._lora_pair(self.XN, p + ".qkv"))
+        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+        Ya = Y[:, 2 * D: 3 * D]
+        ops.convert_fp8(Ya, Y8[:, :D], self.S_Y8)                                          # attention output -> e4m3 image
+        gate = {s_: base[s_] + 2 * D for s_ in base}
+        self._gemm_streams_8(Y8[:, :D], self.S_Y8, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate,
+                             lora=self._lora_pair(Ya, p + ".out"))
+        if self.C and self.model_config.get("add_cond_attn", False):
+            raise NotImplementedError("add_cond_attn is not wired into the fp8 GEMM path (use the bf16 or the precise mode)")
+        self._ln8(base, 3 * D, 4 * D)
+        self._gemm_streams_8(self.XN8, self.S_X8, Y8[:, D:], p + ".ff1", p + ".ff1_txt", epilogue=ops.LX_EPI_STORE_FP8, gelu=True, out_scale=self.S_Y8)
+        gate = {s_: base[s_] + 5 * D for s_ in base}
+        self._gemm_streams_8(Y8[:, D:], self.S_Y8, self.X, p + ".ff2", p + ".ff2_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate,
+                             lora=self._lora_t8(Y8[:, D:], self.S_Y8, p + ".ff2"))
+
+    def _single_block_8(self, j: int, image_out_only: bool = False) -> None:
+        cfg, w = self.cfg, self.w
+        D, r = cfg.inner_dim, cfg.lora_r
+        b = cfg.mod_base_single(j)
+        base = {"img": b, "cond": b, "txt": b}
+        p = f"s{j}"
+        Y, Y8 = self.Y, self.Y8
+        self._ln8(base, 0, D)
+        lora = self._lora_pair(self.XN, p + ".fused", include_txt=True)
+        only = ("img",) if image_out_only else None
+        # the fused [k | v | q | mlp] weight in two launches: q/k/v as bf16 for the attention prep, the MLP hidden straight to e4m3
+        self._gemm_streams_8(self.XN8, self.S_X8, Y[:, : 3 * D], p + ".fused", None, epilogue=LX_EPI_STORE_BF16, w_rows=slice(0, 3 * D),
+                             lora_mod_cols=D, lora_toff_max=2, lora=lora)
+        self._gemm_streams_8(self.XN8, self.S_X8, Y8[:, D:], p + ".fused", None, epilogue=ops.LX_EPI_STORE_FP8, gelu=True, out_scale=self.S_Y8,
+                             w_rows=slice(3 * D, 7 * D), t_col0=3 * r, only=only, lora=lora)
+        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
+        ops.convert_fp8(Y[:, 2 * D: 3 * D], Y8[:, :D], self.S_Y8)
+        gate = {s_: b + 2 * D for s_ in base}
+        self._gemm_streams_8(Y8, self.S_Y8, self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate, only=only,
+                             lora=self._lora_t8(Y8, self.S_Y8, p + ".out", include_txt=True))
 
     # ------------------------------------------------------------------------------------------ precise mode
     def _desc_p(self, A2: torch.Tensor, name: str, Cbuf: torch.Tensor, *, K: int, a_lo_off: int, w_rows: Optional[slice] = None, **kw):
@@ -735,7 +880,7 @@ class DiTEngine:
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise)
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8)
         g = self.graphs.get(key)
         if g is None:
             if not self._warmed:                                  # lazy code-object loads must not happen inside capture

@@ -12,7 +12,8 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_W_TILED, AttnDesc, GemmDesc, check, lib)
+from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_W_TILED,
+                   AttnDesc, GemmDesc, check, lib)
 
 
 def _stream() -> int:
@@ -33,10 +34,12 @@ def _req(t: torch.Tensor, dtype, name: str):
 def tile_weight(W: torch.Tensor) -> torch.Tensor:
     """nn.Linear weight [N,K] bf16 (N % 256 == 0, K % 64 == 0) -> the pre-tiled layout LX_W_TILED expects, same shape/bytes:
     [N/256][K/64] blocks of 256 rows x 64 cols; inside a block row r, the 16-B chunk c sits at position c ^ ((r>>1)&7)
-    (the LDS swizzle of gemm.hip), so the kernel's global->LDS DMA copies a block verbatim. Pure layout plumbing."""
+    (the LDS swizzle of gemm.hip), so the kernel's global->LDS DMA copies a block verbatim. Pure layout plumbing.
+    e4m3 weights (uint8 [N,K], K % 128 == 0) tile the same way with 128 elements per 128-B block row (16 per chunk)."""
     N, K = W.shape
-    assert N % 256 == 0 and K % 64 == 0 and W.dtype == torch.bfloat16
-    t = W.reshape(N // 256, 256, K // 64, 8, 8).permute(0, 2, 1, 3, 4)            # [nb, kb, row, chunk, 8]
+    e = 16 // W.element_size()                       # elements per 16-B chunk
+    assert W.dtype in (torch.bfloat16, torch.uint8) and N % 256 == 0 and K % (8 * e) == 0
+    t = W.reshape(N // 256, 256, K // (8 * e), 8, e).permute(0, 2, 1, 3, 4)       # [nb, kb, row, chunk, e]
     r = torch.arange(256, device=W.device)
     src = torch.arange(8, device=W.device)[None, :] ^ ((r >> 1) & 7)[:, None]    # position p holds chunk p ^ f(r)
     t = t[:, :, r[:, None], src]                                                  # gather chunks per row
@@ -45,14 +48,38 @@ def tile_weight(W: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def untile_weight(Wt: torch.Tensor) -> torch.Tensor:
+    """Inverse of tile_weight (the chunk XOR is an involution): the tiled image -> nn.Linear row-major [N,K]."""
+    N, K = Wt.shape
+    e = 16 // Wt.element_size()
+    t = Wt.reshape(N // 256, K // (8 * e), 256, 8, e)
+    r = torch.arange(256, device=Wt.device)
+    src = torch.arange(8, device=Wt.device)[None, :] ^ ((r >> 1) & 7)[:, None]
+    return t[:, :, r[:, None], src].permute(0, 2, 1, 3, 4).contiguous().reshape(N, K)
+
+
+def quantize_weight_fp8(W: torch.Tensor):
+    """bf16 / fp32 [N,K] (row-major) -> (e4m3 bytes [N,K] uint8, row_descale [N] fp32): row n is stored as e4m3(W[n] * s_n) with
+    s_n = 448 / max|W[n]| (per-output-channel scale, folded into the GEMM's col_scale), row_descale = 1 / s_n."""
+    Wf = W.float()
+    amax = Wf.abs().amax(dim=1).clamp_min(1e-12)
+    s = 448.0 / amax
+    W8 = (Wf * s[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return W8, (1.0 / s).contiguous()
+
+
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
               gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
               gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0, k_segs=0, a_lo_off=0,
-              c_lo_off=0) -> GemmDesc:
+              c_lo_off=0, fp8=False, col_scale=None, out_scale=0.0) -> GemmDesc:
     """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome).
     Precise mode: k_segs = 2 | 3 with A's lo image a_lo_off columns after the hi image (pass K explicitly: A then has more than K
     columns) and, for 3, W = [N, 2K] = [W_hi | W_lo] (pass N, K); c_lo_off != 0 adds LX_EPI_SPLIT_BF16 (hi/lo output pair)."""
-    _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
+    if fp8:      # e4m3 byte operands (LX_OPERANDS_FP8): acc * col_scale[n] first, then the usual epilogue
+        _req(A, torch.uint8, "A"); _req(W, torch.uint8, "W")
+        epilogue |= LX_OPERANDS_FP8
+    else:
+        _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
     d = GemmDesc()
     d.A, d.W, d.C = A.data_ptr(), W.data_ptr(), C_.data_ptr()
     d.bias = _p(bias)
@@ -74,7 +101,9 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
     if getattr(W, "lx_tiled", False):
         epilogue |= LX_W_TILED
     d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
-    want = torch.bfloat16 if (epilogue & 0xff) == LX_EPI_STORE_BF16 else torch.float32
+    d.col_scale, d.out_scale = _p(col_scale), float(out_scale)
+    kind = epilogue & 0xff
+    want = torch.bfloat16 if kind == LX_EPI_STORE_BF16 else (torch.uint8 if kind == LX_EPI_STORE_FP8 else torch.float32)
     _req(C_, want, "C")
     return d
 
@@ -268,6 +297,31 @@ def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bia
         e.record()
         return
     check(lib.lx_attn_fwd_fp8(*args), "lx_attn_fwd_fp8")
+
+
+# ---- fp8 GEMM path (include/lx.h "fp8 GEMM path") ----------------------------------------------------------------------
+def ln_modulate_fp8_segs(X, segs, Y, Y8, mod_ld, y8_scale, eps=1e-6) -> None:
+    """segs as in ln_modulate_segs; Y bf16 (or None) and Y8 uint8 (e4m3 of y * y8_scale), same row indexing."""
+    n = len(segs)
+    arr = (L.LnSeg * n)()
+    for i, (row0, n_rows, rpb, sh, sc) in enumerate(segs):
+        arr[i].row0, arr[i].n_rows, arr[i].rows_per_batch = row0, n_rows, rpb
+        arr[i].shift, arr[i].scale = sh.data_ptr(), sc.data_ptr()
+    check(lib.lx_ln_modulate_fp8_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, _p(Y), Y.stride(0) if Y is not None else 0, Y8.data_ptr(),
+                                      Y8.stride(0), float(y8_scale), X.shape[1], eps, _stream()), "lx_ln_modulate_fp8_segs")
+
+
+def convert_fp8(src: torch.Tensor, dst: torch.Tensor, scale: float) -> None:
+    """src bf16 | fp32 [M,K] (row stride honoured) -> dst uint8 [M,K] = e4m3(src * scale)."""
+    _req(dst, torch.uint8, "dst")
+    check(lib.lx_convert_fp8(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), dst.data_ptr(), dst.stride(0), float(scale),
+                             src.shape[0], src.shape[1], _stream()), "lx_convert_fp8")
+
+
+def lora_down_fp8(X8: torch.Tensor, x_descale: float, Adown: torch.Tensor, T: torch.Tensor, n_split: int = 1, split_stride: int = 0) -> None:
+    _req(X8, torch.uint8, "X8"); _req(Adown, torch.bfloat16, "Adown"); _req(T, torch.float32, "T")
+    check(lib.lx_lora_down_fp8(X8.data_ptr(), X8.stride(0), float(x_descale), Adown.data_ptr(), T.data_ptr(), T.stride(0), X8.shape[0], X8.shape[1],
+                               Adown.shape[0], n_split, split_stride, _stream()), "lx_lora_down_fp8")
 
 
 # ---- precise mode (include/lx.h "Precise mode") -----------------------------------------------------------------------
