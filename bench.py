@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0      # MI355X dense fp8 MFMA (same table): the peak the fp8 paths (--fp8) are priced against
 D, T_TXT, STEPS = 3072, 512, 28
 ROOFLINE_STEPS = (9, 18)     # denoise steps of the last timed image whose GEMM / attention launches are bracketed with HIP events
 
@@ -71,11 +72,14 @@ def cpu_baseline(threads: int):
                       f"extrapolated x(19,38) blocks x28 steps"}
 
 
-def parity_check(precise: bool = False):
+def parity_check(precise: bool = False, fp8: bool = False):
     """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
-    timed region) at full depth and width on this GPU."""
+    timed region) at full depth and width on this GPU, in the mode the timed region ran."""
     from oracle.parity import full_depth_parity
-    return full_depth_parity("cuda:0", steps=STEPS, precise=precise)
+    mc = {"union_cond_attn": True}
+    if fp8:
+        mc.update(attn_fp8=True, gemm_fp8=True)
+    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc)
 
 
 def _gemm_traffic_mb():
@@ -221,15 +225,21 @@ def main():
                           "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)},
                "outputs_finite": finite,
                "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
-               "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
+               "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS), 4)}
         if timer is not None:
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one image
             traffic, traffic_src = _gemm_traffic_mb()
-            res["roofline"] = {"bound": "mfma", "kernel": "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)", "achieved": round(ach, 1),
-                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            gpeak = PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS
+            gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if a.fp8 else
+                     "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if a.precise else
+                     "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)")
+            if a.fp8 or a.precise:
+                traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels
+            res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
+                               "peak": gpeak, "unit": "TFLOP/s", "frac": round(ach / gpeak, 4), "traffic": traffic,
                                "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",
                                "traffic_source": traffic_src,
                                "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
@@ -238,8 +248,11 @@ def main():
                                "timed": f"HIP events around every launch of denoise steps {list(ROOFLINE_STEPS)} of the last timed image"}
             if at:
                 aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                res["roofline_attention"] = {"bound": "mfma", "kernel": "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)", "achieved": round(aa, 1), "peak": PEAK_BF16_TFLOPS,
-                                             "unit": "TFLOP/s", "frac": round(aa / PEAK_BF16_TFLOPS, 4), "launches": at["launches"],
+                apeak = PEAK_FP8_TFLOPS if a.fp8 else (157.3 if a.precise else PEAK_BF16_TFLOPS)
+                aname = ("lx_attn_fp8_kernel (e4m3 32x32x64 MFMA)" if a.fp8 else "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if a.precise
+                         else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)")
+                res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
+                                             "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
                                              "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
                                              "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / a.steps), 3)}
         if world == 1 and not a.no_cpu_baseline:
@@ -248,7 +261,7 @@ def main():
             del model, pw, batches, out
             torch.cuda.empty_cache()
             try:
-                res["parity"] = parity_check(a.precise)
+                res["parity"] = parity_check(a.precise, a.fp8)
             except Exception as e:          # the checker must never take the measurement down with it
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))

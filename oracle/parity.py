@@ -118,7 +118,10 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
                      prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent", model_config=mc, default_lora=True,
                      use_brain_condition=False, guidance_scale=3.5).images
     errs = [e for _, e in per_step]
-    rec = {"mode": "precise (split-bf16 MFMA, fp32 attention)" if precise else "bf16 MFMA operands, fp32 accumulate / residual",
+    mode = "precise (split-bf16 MFMA, fp32 attention)" if precise else "bf16 MFMA operands, fp32 accumulate / residual"
+    if mc.get("gemm_fp8") or mc.get("attn_fp8"):
+        mode = "fp8 e4m3 operands (" + " + ".join(k for k in ("gemm_fp8", "attn_fp8") if mc.get(k)) + "), fp32 accumulate / residual"
+    rec = {"mode": mode,
            "oracle": "oracle/flux_ref.py fp32 on the same GPU (torch-ROCm), identical weights and inputs",
            "blocks": [num_layers, num_single_layers], "steps": steps, "tokens": [n_txt, N, N],
            "noise_pred_relerr_first": round(errs[0], 6), "noise_pred_relerr_max": round(max(errs), 6),
