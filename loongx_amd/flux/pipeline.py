@@ -148,7 +148,8 @@ class LxFluxPipeline:
                              in_channels=c.get("in_channels", 64), joint_attention_dim=c.get("joint_attention_dim", 4096),
                              pooled_projection_dim=c.get("pooled_projection_dim", 768), guidance_embeds=c.get("guidance_embeds", True),
                              axes_dims_rope=tuple(c.get("axes_dims_rope", (16, 56, 56))))
-        tr = LxFluxTransformer.from_state_dict(load_dir(tdir), cfg or FluxConfig(), device, lora_scale, precise=dtype == torch.float32)
+        tsd = load_dir(tdir)
+        tr = LxFluxTransformer.from_state_dict(tsd, cfg or FluxConfig.from_state_dict(tsd), device, lora_scale, precise=dtype == torch.float32)
         vae = text = None
         vdir = os.path.join(path, "vae")
         if load_vae and os.path.isdir(vdir):
