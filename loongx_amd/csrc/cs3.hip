@@ -336,32 +336,51 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 }
 
 // fp32 linear for a FEW rows (M <= 16: the encoder projection heads, 16384 -> 2048 -> 4096 ...): weight streaming, HBM bound.
-// A wave owns 2 output columns and streams their weight rows once with 16-B loads (lanes split K), all M rows' accumulators
-// stay in registers (the x rows are L2-resident: M*K*4 <= 1 MB); 4 waves per block, N/8 blocks: a 16384 x 2048 layer puts one
+// A wave owns 2 output columns and streams their weight rows once with 16-B loads (lanes split K); the M x-rows of each
+// 256-wide K chunk are staged ONCE per block in LDS and shared by its 4 waves (reading x per wave from L2 made the kernel
+// L2-bound: 16 x loads per 2 weight loads), all rows' accumulators stay in registers; N/8 blocks: a 16384 x 2048 layer puts one
 // block on every CU. No split-K, no atomics: each output is one wave's shuffle reduction in a fixed order.
 template <int MR>
 __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M, int N,
                                                                 int K, int accumulate) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) float xs[2][MR][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = (blockIdx.x * 4 + wave) * 2;
-  if (n0 >= N) return;
-  const float* w0 = W + (size_t)n0 * ldw;
+  const bool active = n0 < N;
+  const float* w0 = W + (size_t)min(n0, N - 1) * ldw;
   const float* w1 = W + (size_t)min(n0 + 1, N - 1) * ldw;
   float acc[MR][2];
 #pragma unroll
   for (int i = 0; i < MR; ++i) acc[i][0] = acc[i][1] = 0.f;
-  for (int k = lane * 4; k < K; k += 256) {
-    const f32x4 a = *(const f32x4*)(w0 + k), b = *(const f32x4*)(w1 + k);
+  auto stage = [&](int k0, int buf) {           // MR x 256 floats: thread -> (row = tid / 64 + 4 j, 4 consecutive k)
 #pragma unroll
-    for (int i = 0; i < MR; ++i) {
-      if (i < M) {
-        const f32x4 x = *(const f32x4*)(X + (size_t)i * ldx + k);
+    for (int j = 0; j < (MR + 3) / 4; ++j) {
+      const int r = (tid >> 6) + 4 * j, k = k0 + (tid & 63) * 4;
+      if (r < MR) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < M && k < K) v = *(const f32x4*)(X + (size_t)r * ldx + k);
+        *(f32x4*)&xs[buf][r][(tid & 63) * 4] = v;
+      }
+    }
+  };
+  stage(0, 0);
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += 256, buf ^= 1) {
+    __syncthreads();                              // chunk k0 is in xs[buf]; everyone is done with xs[buf ^ 1]
+    if (k0 + 256 < K) stage(k0 + 256, buf ^ 1);
+    const int k = k0 + lane * 4;
+    if (active && k < K) {
+      const f32x4 a = *(const f32x4*)(w0 + k), b = *(const f32x4*)(w1 + k);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const f32x4 x = *(const f32x4*)&xs[buf][i][lane * 4];
         acc[i][0] = fmaf(x[0], a[0], fmaf(x[1], a[1], fmaf(x[2], a[2], fmaf(x[3], a[3], acc[i][0]))));
         acc[i][1] = fmaf(x[0], b[0], fmaf(x[1], b[1], fmaf(x[2], b[2], fmaf(x[3], b[3], acc[i][1]))));
       }
     }
   }
+  if (!active) return;
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
