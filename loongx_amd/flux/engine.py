@@ -43,7 +43,7 @@ class DiTEngine:
         self.cond_ready = False
         self.sched = None
         self.graphs: Dict = {}
-        self._warmed = False
+        self._warmed = set()             # kernel sets (modes) that have run eagerly once: first launches must not happen inside a capture
         import os
         self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
         self.model_config: Dict = {}
@@ -306,6 +306,11 @@ class DiTEngine:
         self.gemm_fp8 = bool(self.model_config.get("gemm_fp8", False)) and not self.precise
         if self.gemm_fp8:
             self._setup_fp8()
+        if self.model_config.get("attn_fp8", False) and not self.precise and self.Q8 is None:      # never first allocated inside a capture
+            u8 = torch.uint8
+            self.Q8 = torch.zeros(self.M, cfg.inner_dim, dtype=u8, device=self.device)
+            self.K8 = torch.zeros(self.M, cfg.inner_dim, dtype=u8, device=self.device)
+            self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
@@ -883,10 +888,11 @@ class DiTEngine:
         key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8)
         g = self.graphs.get(key)
         if g is None:
-            if not self._warmed:                                  # lazy code-object loads must not happen inside capture
+            mode = (self.precise, self.gemm_fp8, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0)
+            if mode not in self._warmed:                          # lazy code-object loads / buffer allocations must not happen inside capture
                 self._forward_eager(self.g_lat, self.g_t, False)
                 torch.cuda.synchronize(self.device)
-                self._warmed = True
+                self._warmed.add(mode)
             if len(self.graphs) >= 4:
                 self.graphs.clear()
             g = torch.cuda.CUDAGraph()

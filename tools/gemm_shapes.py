@@ -25,12 +25,13 @@ def launch(N, K, kind, nmod):
             kw.update(lora_t=Tl, lora_up=Bu, lora_mod_cols=D if nmod > 1 else 0, lora_toff_max=nmod - 1, lora_nsplit=4, lora_split_stride=Tls.stride(0))
         ds.append(ops.gemm_desc(A[r0:r0 + M], Wt if (i == 0 and kind != "fused" and N != D * 0) else W, C[r0:r0 + M], **kw)); r0 += M
     return ds, (A, W, Wt, bias, Ad, Bu, Tls, gate, C)
+WS = ops.gemm_workspace(dev) if os.environ.get('LX_PAIR_PLAN', '1') != '0' else None      # the engine's per-stream pair-plan workspace
 def timed(ds, it=20):
-    for _ in range(3): ops.gemm(ds)
+    for _ in range(3): ops.gemm(ds, WS)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(it): ops.gemm(ds)
+    for _ in range(it): ops.gemm(ds, WS)
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / it
 specs = [("qkv", 3 * D, D, "bf16", 3, 19), ("attn out", D, D, "resid", 1, 19), ("ff1", 4 * D, D, "gelu", 1, 19), ("ff2", D, 4 * D, "resid", 1, 19),
