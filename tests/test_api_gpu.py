@@ -238,3 +238,61 @@ def test_scheduler_and_latent_utils_match_oracle():
     p = LxFluxPipeline._pack_latents(z, 2, 16, 8, 8)
     assert torch.equal(p, fm.pack_latents(z)) and torch.equal(LxFluxPipeline._unpack_latents(p, 64, 64, 16), z)
     assert torch.equal(LxFluxPipeline._prepare_latent_image_ids(1, 8, 8, "cpu", torch.float32), fm.prepare_latent_image_ids(4, 4))
+
+
+def test_generate_edge_cases_batch_nonsquare_callback_nocondition_errors():
+    """generate() surface beyond the golden cases: a batch of two prompts, a non-square 64x96 edit (24 image tokens: ragged against
+    every tile size), no condition at all, `callback_on_step_end` rewriting the latents, the latent noise drawn from `generator`,
+    `num_images_per_prompt`, and the input checks of the reference pipeline (generate.py:97-106)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ducks
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    tr = ducks.generate_transformer()
+    _, model = _mk_model(tr)
+    pipe = model.flux_pipe
+    g = torch.Generator().manual_seed(12)
+    B, H2, W2 = 2, 4, 6                                                 # 64 x 96 pixels -> 4 x 6 packed grid
+    lat = torch.randn(B, H2 * W2, 64, generator=g)
+    cond = torch.randn(B, H2 * W2, 64, generator=g)
+    pe, pooled = torch.randn(B, 512, 4096, generator=g) * 0.1, torch.randn(B, 768, generator=g)
+    ids = fm.prepare_latent_image_ids(H2, W2)
+    cids = ids.clone()
+    cids[:, 2] -= W2
+    with torch.no_grad():
+        want = fr.denoise_loop(tr, fm.FlowMatchEulerDiscreteScheduler(), lat, pe, pooled, torch.zeros(512, 3), ids, cond, cids, num_inference_steps=3)
+        want_nc = fr.denoise_loop(tr, fm.FlowMatchEulerDiscreteScheduler(), lat, pe, pooled, torch.zeros(512, 3), ids, None, None, num_inference_steps=3)
+    kw = dict(height=H2 * 16, width=W2 * 16, num_inference_steps=3, prompt_embeds=pe.cuda(), pooled_prompt_embeds=pooled.cuda(),
+              output_type="latent", model_config={}, default_lora=True, use_brain_condition=False)
+    c = Condition("subject", latents=cond.cuda(), latent_hw=(H2, W2), position_delta=[0, -W2])
+    out = generate(model, pipe, conditions=[c], latents=lat.cuda(), **kw)
+    assert out.images.shape == (B, H2 * W2, 64) and relerr(out.images.cpu(), want) < 3e-2
+    out_nc = generate(model, pipe, conditions=None, latents=lat.cuda(), **kw)
+    assert relerr(out_nc.images.cpu(), want_nc) < 3e-2 and relerr(out_nc.images.cpu(), want) > 1e-3
+    # callback: sees every step, may replace the latents (here: zero them after the last step)
+    seen = []
+
+    def cb(pipe_, i, t, kwargs):
+        seen.append((i, float(t), tuple(kwargs["latents"].shape)))
+        return {"latents": kwargs["latents"] * 0} if i == 2 else {}
+    z = generate(model, pipe, conditions=[c], latents=lat.cuda(), callback_on_step_end=cb, **kw).images
+    assert [s[0] for s in seen] == [0, 1, 2] and seen[0][1] > seen[2][1] and float(z.abs().max()) == 0.0
+    # noise from the generator: reproducible, and num_images_per_prompt multiplies the batch
+    kw1 = dict(kw, prompt_embeds=pe[:1].cuda(), pooled_prompt_embeds=pooled[:1].cuda())
+    a = generate(model, pipe, conditions=None, generator=torch.Generator(device="cuda").manual_seed(3), **kw1).images
+    b = generate(model, pipe, conditions=None, generator=torch.Generator(device="cuda").manual_seed(3), **kw1).images
+    assert torch.equal(a, b) and a.shape == (1, H2 * W2, 64)
+    two = generate(model, pipe, conditions=None, num_images_per_prompt=2, generator=torch.Generator(device="cuda").manual_seed(3), **kw1).images
+    assert two.shape == (2, H2 * W2, 64) and not torch.equal(two[0], two[1])
+    # input checks (diffusers FluxPipeline.check_inputs, called at generate.py:97-106)
+    with pytest.raises(ValueError):
+        generate(model, pipe, conditions=None, latents=lat.cuda(), **dict(kw, height=66))
+    with pytest.raises(ValueError):
+        generate(model, pipe, conditions=None, latents=lat.cuda(), prompt="x", **kw)
+    with pytest.raises(ValueError):
+        generate(model, pipe, conditions=None, latents=lat.cuda(), **{k: v for k, v in kw.items() if k != "pooled_prompt_embeds"})
+    with pytest.raises(AssertionError):
+        generate(model, pipe, conditions=[c, c], latents=lat.cuda(), **kw)
+    with pytest.raises(NotImplementedError):                            # no text encoder plugged in: a prompt string cannot be encoded
+        generate(model, pipe, conditions=None, latents=lat.cuda(), prompt="make it red", **{k: v for k, v in kw.items() if "embeds" not in k})
