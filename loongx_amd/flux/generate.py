@@ -191,7 +191,10 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
                 joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, lx_schedule=(i, sched_ts))[0]
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if callback_on_step_end is not None:
-                callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
+                scope = locals()                                        # (a comprehension has its own locals() before 3.12)
+                callback_kwargs = {}
+                for k in callback_on_step_end_tensor_inputs:
+                    callback_kwargs[k] = scope[k]
                 callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
                 latents = callback_outputs.pop("latents", latents)
                 prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
