@@ -60,7 +60,12 @@ enum {
   LX_EPI_SPLIT_BF16 = 0x400, /* OR-able flag (with LX_EPI_STORE_BF16): also store bf16(x - bf16(x)) at column n + c_lo_off, so
                             that a consumer GEMM with k_segs >= 2 sees x to 16 mantissa bits (precise mode) */
   LX_EPI_STORE_FP8 = 3,  /* (fp8 GEMMs only) C(e4m3 bytes) = act(acc * col_scale + bias) * out_scale, saturated to +-448 */
-  LX_OPERANDS_FP8 = 0x800 /* OR-able flag: A and W are OCP e4m3 bytes (lda / ldw in bytes, K %% 128 == 0), products on the
+  LX_EPI_QKV = 0x1000,   /* OR-able flag (with LX_EPI_STORE_BF16, bf16 operands): the first 3*qkv_d output columns are the attention
+                          * projections [k | v | q] of heads of 128 (block.py:43-99): the epilogue applies RMSNorm(128, norm_k /
+                          * norm_q) + RoPE to the k and q columns in fp32 BEFORE the single bf16 rounding and stores them in place,
+                          * and writes the v columns straight into the V^T image the attention kernel reads (and nowhere else):
+                          * lx_qkv_prep of the same buffer is then not needed. See the qkv_* fields. */
+  LX_OPERANDS_FP8 = 0x800 /* OR-able flag: A and W are OCP e4m3 bytes (lda / ldw in bytes, K % 128 == 0), products on the
                             64-deep f8f6f4 MFMA at twice the bf16 rate; acc[m,n] *= col_scale[n] before everything else.
                             BASELINE configs[4]; opt-in (model_config["gemm_fp8"]). Every problem of a launch must carry it. */
 };
@@ -90,6 +95,17 @@ typedef struct lx_gemm_desc {
   int32_t c_lo_off;          /* LX_EPI_SPLIT_BF16: column distance of the lo image of the output */
   float out_scale;           /* LX_EPI_STORE_FP8: multiplier applied before the e4m3 rounding */
   const float* col_scale;    /* LX_OPERANDS_FP8: [N] fp32, 1 / (activation scale * weight scale of row n); NULL => 1 */
+  /* LX_EPI_QKV (replaces lx_qkv_prep for this problem's rows; block.py:60-99 attn.norm_q / norm_k + apply_rotary_emb):
+   * columns [0, qkv_d) = k, [qkv_d, 2 qkv_d) = v, [2 qkv_d, 3 qkv_d) = q; qkv_d % 256 == 0; rows_per_batch % 32 == 0 (one
+   * token stream: row m is position (m % rows_per_batch) of batch m / rows_per_batch); N may stop short of 3 qkv_d at a
+   * multiple of 256 (a block whose q nobody reads). */
+  const float* qkv_norm_q;   /* [128] fp32 RMSNorm weights (eps 1e-6) */
+  const float* qkv_norm_k;   /* [128] */
+  const float* qkv_rope;     /* [rows_per_batch, 128] fp32: (cos, sin) of rotary pair i at [2i, 2i+1] (identity: 1, 0) */
+  void* qkv_vt;              /* bf16 [B * qkv_d/128, 128, qkv_vt_ld]: V^T image, key p of the stream at slot qkv_vt_pos0 + il(p), il =
+                              * the 16-key interleave of lx_qkv_prep */
+  int32_t qkv_d, qkv_vt_ld, qkv_vt_pos0;   /* qkv_vt_ld, qkv_vt_pos0 % 64 == 0 */
+  int32_t _pad0;
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4

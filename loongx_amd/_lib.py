@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
 LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED, LX_EPI_SPLIT_BF16 = 0, 1, 2, 0x100, 0x200, 0x400
-LX_EPI_STORE_FP8, LX_OPERANDS_FP8 = 3, 0x800
+LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_EPI_QKV = 3, 0x800, 0x1000
 LX_GEMM_MAX_GROUP = 4
 
 
@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32),
                 ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32),
                 ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32), ("out_scale", C.c_float),
-                ("col_scale", C.c_void_p)]
+                ("col_scale", C.c_void_p),
+                ("qkv_norm_q", C.c_void_p), ("qkv_norm_k", C.c_void_p), ("qkv_rope", C.c_void_p), ("qkv_vt", C.c_void_p),
+                ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class AttnDesc(C.Structure):

@@ -46,6 +46,7 @@ struct GemmArgs {
   int m_base[MAX_SUB];       // row of the original problem at which this (sub)problem starts (for the gate batch index)
   int n;
 };
+static_assert(2 * sizeof(GemmArgs) + 16 <= 4096, "lx_gemm_mixed_kernel takes two plans by value: the kernarg segment is 4 KiB");
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -167,6 +168,142 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
   return (uint32_t)w;
 }
 
+
+// ---- LX_EPI_QKV: RMSNorm(128) + RoPE on the k / q columns, V^T image for the v columns, inside the projection's epilogue --------
+// (block.py:60-99: attn.norm_q / norm_k, apply_rotary_emb; replaces the qkv_prep pass over the projected buffer: one read + one
+//  write of 3 D columns per token, 22 us x 57 launches per denoise step at S = 2560.) A 256-column tile is two whole heads of
+// one kind (qkv_d % 256 == 0); a wave holds 64 columns, so the sum of squares of a head's row is the sum of two waves' partial
+// sums, exchanged through LDS once per tile. Everything is computed in fp32 on the accumulators: one bf16 rounding instead of
+// the two of the separate pass.
+__device__ __forceinline__ int qkv_vt_interleave(int key) {  // within every 16 keys: [0-3, 8-11, 4-7, 12-15] (= rowops.hip)
+  return (key & ~15) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
+}
+
+template <int BM, int MI>
+__device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
+                                                  int wave, int wm, int wn, int lane, int l31, int lhi) {
+  const int M = P.M, D = P.qkv_d, L = P.rows_per_batch;
+  const int kind = n0 / D;                     // 0: k, 1: v, 2: q (tile-uniform)
+  const int mw0 = m0 + wm * (BM / 2), nw0 = n0 + wn * 64;
+  constexpr int EP_LD = 68;
+  float* patch = (float*)smem + wave * (32 * EP_LD);
+  float* ssq = (float*)smem + 8 * (32 * EP_LD);          // [8 waves][BM / 2]: per-row partial sums of squares
+  // bias in the accumulator layout: n = nw0 + j*32 + 8*rq + 4*lhi + c
+  if (P.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 b = *(const f32x4*)(P.bias + nw0 + j * 32 + rq * 8 + 4 * lhi);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[j][i][rq * 4 + c] += b[c];
+      }
+  }
+  __syncthreads();                                   // every wave is done with the operand tiles
+  auto to_patch = [&](int i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v = {acc[j][i][rq * 4], acc[j][i][rq * 4 + 1], acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
+        *(f32x4*)(patch + l31 * EP_LD + j * 32 + rq * 8 + 4 * lhi) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (kind == 1) {
+    // v: 32 keys x 64 head dims per block -> V^T rows of 32 slots (64 B), 16 B per lane
+    const int h = (nw0 - D) >> 7, d0 = (nw0 - D) & 127, H = D >> 7;
+    const int dl = lane >> 2, g = lane & 3;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = mw0 + i * 32;
+      if (mb >= M) continue;                         // M % 32 == 0: a block is whole or absent
+      to_patch(i);
+      const int gm = m_base + mb, b = gm / L, p0 = gm - b * L;
+      uint16_t* vtb = (uint16_t*)P.qkv_vt + ((size_t)(b * H + h) * 128 + d0) * P.qkv_vt_ld + P.qkv_vt_pos0 + p0 + g * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int d = it * 16 + dl;
+        float e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = patch[qkv_vt_interleave(g * 8 + k) * EP_LD + d];
+        u32x4 o = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+        *(u32x4*)(vtb + (size_t)d * P.qkv_vt_ld) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  // k / q: partial sums of squares of this wave's 64 columns, row = lane & 31 of each block
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss = __builtin_fmaf(acc[j][i][r], acc[j][i][r], ss);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lhi == 0) ssq[wave * (BM / 2) + i * 32 + l31] = ss;
+  }
+  const float* __restrict__ nw = kind == 2 ? P.qkv_norm_q : P.qkv_norm_k;
+  const int c8 = (lane & 7) * 8;
+  const int hd = (nw0 & 127) + c8;                   // first of this lane's 8 columns within the head
+  f32x4 w0 = *(const f32x4*)(nw + hd), w1 = *(const f32x4*)(nw + hd + 4);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1)::"memory");
+  __syncthreads();                                   // both halves of every head's sums are in LDS
+  const int ncol = nw0 + c8;
+  const float* own = ssq + wave * (BM / 2);
+  const float* oth = ssq + (wave ^ 1) * (BM / 2);
+  // RoPE rows of a 32-row block: 8 x 16 B per lane. vmcnt is one in-order queue of loads AND stores (see gemm_epilogue): the rows
+  // of block i+1 are requested BEFORE block i's stores, so that waiting for them (vmcnt(4): only the four stores behind them may
+  // still be in flight) never waits for a store's acknowledgement. The loads are inline asm: hipcc's own wait-count pass, which
+  // falls back to vmcnt(0) behind any branch, does not see them, and the counted waits below are the only ones. Blocks are whole
+  // or absent (M % 32 == 0) and a table row index is always < rows_per_batch, so loads and counts need no conditions.
+  f32x4 cs[2][4][2];
+  auto rope_rows = [&](int i, f32x4 (&c)[4][2]) {
+    const int gm = m_base + mw0 + i * 32, b = gm / L, p0 = gm - b * L;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* rp = P.qkv_rope + (size_t)(p0 + t * 8 + (lane >> 3)) * 128 + hd;
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(c[t][0]), "=&v"(c[t][1]) : "v"(rp) : "memory");
+    }
+  };
+  rope_rows(0, cs[0]);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int mb = mw0 + i * 32;
+    if (mb >= M) break;                              // (the loads in flight land in dead registers)
+    f32x4 (&cur)[4][2] = cs[i & 1];
+    to_patch(i);
+    if (i == 0)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[2][0]), "+v"(cur[2][1]), "+v"(cur[3][0]), "+v"(cur[3][1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[2][0]), "+v"(cur[2][1]), "+v"(cur[3][0]), "+v"(cur[3][1])::"memory");
+    if (i + 1 < MI) rope_rows(i + 1, cs[(i + 1) & 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 8 + (lane >> 3), m = mb + row;
+      const f32x4 v0 = *(const f32x4*)(patch + row * EP_LD + c8);
+      const f32x4 v1 = *(const f32x4*)(patch + row * EP_LD + c8 + 4);
+      const float r = rsqrtf((own[i * 32 + row] + oth[i * 32 + row]) * (1.0f / 128.0f) + 1e-6f);
+      float x[8], y[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { x[c] = v0[c] * r * w0[c]; x[4 + c] = v1[c] * r * w1[c]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                  // pairs (2q, 2q+1): out = x*cos + rot*sin, rot = (-x_odd, x_even)
+        const float co = q < 2 ? cur[t][0][2 * q] : cur[t][1][2 * q - 4], si = q < 2 ? cur[t][0][2 * q + 1] : cur[t][1][2 * q - 3];
+        y[2 * q] = x[2 * q] * co - x[2 * q + 1] * si;
+        y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
+      }
+      u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+      *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int BM, int MI, bool SPLIT = false, bool FP8 = false>
 __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&acc)[2][MI], char* smem, int m0, int n0, int m_base,
                                               int wave, int wm, int wn, int lane, int l31, int lhi, bool lora_done, int i_begin = 0, int i_end = MI) {
@@ -191,6 +328,13 @@ __device__ __forceinline__ void gemm_epilogue(const lx_gemm_desc& P, f32x16 (&ac
         lora_sum<MI>(P, sp0, sv, t4);
       }
       lora_apply<MI>(u4, t4, lhi, acc);
+    }
+  }
+
+  if constexpr (!SPLIT && !FP8) {
+    if ((P.epilogue & LX_EPI_QKV) && n0 < 3 * P.qkv_d) {           // tile-uniform: the projection tiles of a (fused) launch
+      gemm_epilogue_qkv<BM, MI>(P, acc, smem, m0, n0, m_base, wave, wm, wn, lane, l31, lhi);
+      return;
     }
   }
 
@@ -1050,7 +1194,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   LX_CHECK_ARG(problems && n >= 1 && n <= LX_GEMM_MAX_GROUP, "lx_gemm_bf16: n=%d out of range [1,%d]", n, LX_GEMM_MAX_GROUP);
   long t256 = 0, t128 = 0;
   int kmax = 0;
-  bool split = false, fp8 = false;
+  bool split = false, fp8 = false, qkv = false;
   for (int i = 0; i < n; ++i) fp8 = fp8 || (problems[i].epilogue & LX_OPERANDS_FP8) != 0;
   for (int i = 0; i < n; ++i) {
     const lx_gemm_desc& p = problems[i];
@@ -1083,6 +1227,16 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     if (p.lora_t) {
       LX_CHECK_ARG(p.lora_up && p.lora_r >= 1 && p.lora_r <= 16, "lx_gemm_bf16[%d]: LoRA needs lora_up and 1 <= r <= 16", i);
       LX_CHECK_ARG(p.lora_mod_cols <= 0 || p.lora_mod_cols % BN == 0, "lx_gemm_bf16[%d]: lora_mod_cols must be a multiple of %d", i, BN);
+    }
+    if (p.epilogue & LX_EPI_QKV) {
+      LX_CHECK_ARG(!fp8 && segs == 1 && !(p.epilogue & LX_EPI_SPLIT_BF16) && epi == LX_EPI_STORE_BF16, "lx_gemm_bf16[%d]: LX_EPI_QKV goes with plain bf16 operands and LX_EPI_STORE_BF16", i);
+      LX_CHECK_ARG(p.qkv_d > 0 && p.qkv_d % BN == 0 && (p.N >= 3 * p.qkv_d || p.N % BN == 0), "lx_gemm_bf16[%d]: LX_EPI_QKV needs qkv_d %% 256 == 0 and whole projection tiles (qkv_d=%d N=%d)", i, p.qkv_d, p.N);
+      LX_CHECK_ARG(p.rows_per_batch % 32 == 0 && p.M % 32 == 0, "lx_gemm_bf16[%d]: LX_EPI_QKV needs rows_per_batch %% 32 == 0 and M %% 32 == 0 (%d, %d)", i, p.rows_per_batch, p.M);
+      LX_CHECK_ARG(p.qkv_norm_q && p.qkv_norm_k && p.qkv_vt && p.qkv_rope && ((uintptr_t)p.qkv_norm_q & 15) == 0 && ((uintptr_t)p.qkv_norm_k & 15) == 0 && ((uintptr_t)p.qkv_vt & 15) == 0 &&
+                   ((uintptr_t)p.qkv_rope & 15) == 0, "lx_gemm_bf16[%d]: LX_EPI_QKV needs 16-byte aligned qkv_norm_q / qkv_norm_k / qkv_rope / qkv_vt", i);
+      LX_CHECK_ARG(p.qkv_vt_ld > 0 && p.qkv_vt_ld % 64 == 0 && p.qkv_vt_pos0 >= 0 && p.qkv_vt_pos0 % 64 == 0 && p.qkv_vt_pos0 + p.rows_per_batch <= p.qkv_vt_ld,
+                   "lx_gemm_bf16[%d]: qkv_vt_ld / qkv_vt_pos0 must be multiples of 64 with the stream inside a V^T row", i);
+      qkv = true;
     }
     if (p.bias) LX_CHECK_ARG(((uintptr_t)p.bias & 15) == 0, "lx_gemm_bf16[%d]: bias must be 16-byte aligned", i);
     t256 += tiles_of(p, 256);
@@ -1130,7 +1284,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const bool fits = per_xcd * 16 <= PAIR_MAX_WG && kmax / BK >= 2;
     const bool pays = pair_mode == 2 || kmax / BK >= env.pair_min_kt;
     if (workspace) LX_CHECK_ARG(ws_bytes >= PAIR_WS_BYTES && ((uintptr_t)workspace & 255) == 0, "lx_gemm_bf16_ws: workspace needs %zu bytes, 256-byte aligned", PAIR_WS_BYTES);
-    if (workspace && pair_mode && forced == 0 && uniform_k && fits && pays && NCU == PAIR_MAX_WG) {
+    if (workspace && pair_mode && forced == 0 && uniform_k && fits && pays && !qkv && NCU == PAIR_MAX_WG) {
       {
         float* slots = (float*)workspace;
         int* flags = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float));

@@ -99,6 +99,10 @@ class DiTEngine:
         rd = sum(cfg.axes_dims_rope)
         self.rope_main = torch.zeros(2, T + N, rd, dtype=f32, device=dev)
         self.rope_cond = torch.zeros(2, max(C, 1), rd, dtype=f32, device=dev)
+        # the same tables as (cos, sin) per rotary pair, for the projection GEMM's fused RMSNorm + RoPE epilogue (LX_EPI_QKV)
+        self.rope_cs_main = torch.zeros(T + N, rd, dtype=f32, device=dev)
+        self.rope_cs_cond = torch.zeros(max(C, 1), rd, dtype=f32, device=dev)
+        self.qkv_fused = False
         self.g_lat = torch.zeros(B, N, cfg.in_channels, dtype=f32, device=dev)
         self.g_t = torch.zeros(B, dtype=f32, device=dev)
         self.graphs = {}
@@ -342,6 +346,7 @@ class DiTEngine:
         if C:
             self.cos_cond, self.sin_cond = ops.rope_table(condition_ids.to(dev, f32).reshape(-1, 3), cfg.axes_dims_rope,
                                                           out=(self.rope_cond[0], self.rope_cond[1]))
+        self._rope_pairs(check=False)
         # temb_base = text_embedder(pooled) [+ guidance_embedder(sinusoid(1000 g))]
         pooled = pooled.to(device=dev, dtype=f32).contiguous()
         self._lin_skinny(pooled, "tte.text_embedder.linear_1", self.thid, act_out=1)
@@ -393,7 +398,8 @@ class DiTEngine:
 
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
                       gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
-                      gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None) -> None:
+                      gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None,
+                      qkv=None) -> None:
         """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
         (None => text rows use `main` too: single blocks). `only` restricts the launch to those streams and `ncols[s]` to the
         first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
@@ -414,6 +420,10 @@ class DiTEngine:
                 if tiled:
                     W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
             kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
+            if qkv is not None:                # (wq, wk, wq_txt, wk_txt): RMSNorm + RoPE + V^T in this launch's epilogue
+                rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
+                kw["qkv"] = dict(norm_q=qkv[2] if s == "txt" else qkv[0], norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
+                                 vt=self.VT, vt_pos0=self.vt0[s], d=self.cfg.inner_dim)
             if gate_off is not None:
                 mods = self.cmods if s == "cond" else self.mods
                 kw["gate"] = mods[:, gate_off[s]:]
@@ -426,7 +436,30 @@ class DiTEngine:
             probs.append(ops.gemm_desc(a, W, c, **kw))
         ops.gemm(probs, self.gemm_ws())
 
-    def _attention(self, wq, wk, wq_txt, wk_txt) -> None:
+    def _rope_pairs(self, check: bool) -> None:
+        """(cos, sin) per rotary pair, [L, 128], for LX_EPI_QKV, and the decision whether the projections of this configuration
+        use it (self.qkv_fused): bf16 kernel set, every stream a multiple of 32 tokens, heads in pairs, tables whose two
+        entries of a pair agree (FluxPosEmbed's repeat_interleave; `check`: tables handed in by a caller are verified)."""
+        D, rd = self.cfg.inner_dim, sum(self.cfg.axes_dims_rope)
+        ok = (os.environ.get("LX_QKV_FUSED", "1") != "0" and D % 256 == 0 and rd == 128 and self.cos_main is not None
+              and all(L % 32 == 0 for _, L in self._streams()) and (self.C == 0 or self.cos_cond is not None)
+              and self.cos_main.shape[0] == self.T + self.N)
+        if ok:
+            pairs = [(self.rope_cs_main, self.cos_main, self.sin_main)]
+            if self.C:
+                pairs.append((self.rope_cs_cond, self.cos_cond, self.sin_cond))
+            for dst, cos, sin in pairs:
+                if check and not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+                    ok = False
+                    break
+                dst[:, 0::2].copy_(cos[:, 0::2])
+                dst[:, 1::2].copy_(sin[:, 0::2])
+        self.qkv_fused = bool(ok)
+
+    def _qkv_epilogue(self) -> bool:
+        return (self.qkv_fused and not self.precise and not self.gemm_fp8 and not self.model_config.get("attn_fp8", False))
+
+    def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False) -> None:
         cfg = self.cfg
         D, H, B = cfg.inner_dim, cfg.num_attention_heads, self.B
         Y = self.Y
@@ -460,7 +493,8 @@ class DiTEngine:
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                              seg_vt0=seg_vt0, bias=bias)
             return
-        ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
+        if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
+            ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                      seg_vt0=seg_vt0, bias=bias)
 
@@ -477,8 +511,11 @@ class DiTEngine:
         p = f"d{i}"
         Yq, Ya, Yf = self.Y[:, : 3 * D], self.Y[:, 2 * D: 3 * D], self.Y[:, 3 * D:]
         self._ln(base, 0, D)                                                               # norm1 / norm1_context
-        self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2)
-        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+        nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
+        fused = self._qkv_epilogue()
+        self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2,
+                           qkv=nw if fused else None)
+        self._attention(*nw, prepped=fused)
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
         if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
@@ -509,9 +546,11 @@ class DiTEngine:
         p = f"s{j}"
         self._ln(base, 0, D)
         kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
+        nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
+        fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only)
-        self._attention(w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
+                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw if fused else None)
+        self._attention(*nw, prepped=fused)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)
@@ -959,6 +998,7 @@ class DiTEngine:
             self.cos_cond, self.sin_cond = (t.to(self.device, f32).contiguous() for t in rope_cond)
         else:
             self.cos_cond = self.sin_cond = None
+        self._rope_pairs(check=True)
         self.cond_ready = True
 
     def attention_module(self, kind: str, idx: int, project_out: bool) -> None:

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_W_TILED,
+from ._lib import (LX_EPI_QKV, LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_W_TILED,
                    AttnDesc, GemmDesc, check, lib)
 
 
@@ -71,7 +71,7 @@ def quantize_weight_fp8(W: torch.Tensor):
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
               gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
               gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0, k_segs=0, a_lo_off=0,
-              c_lo_off=0, fp8=False, col_scale=None, out_scale=0.0) -> GemmDesc:
+              c_lo_off=0, fp8=False, col_scale=None, out_scale=0.0, qkv=None) -> GemmDesc:
     """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome).
     Precise mode: k_segs = 2 | 3 with A's lo image a_lo_off columns after the hi image (pass K explicitly: A then has more than K
     columns) and, for 3, W = [N, 2K] = [W_hi | W_lo] (pass N, K); c_lo_off != 0 adds LX_EPI_SPLIT_BF16 (hi/lo output pair)."""
@@ -102,6 +102,20 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         epilogue |= LX_W_TILED
     d.epilogue, d.gelu_col_start = epilogue, gelu_col_start
     d.col_scale, d.out_scale = _p(col_scale), float(out_scale)
+    if qkv is not None:
+        # LX_EPI_QKV: the first 3 * d columns are [k | v | q]; RMSNorm + RoPE on k / q and the V^T image come out of the epilogue
+        # qkv = dict(norm_q=[128] f32, norm_k=[128] f32, rope=[rows_per_batch, 128] f32 (cos, sin) pairs, vt=V^T image,
+        #            vt_pos0=first slot of this stream in a V^T row, d=inner dim)
+        _req(qkv["norm_q"], torch.float32, "qkv.norm_q"); _req(qkv["norm_k"], torch.float32, "qkv.norm_k")
+        _req(qkv["vt"], torch.bfloat16, "qkv.vt")
+        rope = qkv["rope"]
+        _req(rope, torch.float32, "qkv.rope")
+        assert rope.is_contiguous() and rope.shape == (d.rows_per_batch, 128), (rope.shape, d.rows_per_batch)
+        assert qkv["vt"].is_contiguous()
+        d.qkv_norm_q, d.qkv_norm_k, d.qkv_rope, d.qkv_vt = _p(qkv["norm_q"]), _p(qkv["norm_k"]), _p(rope), _p(qkv["vt"])
+        d.qkv_d, d.qkv_vt_ld, d.qkv_vt_pos0 = int(qkv["d"]), qkv["vt"].shape[-1], int(qkv["vt_pos0"])
+        d.epilogue = epilogue = epilogue | LX_EPI_QKV
+        d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"])     # the descriptor holds raw pointers: keep temporaries alive until launch
     kind = epilogue & 0xff
     want = torch.bfloat16 if kind == LX_EPI_STORE_BF16 else (torch.uint8 if kind == LX_EPI_STORE_FP8 else torch.float32)
     _req(C_, want, "C")

@@ -145,3 +145,38 @@ def test_load_lora_from_safetensors(G, tmp_path):
         pipe.load_lora_weights(str(tmp_path / "bad.safetensors"))
     with pytest.raises(FileNotFoundError):
         pipe.load_lora_weights(str(tmp_path / "nowhere"))
+
+
+@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}, {"union_cond_attn": False}])
+def test_forward_with_fused_qkv_epilogue(monkeypatch, mc):
+    """Streams of 32 / 64 / 64 tokens take the LX_EPI_QKV projection epilogue (RMSNorm + RoPE + V^T inside the GEMM, no qkv_prep
+    launch): against the fp32 oracle, and against the same engine with LX_QKV_FUSED=0 (the two-pass path the goldens cover).
+    The last single block exercises the kv-only (N = 2D) launch of the text / condition streams."""
+    from oracle import flux_modules as fm
+    tr = tiny_transformer(seed=5)
+    g = torch.Generator().manual_seed(7)
+    B, T, hw = 2, 32, 8
+    N = hw * hw
+    kw = dict(hidden_states=torch.randn(B, N, 64, generator=g), encoder_hidden_states=torch.randn(B, T, 64, generator=g) * 0.5,
+              pooled_projections=torch.randn(B, 32, generator=g), timestep=torch.tensor([0.8, 0.3]),
+              img_ids=fm.prepare_latent_image_ids(hw, hw), txt_ids=torch.zeros(T, 3), guidance=torch.full((B,), 3.5))
+    cond = torch.randn(B, N, 64, generator=g)
+    cids = fm.prepare_latent_image_ids(hw, hw)
+    cids[:, 2] -= hw
+    with torch.no_grad():
+        want = fr.tranformer_forward(tr, cond, cids, None, mc, **kw)[0]
+    d = "cuda"
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LX_QKV_FUSED", fused)
+        eng = _engine(tr)
+        eng.set_conditioning(kw["encoder_hidden_states"].to(d), kw["pooled_projections"].to(d), kw["guidance"].to(d), kw["txt_ids"].to(d),
+                             kw["img_ids"].to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=mc)
+        assert eng.qkv_fused == (fused == "1")
+        a = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()
+        b = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()      # graph replay
+        assert torch.equal(a, b)
+        outs[fused] = a
+    e1, e0 = relerr(outs["1"], want), relerr(outs["0"], want)
+    assert e1 < TOL and e0 < TOL, (e1, e0)
+    assert relerr(outs["1"], outs["0"]) < 1e-2

@@ -383,6 +383,113 @@ def test_qkv_prep_rmsnorm_rope(ops):
     assert torch.equal(vt, expect)
 
 
+@pytest.mark.parametrize("bm", [256, 128, None])
+@pytest.mark.parametrize("extra", [0, 512, -256])
+def test_gemm_qkv_epilogue_matches_projection_plus_qkv_prep(ops, monkeypatch, bm, extra):
+    """LX_EPI_QKV (RMSNorm + RoPE on k / q, V^T image, inside the projection's epilogue) against (a) an fp64 restatement of
+    block.py:43-99 and (b) the two-pass path it replaces (plain projection + lx_qkv_prep). extra = 512: GELU columns after the
+    projections (the single block's fused launch); -256: a block whose q columns stop early (N = 3D - 256); two token streams
+    with different norm weights / tables / V^T offsets in one launch, rows per batch a multiple of 32 but not of 64 or 256."""
+    from oracle.flux_modules import apply_rotary_emb, rope_tables
+    from loongx_amd import _lib
+    if bm is not None:
+        monkeypatch.setenv("LX_GEMM_BM", str(bm))
+        _lib.lib.lx_gemm_reload_env()
+    B, H, K = 2, 2, 192
+    D = H * 128
+    N = 3 * D + extra
+    lens = [96, 160]
+    row0, vt0, vt_ld = _segments(B, lens)
+    M = B * sum(lens)
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    Ws = [rnd(N, K, seed=2 + i, scale=K ** -0.5, dtype=torch.bfloat16) for i in range(2)]
+    bias = [rnd(N, seed=4 + i, scale=0.3) for i in range(2)]
+    wq = [1 + 0.1 * rnd(128, seed=6 + i) for i in range(2)]
+    wk = [1 + 0.1 * rnd(128, seed=8 + i) for i in range(2)]
+    tabs = []
+    for i, Ls in enumerate(lens):
+        ids = torch.zeros(Ls, 3)
+        ids[:, 1] = torch.arange(Ls) // 8 + i
+        ids[:, 2] = torch.arange(Ls) % 8 - 3 * i
+        tabs.append(rope_tables(ids))
+    cs_dev = []
+    for i, Ls in enumerate(lens):
+        cos, sin = tabs[i]
+        cs = torch.empty(Ls, 128)
+        cs[:, 0::2], cs[:, 1::2] = cos[:, 0::2], sin[:, 0::2]
+        cs_dev.append(cs.to(DEV))
+
+    def run(fused):
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        VT = torch.zeros(B, H, 128, vt_ld, dtype=torch.bfloat16, device=DEV)
+        probs = []
+        for i, Ls in enumerate(lens):
+            rows = slice(row0[i], row0[i] + B * Ls)
+            kw = {}
+            if fused:
+                kw["qkv"] = dict(norm_q=wq[i], norm_k=wk[i], rope=cs_dev[i], vt=VT, vt_pos0=vt0[i], d=D)
+            ep = ops.LX_EPI_STORE_BF16 | (ops.LX_EPI_GELU if extra > 0 else 0)
+            probs.append(ops.gemm_desc(A[rows], Ws[i], C[rows], bias=bias[i], epilogue=ep, rows_per_batch=Ls, gelu_col_start=3 * D, **kw))
+        ops.gemm(probs)
+        if not fused:
+            segs = [(row0[i], Ls, vt0[i], wq[i], wk[i], tabs[i][0].to(DEV), tabs[i][1].to(DEV)) for i, Ls in enumerate(lens)]
+            if extra >= 0:
+                ops.qkv_prep_segs(C, 2 * D, 0, D, segs, B, H, VT)
+        torch.cuda.synchronize()
+        return C.float().cpu(), VT.float().cpu()
+    Cf, VTf = run(True)
+    Cu, VTu = run(False)
+    for i, Ls in enumerate(lens):
+        rows = slice(row0[i], row0[i] + B * Ls)
+        y = A[rows].double().cpu() @ Ws[i].double().cpu().T + bias[i].double().cpu()
+        cos, sin = (t.double() for t in tabs[i])
+        def ref(x, w):
+            x = x.view(B, Ls, -1, 128).permute(0, 2, 1, 3)
+            x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double().cpu()
+            return apply_rotary_emb(x, (cos, sin)).permute(0, 2, 1, 3).reshape(B * Ls, -1)
+        want_k, want_v = ref(y[:, :D], wk[i]), y[:, D:2 * D]
+        ek, eku = relerr(Cf[rows, :D], want_k), relerr(Cu[rows, :D], want_k)
+        assert ek < 3e-3, ek
+        if extra >= 0:
+            want_q = ref(y[:, 2 * D:3 * D], wq[i])
+            eq, equ = relerr(Cf[rows, 2 * D:3 * D], want_q), relerr(Cu[rows, 2 * D:3 * D], want_q)
+            assert eq < 3e-3 and eq <= equ * 1.02 and ek <= eku * 1.02, (eq, equ, ek, eku)     # one rounding instead of two
+        else:
+            qn = 3 * D + extra - 2 * D                          # the q columns that exist: whole heads
+            if qn:
+                want_q = ref(y[:, 2 * D:2 * D + qn], wq[i])
+                assert relerr(Cf[rows, 2 * D:2 * D + qn], want_q) < 3e-3
+        if extra > 0:                                           # the GELU columns behind the projections are untouched by the flag
+            assert torch.equal(Cf[rows, 3 * D:], Cu[rows, 3 * D:])
+            g = torch.nn.functional.gelu(y[:, 3 * D:], approximate="tanh")
+            assert relerr(Cf[rows, 3 * D:], g) < 4e-3
+        # V^T image: bf16(acc + bias) at slot interleave(key); identical to the two-pass image
+        perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+        v = want_v.view(B, Ls, H, 128).to(torch.bfloat16).float()
+        slots = (torch.arange(Ls) // 16) * 16 + perm[torch.arange(Ls) % 16]
+        got = VTf[:, :, :, vt0[i]: vt0[i] + Ls]
+        assert relerr(got, v[:, slots].permute(0, 2, 3, 1)) < 3e-3
+        assert float(VTf[:, :, :, vt0[i] + Ls: vt0[i] + (Ls + 63) // 64 * 64].abs().max() if Ls % 64 else 0.0) == 0.0
+    if extra >= 0:
+        assert torch.equal(VTf, VTu)
+
+
+def test_gemm_qkv_epilogue_argument_checks(ops):
+    from loongx_amd._lib import LxError
+    D, K, Ls = 256, 64, 48
+    A, W = rnd(Ls, K, dtype=torch.bfloat16), rnd(3 * D, K, dtype=torch.bfloat16)
+    C = torch.zeros(Ls, 3 * D, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(1, 2, 128, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.ones(128, device=DEV)
+    rope = torch.zeros(Ls, 128, device=DEV)
+    with pytest.raises(LxError):        # rows_per_batch % 32 != 0
+        ops.gemm([ops.gemm_desc(A, W, C, qkv=dict(norm_q=w, norm_k=w, rope=rope, vt=VT, vt_pos0=0, d=D))])
+    A2, C2 = rnd(64, K, dtype=torch.bfloat16), torch.zeros(64, 3 * D, dtype=torch.float32, device=DEV)
+    with pytest.raises(LxError):        # fp32 store
+        ops.gemm([ops.gemm_desc(A2, W, C2, epilogue=ops.LX_EPI_STORE_F32,
+                                qkv=dict(norm_q=w, norm_k=w, rope=torch.zeros(64, 128, device=DEV), vt=VT, vt_pos0=0, d=D))])
+
+
 def _attn_reference(buf, B, H, lens, bias, q_col, k_col, v_col):
     """fp32 SDPA over the concatenated segments with the block bias."""
     S = sum(lens)
