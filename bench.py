@@ -98,6 +98,64 @@ def _gemm_traffic_mb():
         return None, None
 
 
+class PowerSampler:
+    """Package power and shader clock of one GPU over the timed region, from the amdgpu hwmon files (power1_input in uW,
+    freq1_input = sclk in Hz), every 50 ms on a host thread. The denoise loop runs at the 1400 W package cap with the clock
+    pulled below 2.4 GHz, so the spec-sheet peak is not what the matrix cores can reach under this load: the line
+    reports both. Absent files (container without sysfs) => None."""
+
+    def __init__(self, dev_index: int):
+        import glob
+        import threading
+        self.dir = None
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            for c in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(c).endswith(bdf):
+                    hw = glob.glob(c + "/hwmon/hwmon*")
+                    if hw and os.path.exists(hw[0] + "/power1_input"):
+                        self.dir = hw[0]
+        except Exception:
+            self.dir = None
+        self.samples, self._stop, self._th = [], threading.Event(), None
+
+    def _read(self, name):
+        with open(f"{self.dir}/{name}") as f:
+            return float(f.read().strip())
+
+    def start(self):
+        import threading
+        if self.dir is None:
+            return
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+                except Exception:
+                    pass
+                self._stop.wait(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        if len(self.samples) < 4:
+            return None
+        s = self.samples[1:-1]                      # the first / last sample straddle the region's edges
+        cap = None
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            pass
+        return {"avg_W": round(sum(x[0] for x in s) / len(s), 1), "cap_W": cap, "sclk_MHz_avg": round(sum(x[1] for x in s) / len(s), 1),
+                "sclk_MHz_min": round(min(x[1] for x in s), 1), "samples": len(s),
+                "source": "amdgpu hwmon power1_input / freq1_input of this GPU, every 50 ms over the timed region"}
+
+
 def _self_launch(n: int) -> int:
     """Re-execute this script under torch.distributed.run with n ranks on this node (one process per GPU, RCCL)."""
     import socket
@@ -192,6 +250,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    power = PowerSampler(local) if rank == 0 else None
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     for i in range(a.steps):
         # HIP-event brackets around every GEMM / attention launch of ROOFLINE_STEPS denoise steps of the LAST timed image
@@ -204,6 +265,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed_ms = (time.perf_counter() - t0) * 1e3
+    pw_rec = power.stop() if power is not None else None
     ops.TIMER = None
     elapsed_ms = lxd.barrier_max_ms(elapsed_ms, dev)
     finite = bool(torch.isfinite(out).all())
@@ -226,6 +288,12 @@ def main():
                "outputs_finite": finite,
                "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
                "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS), 4)}
+        if pw_rec is not None:
+            # the matrix-core peak at the clock the part actually sustained under this load (spec peak is quoted at 2.4 GHz)
+            peak_here = (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS) * pw_rec["sclk_MHz_avg"] / 2400.0
+            pw_rec["mfma_peak_at_measured_clock_TFLOPs"] = round(peak_here, 1)
+            pw_rec["mfma_frac_end_to_end_at_measured_clock"] = round(value * fpi / world / 1e12 / peak_here, 4)
+            res["power"] = pw_rec
         if timer is not None:
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")
@@ -246,6 +314,8 @@ def main():
                                "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
                                "share_of_step_time": round(gm["ms"] * to_image / (elapsed_ms / a.steps), 3),
                                "timed": f"HIP events around every launch of denoise steps {list(ROOFLINE_STEPS)} of the last timed image"}
+            if pw_rec is not None:
+                res["roofline"]["frac_at_measured_clock"] = round(ach / pw_rec["mfma_peak_at_measured_clock_TFLOPs"], 4)
             if at:
                 aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
                 apeak = PEAK_FP8_TFLOPS if a.fp8 else (157.3 if a.precise else PEAK_BF16_TFLOPS)

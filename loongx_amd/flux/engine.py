@@ -61,6 +61,10 @@ class DiTEngine:
         self.gemm_fp8 = False
         self.w8: Dict[str, torch.Tensor] = {}          # name -> tiled e4m3 weight / name + ".rs" -> row de-scale, built on first use
         self._gemm_ws: Optional[torch.Tensor] = None
+        # two-stream single blocks (opt-in, LX_OVERLAP=1): measured +0.3 % -- the step runs at the 1400 W package power cap, so filling
+        # the partly idle last rounds of a kernel with another kernel's workgroups buys clock back elsewhere, not time
+        self.overlap = os.environ.get("LX_OVERLAP", "0") == "1"
+        self.side_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
 
     # ------------------------------------------------------------------------------------------ workspace
     def setup(self, B: int, T: int, N: int, C: int) -> None:
@@ -399,20 +403,29 @@ class DiTEngine:
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
                       gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
                       gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None,
-                      qkv=None) -> None:
+                      qkv=None, cols: Optional[tuple] = None, lora=None, lora_t_col0: int = 0, ws: bool = True) -> None:
         """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
         (None => text rows use `main` too: single blocks). `only` restricts the launch to those streams and `ncols[s]` to the
         first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
         w = self.w
         lora_needed = only is None or "cond" in only or self.latent_lora
-        lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
+        if lora is not None:               # (Lora, first row) already projected down by the caller (one lx_lora_down for several launches)
+            lo, lr0 = lora if lora_needed else (None, None)
+        else:
+            lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
         probs = []
+        c0, c1 = cols if cols is not None else (0, None)     # output-column range of this launch (multiples of 256)
         for s, L in self._streams():
             if only is not None and s not in only:
                 continue
             name = txt if (s == "txt" and txt is not None) else main
             a, c = self.rows(A, s), self.rows(Cbuf, s)
             W, bias = w.t[name + ".w"], w.t[name + ".b"]
+            if cols is not None:
+                tiled = getattr(W, "lx_tiled", False)
+                W, bias, c = W[c0:c1], bias[c0:c1], c[:, c0:c1]
+                if tiled:
+                    W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
             n_out = ncols.get(s) if ncols else None
             if n_out is not None and n_out < W.shape[0]:
                 tiled = getattr(W, "lx_tiled", False)
@@ -431,10 +444,10 @@ class DiTEngine:
                                                     (s == "txt" and self.latent_lora and txt is None)):
                 row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
                 if row0 >= lr0:
-                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up[:W.shape[0]], lora_mod_cols=lora_mod_cols,
+                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0], lora_t_col0:], lora_up=lo.up[c0:c0 + W.shape[0]], lora_mod_cols=lora_mod_cols,
                               lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, W, c, **kw))
-        ops.gemm(probs, self.gemm_ws())
+        ops.gemm(probs, self.gemm_ws() if ws else None)
 
     def _rope_pairs(self, check: bool) -> None:
         """(cos, sin) per rotary pair, [L, 128], for LX_EPI_QKV, and the decision whether the projections of this configuration
@@ -548,9 +561,28 @@ class DiTEngine:
         kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
         fused = self._qkv_epilogue()
-        self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw if fused else None)
-        self._attention(*nw, prepped=fused)
+        if self.overlap:
+            # The MLP-up half of the fused projection does not feed the attention: it runs on a second stream beside
+            # {q/k/v projection -> attention}, so that the partly filled last rounds of the three kernels (0.41 + 0.88 + 0.94 of a
+            # round of 256 CUs) share the chip instead of each waiting for its own stragglers. One lx_lora_down serves both launches.
+            lora = self._lora_t(self.XN, p + ".fused", include_txt=True)
+            main_s, side = torch.cuda.current_stream(self.device), self.side_stream
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(main_s)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=0,
+                                   cols=(3 * D, 7 * D), lora=lora, lora_t_col0=3 * self.cfg.lora_r, ws=False,
+                                   only=("img",) if image_out_only else None)
+                join.record(side)
+            self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=3,
+                               cols=(0, 3 * D), ncols=kv_only, qkv=nw if fused else None, lora=lora)
+            self._attention(*nw, prepped=fused)
+            main_s.wait_event(join)
+        else:
+            self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
+                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw if fused else None)
+            self._attention(*nw, prepped=fused)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)

@@ -180,3 +180,20 @@ def test_forward_with_fused_qkv_epilogue(monkeypatch, mc):
     e1, e0 = relerr(outs["1"], want), relerr(outs["0"], want)
     assert e1 < TOL and e0 < TOL, (e1, e0)
     assert relerr(outs["1"], outs["0"]) < 1e-2
+
+
+def test_two_stream_single_blocks_match_the_serial_schedule(monkeypatch, G):
+    """LX_OVERLAP=1: the MLP-up half of a single block's fused projection runs on a second stream beside {q/k/v projection ->
+    attention} (fork / join inside the captured step graph). Same arithmetic per output element: the results must agree with the
+    one-stream schedule to the last bit, eagerly and replayed."""
+    outs = {}
+    for ov in ("0", "1"):
+        monkeypatch.setenv("LX_OVERLAP", ov)
+        eng = _engine(tiny_transformer())
+        assert eng.overlap == (ov == "1")
+        a = _run(eng, G)
+        b = eng.forward(G["in_latents"].to("cuda"), G["in_timestep"].to("cuda")).float().cpu().clone()      # graph replay
+        assert torch.equal(a, b)
+        outs[ov] = a
+    assert torch.equal(outs["0"], outs["1"])
+    assert relerr(outs["1"], G["fwd_cond"]) < TOL
