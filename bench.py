@@ -46,6 +46,15 @@ def flops_per_image(n_img_tokens: int, n_cond_tokens: int, layers: int = 57) -> 
     return total - skipped
 
 
+def flops_per_image_cond_cached(n_img_tokens: int, n_cond_tokens: int, layers: int = 57) -> float:
+    """--independent-condition: the condition stream is computed in the first denoise step only (its keys / values are cached per
+    layer); the other 27 steps run the text + image rows: 24*Sq*D^2 of GEMMs and 4*Sq*S*D of attention (Sq queries, S keys)."""
+    Sq, S = T_TXT + n_img_tokens, T_TXT + n_img_tokens + n_cond_tokens
+    first = flops_per_image(n_img_tokens, n_cond_tokens, layers) / STEPS
+    rest = layers * (24.0 * Sq * D * D + 4.0 * Sq * S * D) - (2.0 * T_TXT * (2 * 5 * D * D) if layers == 57 else 0.0)
+    return first + (STEPS - 1) * rest
+
+
 def cpu_baseline(threads: int):
     """The oracle (torch-CPU fp32 restatement, oracle/flux_ref.py) timed on this box's host cores on a BOUNDED sample:
     one double + one single block at full width (B=1, S=2560), extrapolated to 19/38 blocks x 28 steps."""
@@ -72,13 +81,14 @@ def cpu_baseline(threads: int):
                       f"extrapolated x(19,38) blocks x28 steps"}
 
 
-def parity_check(precise: bool = False, fp8: bool = False):
+def parity_check(precise: bool = False, fp8: bool = False, extra_mc=None):
     """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
     timed region) at full depth and width on this GPU, in the mode the timed region ran."""
     from oracle.parity import full_depth_parity
     mc = {"union_cond_attn": True}
     if fp8:
         mc.update(attn_fp8=True, gemm_fp8=True)
+    mc.update(extra_mc or {})
     return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc)
 
 
@@ -182,6 +192,9 @@ def main():
     ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32 attention)")
     ap.add_argument("--hw", type=int, default=32, help="packed latent grid side: 32 = 512x512 (the metric's config), 64 = 1024x1024 (configs[4])")
     ap.add_argument("--fp8", action="store_true", help="model_config attn_fp8 / gemm_fp8: the e4m3 MFMA paths of BASELINE configs[4]")
+    ap.add_argument("--independent-condition", action="store_true",
+                    help="model_config independent_condition (block.py:115-120): the condition queries see only condition keys, so the "
+                         "condition stream is step-invariant and the engine computes it once per image (not the metric's configuration)")
     ap.add_argument("--modalities", type=str, default="eeg", help="eeg (configs[1]) | all (EEG+fNIRS+PPG+motion, CS3+DGF fuse: configs[2]/[3])")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -220,6 +233,8 @@ def main():
         mc["precise"] = True
     if a.fp8:
         mc.update(attn_fp8=True, gemm_fp8=True)
+    if a.independent_condition:
+        mc["independent_condition"] = True
     model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
 
     B, hw = a.batch, a.hw
@@ -273,7 +288,8 @@ def main():
     if rank == 0:
         images = world * B * a.steps
         value = images / (elapsed_ms / 1e3)
-        fpi = flops_per_image(N, N)
+        cached = a.independent_condition and model.flux_pipe.transformer.engine.cond_cache
+        fpi = flops_per_image_cond_cached(N, N) if cached else flops_per_image(N, N)
         res = {"metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed_ms / a.steps, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -281,7 +297,8 @@ def main():
                "config": {"workload": (f"BASELINE configs[{1 if not allmod else (2 if B == 1 else 3)}]: " if hw == 32 and not a.fp8 else "BASELINE configs[4] shape: ") +
                                       ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
                                       f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, "
-                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 paths" if a.fp8 else ""),
+                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 paths" if a.fp8 else "") +
+                                      (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if a.independent_condition else ""),
                           "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
                           "rccl_ranks": world, "weight_broadcast_GB": round(moved / 1e9, 2), "weight_broadcast_s": round(t_bcast, 2),
                           "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)},
@@ -331,7 +348,7 @@ def main():
             del model, pw, batches, out
             torch.cuda.empty_cache()
             try:
-                res["parity"] = parity_check(a.precise, a.fp8)
+                res["parity"] = parity_check(a.precise, a.fp8, {"independent_condition": True} if a.independent_condition else None)
             except Exception as e:          # the checker must never take the measurement down with it
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))

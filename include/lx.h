@@ -104,8 +104,11 @@ typedef struct lx_gemm_desc {
   const float* qkv_rope;     /* [rows_per_batch, 128] fp32: (cos, sin) of rotary pair i at [2i, 2i+1] (identity: 1, 0) */
   void* qkv_vt;              /* bf16 [B * qkv_d/128, 128, qkv_vt_ld]: V^T image, key p of the stream at slot qkv_vt_pos0 + il(p), il =
                               * the 16-key interleave of lx_qkv_prep */
+  void* qkv_k;               /* NULL: the k columns are stored in place in C. Otherwise bf16 [M, qkv_k_ld]: row m's k head h at column h*128 of
+                              * a SEPARATE image (one per layer: a token stream whose queries see only its own keys -- model_config
+                              * independent_condition / union_cond_attn = False -- then keeps its keys and values across denoise steps) */
   int32_t qkv_d, qkv_vt_ld, qkv_vt_pos0;   /* qkv_vt_ld, qkv_vt_pos0 % 64 == 0 */
-  int32_t _pad0;
+  int32_t qkv_k_ld;          /* % 8 == 0, >= qkv_d */
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4
@@ -211,6 +214,8 @@ typedef struct lx_attn_desc {
   int32_t seg_row0[3], seg_len[3], seg_vt0[3];
   float bias[3][3];
   float scale;
+  int32_t n_qseg;        /* 0 / n_seg: every segment has queries. k < n_seg: only segments 0..k-1 do (keys and values of all n_seg segments
+                          * are still attended to): the rows of the other segments of O are not written */
 } lx_attn_desc;
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 

@@ -33,7 +33,8 @@ class GemmDesc(C.Structure):
                 ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32), ("out_scale", C.c_float),
                 ("col_scale", C.c_void_p),
                 ("qkv_norm_q", C.c_void_p), ("qkv_norm_k", C.c_void_p), ("qkv_rope", C.c_void_p), ("qkv_vt", C.c_void_p),
-                ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("_pad0", C.c_int32)]
+                ("qkv_k", C.c_void_p),
+                ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("qkv_k_ld", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -42,7 +43,7 @@ class AttnDesc(C.Structure):
                 ("q_col", C.c_int32), ("k_col", C.c_int32), ("o_col", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
                 ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
-                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float)]
+                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32)]
 
 
 class AttnF32Desc(C.Structure):

@@ -760,6 +760,8 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   static const int nw = [] { const char* e = getenv("LX_ATTN_NW"); const int v = e ? atoi(e) : 8; return (v == 4 && !piped) ? 4 : 8; }();
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   const int qblk = nw * 32;
+  LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd: n_qseg=%d must be 0..n_seg", d->n_qseg);
+  const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
   AttnArgs a;
   a.d = *d;
   int t = 0;
@@ -770,6 +772,7 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
       LX_CHECK_ARG(d->seg_vt0[s] % 64 == 0, "lx_attn_fwd: seg_vt0 must be 64-aligned");
       bool any = false;
       for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
+      if (s >= nq) continue;                 // a segment without queries (n_qseg): keys / values only
       LX_CHECK_ARG(any, "lx_attn_fwd: query segment %d is masked from every key segment", s);
       t += (d->seg_len[s] + qblk - 1) / qblk;
     }
@@ -799,6 +802,8 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
+  LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
+  const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
   AttnArgs a;
   a.d = *d;
   int t = 0;
@@ -809,6 +814,7 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
       LX_CHECK_ARG(d->seg_vt0[s] % 64 == 0, "lx_attn_fwd_fp8: seg_vt0 must be 64-aligned");
       bool any = false;
       for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
+      if (s >= nq) continue;
       LX_CHECK_ARG(any, "lx_attn_fwd_fp8: query segment %d is masked from every key segment", s);
       t += (d->seg_len[s] + 255) / 256;
     }

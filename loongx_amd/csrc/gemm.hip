@@ -253,7 +253,9 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 
   f32x4 w0 = *(const f32x4*)(nw + hd), w1 = *(const f32x4*)(nw + hd + 4);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1)::"memory");
   __syncthreads();                                   // both halves of every head's sums are in LDS
-  const int ncol = nw0 + c8;
+  const int ncol = nw0 + c8;                         // (k columns start at 0: the same column in a separate key image)
+  uint16_t* const out = (kind == 0 && P.qkv_k) ? (uint16_t*)P.qkv_k : (uint16_t*)P.C;
+  const int out_ld = (kind == 0 && P.qkv_k) ? P.qkv_k_ld : P.ldc;
   const float* own = ssq + wave * (BM / 2);
   const float* oth = ssq + (wave ^ 1) * (BM / 2);
   // RoPE rows of a 32-row block: 8 x 16 B per lane. vmcnt is one in-order queue of loads AND stores (see gemm_epilogue): the rows
@@ -298,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 
         y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
       }
       u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-      *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
+      *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1144,6 +1146,7 @@ static lx_gemm_desc sub_rows(const lx_gemm_desc& p, int r0, int rows) {   // row
   const int epi = p.epilogue & 0xff;
   q.C = epi == LX_EPI_STORE_BF16 ? (void*)((uint16_t*)p.C + (size_t)r0 * p.ldc) : (void*)((float*)p.C + (size_t)r0 * p.ldc);
   if (p.lora_t) q.lora_t = p.lora_t + (size_t)r0 * p.lora_ldt;
+  if (p.qkv_k) q.qkv_k = (uint16_t*)p.qkv_k + (size_t)r0 * p.qkv_k_ld;
   q.M = rows;
   return q;
 }
@@ -1236,6 +1239,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
                    ((uintptr_t)p.qkv_rope & 15) == 0, "lx_gemm_bf16[%d]: LX_EPI_QKV needs 16-byte aligned qkv_norm_q / qkv_norm_k / qkv_rope / qkv_vt", i);
       LX_CHECK_ARG(p.qkv_vt_ld > 0 && p.qkv_vt_ld % 64 == 0 && p.qkv_vt_pos0 >= 0 && p.qkv_vt_pos0 % 64 == 0 && p.qkv_vt_pos0 + p.rows_per_batch <= p.qkv_vt_ld,
                    "lx_gemm_bf16[%d]: qkv_vt_ld / qkv_vt_pos0 must be multiples of 64 with the stream inside a V^T row", i);
+      if (p.qkv_k) LX_CHECK_ARG(((uintptr_t)p.qkv_k & 15) == 0 && p.qkv_k_ld % 8 == 0 && p.qkv_k_ld >= p.qkv_d, "lx_gemm_bf16[%d]: qkv_k must be 16-byte aligned with qkv_k_ld %% 8 == 0, >= qkv_d", i);
       qkv = true;
     }
     if (p.bias) LX_CHECK_ARG(((uintptr_t)p.bias & 15) == 0, "lx_gemm_bf16[%d]: bias must be 16-byte aligned", i);

@@ -61,6 +61,15 @@ class DiTEngine:
         self.gemm_fp8 = False
         self.w8: Dict[str, torch.Tensor] = {}          # name -> tiled e4m3 weight / name + ".rs" -> row de-scale, built on first use
         self._gemm_ws: Optional[torch.Tensor] = None
+        # Step-invariant condition stream (model_config independent_condition / union_cond_attn = False: the condition queries see
+        # only condition keys, its timestep c_t is fixed, so its hidden states, keys and values are the same at every denoise step):
+        # the first forward after set_conditioning() computes all three streams and leaves the condition keys / V^T of every layer in
+        # per-layer images; the following forwards run the text and image rows only. LX_COND_CACHE=0 recomputes every step.
+        self.cond_cache_enabled = os.environ.get("LX_COND_CACHE", "1") != "0"
+        self.cond_cache = False          # decided per conditioning (set_conditioning)
+        self.cond_cached = False         # the per-layer images hold this conditioning's condition keys / values
+        self.cond_skip = False           # the forward being enqueued runs without the condition rows
+        self.KC = self.VTC = None        # [layers, M, D] keys / [layers, B, H, 128, vt_ld] V^T, allocated on first use
         # two-stream single blocks (opt-in, LX_OVERLAP=1): measured +0.3 % -- the step runs at the 1400 W package power cap, so filling
         # the partly idle last rounds of a kernel with another kernel's workgroups buys clock back elsewhere, not time
         self.overlap = os.environ.get("LX_OVERLAP", "0") == "1"
@@ -112,6 +121,8 @@ class DiTEngine:
         self.graphs = {}
         self.shape = (B, T, N, C)
         self.cond_ready = False
+        self.KC = self.VTC = None                                  # per-layer key / V^T images of the condition cache: shape-bound
+        self.cond_cache = self.cond_cached = False
         self.XN2 = self.Y32 = self.YA = self.lat2 = None          # precise-mode buffers, allocated by _setup_precise()
         self.XN8 = self.Y8 = None                                  # fp8-GEMM operand images, allocated by _setup_fp8()
 
@@ -186,6 +197,10 @@ class DiTEngine:
         return buf[self.r_cond:self.M]
 
     def _streams(self):
+        """Token streams with rows in this forward (cond_skip: the condition stream's keys / values come from the per-layer cache)."""
+        return [(n, l) for n, l in (("txt", self.T), ("img", self.N), ("cond", 0 if self.cond_skip else self.C)) if l > 0]
+
+    def _all_streams(self):
         return [(n, l) for n, l in (("txt", self.T), ("img", self.N), ("cond", self.C)) if l > 0]
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -369,6 +384,7 @@ class DiTEngine:
             self._compute_mods(self.cond_temb, self.cmods, lora=True)
         self.attn_bias = self._attn_bias()
         self.cond_ready = True
+        self.cond_cached = False          # a new condition stream: the per-layer key / value images are stale
         self.sched = None
 
     # ------------------------------------------------------------------------------------------ building blocks
@@ -383,15 +399,19 @@ class DiTEngine:
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
-        model_config["latent_lora"] also the image stream and, where text shares the module (single blocks), text."""
+        model_config["latent_lora"] also the image stream and, where text shares the module (single blocks), text.
+        None: no such rows in this forward (cond_skip without latent_lora)."""
+        end = self.r_cond if self.cond_skip else self.M
         if self.latent_lora:
             r0 = self.r_txt if include_txt else self.r_img
-            return r0, self.M - r0
+            return r0, end - r0
+        if self.cond_skip:
+            return None
         return self.r_cond, self.M - self.r_cond
 
     def _lora_t(self, A: torch.Tensor, name: str, include_txt: bool = False):
         lo = self.w.lora.get(name)
-        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0:
+        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0 or self._lora_rows(include_txt) is None:
             return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
@@ -433,10 +453,12 @@ class DiTEngine:
                 if tiled:
                     W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
             kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
-            if qkv is not None:                # (wq, wk, wq_txt, wk_txt): RMSNorm + RoPE + V^T in this launch's epilogue
+            if qkv is not None:                # (wq, wk, wq_txt, wk_txt[, layer]): RMSNorm + RoPE + V^T in this launch's epilogue
                 rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
                 kw["qkv"] = dict(norm_q=qkv[2] if s == "txt" else qkv[0], norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
                                  vt=self.VT, vt_pos0=self.vt0[s], d=self.cfg.inner_dim)
+                if self.cond_cache and len(qkv) > 4:      # per-layer key / V^T images: the condition rows' entries outlive the step
+                    kw["qkv"].update(k=self.rows(self.KC[qkv[4]], s), vt=self.VTC[qkv[4]])
             if gate_off is not None:
                 mods = self.cmods if s == "cond" else self.mods
                 kw["gate"] = mods[:, gate_off[s]:]
@@ -455,7 +477,7 @@ class DiTEngine:
         entries of a pair agree (FluxPosEmbed's repeat_interleave; `check`: tables handed in by a caller are verified)."""
         D, rd = self.cfg.inner_dim, sum(self.cfg.axes_dims_rope)
         ok = (os.environ.get("LX_QKV_FUSED", "1") != "0" and D % 256 == 0 and rd == 128 and self.cos_main is not None
-              and all(L % 32 == 0 for _, L in self._streams()) and (self.C == 0 or self.cos_cond is not None)
+              and all(L % 32 == 0 for _, L in self._all_streams()) and (self.C == 0 or self.cos_cond is not None)
               and self.cos_main.shape[0] == self.T + self.N)
         if ok:
             pairs = [(self.rope_cs_main, self.cos_main, self.sin_main)]
@@ -472,13 +494,14 @@ class DiTEngine:
     def _qkv_epilogue(self) -> bool:
         return (self.qkv_fused and not self.precise and not self.gemm_fp8 and not self.model_config.get("attn_fp8", False))
 
-    def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False) -> None:
+    def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False, layer: Optional[int] = None) -> None:
         cfg = self.cfg
         D, H, B = cfg.inner_dim, cfg.num_attention_heads, self.B
         Y = self.Y
         seg_row0, seg_len, seg_vt0, qsegs = [], [], [], []
         off = 0
-        streams = self._streams()
+        cached = self.cond_cache and layer is not None and prepped
+        streams = self._all_streams() if cached else self._streams()      # key / value segments (queries: the streams of this forward)
         bias = [[0.0] * 3 for _ in range(3)]
         for qi, (qs, _) in enumerate(streams):
             for ki, (ks, _) in enumerate(streams):
@@ -506,6 +529,12 @@ class DiTEngine:
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                              seg_vt0=seg_vt0, bias=bias)
             return
+        if cached:
+            # keys from the layer's key image, V^T from the layer's V^T image (the condition stream's part written by the first
+            # forward of this conditioning); in a cond_skip forward only the text / image segments have queries
+            ops.attn_fwd(Y, self.KC[layer], self.VTC[layer], Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0,
+                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0)
+            return
         if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
             ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
@@ -527,8 +556,8 @@ class DiTEngine:
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
         fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2,
-                           qkv=nw if fused else None)
-        self._attention(*nw, prepped=fused)
+                           qkv=nw + (i,) if fused else None)
+        self._attention(*nw, prepped=fused, layer=i)
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
         if self.C and self.model_config.get("add_cond_attn", False):                          # block.py:233-234
@@ -576,13 +605,13 @@ class DiTEngine:
                                    only=("img",) if image_out_only else None)
                 join.record(side)
             self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=3,
-                               cols=(0, 3 * D), ncols=kv_only, qkv=nw if fused else None, lora=lora)
-            self._attention(*nw, prepped=fused)
+                               cols=(0, 3 * D), ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None, lora=lora)
+            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j)
             main_s.wait_event(join)
         else:
             self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw if fused else None)
-            self._attention(*nw, prepped=fused)
+                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None)
+            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)
@@ -900,7 +929,7 @@ class DiTEngine:
         ops.gemm([ops.gemm_desc(self.lat16, w.t["x_embedder.w"], self.rows(self.X, "img"), bias=w.t["x_embedder.b"],
                                 epilogue=LX_EPI_STORE_F32, lora_t=tl, lora_up=lo.up if lo is not None else None)])
         self.rows(self.X, "txt").copy_(self.X_txt_init)
-        if self.C:
+        if self.C and not self.cond_skip:
             self.rows(self.X, "cond").copy_(self.X_cond_init)
         if mods_ready:                      # self.mods already holds this step's row of the prepare_schedule() table
             return
@@ -948,32 +977,59 @@ class DiTEngine:
         if pre and not 0 <= step_index < len(self.sched[0]):
             raise IndexError(f"step_index {step_index} outside the prepared schedule of {len(self.sched[0])} steps")
         timed = ops.TIMER is not None and ops.TIMER.next_call()      # event brackets need the eager launch path
+        self.cond_cache = self._cond_cache_ok()
+        skip = self.cond_cache and self.cond_cached            # the condition stream's keys / values of this conditioning are cached
+        if self.cond_cache and self.KC is None:                # per-layer key / V^T images (outside any capture)
+            nl = self.cfg.num_layers + self.cfg.num_single_layers
+            self.KC = torch.zeros(nl, self.M, self.cfg.inner_dim, dtype=torch.bfloat16, device=self.device)
+            self.VTC = torch.zeros((nl,) + tuple(self.VT.shape), dtype=torch.bfloat16, device=self.device)
         if not self.use_graph or timed:
             if pre:
                 self.mods.copy_(self.sched[1][step_index])
-            return self._forward_eager(latents, timestep, pre)
+            self.cond_skip = skip
+            try:
+                out = self._forward_eager(latents, timestep, pre)
+            finally:
+                self.cond_skip = False
+            self.cond_cached = self.cond_cache
+            return out
         self.g_lat.copy_(latents.reshape(self.g_lat.shape))
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8)
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8,
+               self.cond_cache, skip)
         g = self.graphs.get(key)
         if g is None:
-            mode = (self.precise, self.gemm_fp8, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0)
-            if mode not in self._warmed:                          # lazy code-object loads / buffer allocations must not happen inside capture
-                self._forward_eager(self.g_lat, self.g_t, False)
-                torch.cuda.synchronize(self.device)
-                self._warmed.add(mode)
-            if len(self.graphs) >= 4:
-                self.graphs.clear()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._forward_eager(self.g_lat, self.g_t, pre)
+            mode = (self.precise, self.gemm_fp8, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0, skip)
+            self.cond_skip = skip
+            try:
+                if mode not in self._warmed:                          # lazy code-object loads / buffer allocations must not happen inside capture
+                    self._forward_eager(self.g_lat, self.g_t, False)
+                    torch.cuda.synchronize(self.device)
+                    self._warmed.add(mode)
+                if len(self.graphs) >= 4:
+                    self.graphs.clear()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward_eager(self.g_lat, self.g_t, pre)
+            finally:
+                self.cond_skip = False
             self.graphs[key] = g
         if pre:                                   # AFTER any warm-up pass above, which recomputes the per-step modulations
             self.mods.copy_(self.sched[1][step_index])
         g.replay()
+        self.cond_cached = self.cond_cache
         return self.out.view(self.B, self.N, self.cfg.in_channels)
+
+    def _cond_cache_ok(self) -> bool:
+        """The condition stream is step-invariant and this kernel set can keep its keys / values per layer: condition queries
+        masked from text and image keys (block.py:106-120), the fused projection epilogue in use (it writes the per-layer
+        images), no add_cond_attn (which also needs the condition stream's attention OUTPUT every step)."""
+        if not (self.cond_cache_enabled and self.C and self._qkv_epilogue()) or self.model_config.get("add_cond_attn", False):
+            return False
+        ab = self.attn_bias["cond"]
+        return ab["txt"] == NEG_INF and ab["img"] == NEG_INF
 
     # ------------------------------------------------------------------------------------------ block-level entry points
     # (used by the reference-API mirrors in block.py: same arithmetic as forward(), driven one block at a time)
@@ -1014,6 +1070,7 @@ class DiTEngine:
         self.setup(B, T, N, C)
         self.gemm_ws()
         self.graphs = {}
+        self.cond_cache = self.cond_cached = False                # block-level use: every call computes all three streams
         self.model_config = dict(model_config or {})
         self.c_factor = c_factor
         self.latent_lora = bool(self.model_config.get("latent_lora", False))

@@ -115,7 +115,12 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         d.qkv_norm_q, d.qkv_norm_k, d.qkv_rope, d.qkv_vt = _p(qkv["norm_q"]), _p(qkv["norm_k"]), _p(rope), _p(qkv["vt"])
         d.qkv_d, d.qkv_vt_ld, d.qkv_vt_pos0 = int(qkv["d"]), qkv["vt"].shape[-1], int(qkv["vt_pos0"])
         d.epilogue = epilogue = epilogue | LX_EPI_QKV
-        d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"])     # the descriptor holds raw pointers: keep temporaries alive until launch
+        kimg = qkv.get("k")                 # optional separate key image [M, ld]
+        if kimg is not None:
+            _req(kimg, torch.bfloat16, "qkv.k")
+            assert kimg.shape[0] == d.M and kimg.stride(1) == 1
+            d.qkv_k, d.qkv_k_ld = kimg.data_ptr(), kimg.stride(0)
+        d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"], kimg)     # the descriptor holds raw pointers: keep temporaries alive until launch
     kind = epilogue & 0xff
     want = torch.bfloat16 if kind == LX_EPI_STORE_BF16 else (torch.uint8 if kind == LX_EPI_STORE_FP8 else torch.float32)
     _req(C_, want, "C")
@@ -271,11 +276,14 @@ def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt
     return d
 
 
-def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0) -> None:
+    """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values)."""
     d = _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
+    d.n_qseg = n_qseg
     if TIMER is not None:
         S = sum(seg_len)
-        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        Sq = sum(seg_len[:n_qseg]) if n_qseg else S
+        s, e = TIMER.bracket("attn", 4.0 * B * H * Sq * S * 128)
         s.record()
         check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
         e.record()

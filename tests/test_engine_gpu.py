@@ -197,3 +197,56 @@ def test_two_stream_single_blocks_match_the_serial_schedule(monkeypatch, G):
         outs[ov] = a
     assert torch.equal(outs["0"], outs["1"])
     assert relerr(outs["1"], G["fwd_cond"]) < TOL
+
+
+@pytest.mark.parametrize("mc", [{"independent_condition": True}, {"union_cond_attn": False}, {"independent_condition": True, "latent_lora": True}])
+def test_step_invariant_condition_stream_is_cached(monkeypatch, mc):
+    """independent_condition / union_cond_attn = False (block.py:106-120): the condition queries see only condition keys and c_t is
+    fixed, so the condition stream repeats itself every denoise step. The engine computes it in the first forward of a
+    conditioning, keeps its keys / V^T per layer and runs only the text and image rows afterwards. Three steps with different
+    latents and timesteps: against the fp32 oracle (which recomputes everything every step) and against the engine with
+    LX_COND_CACHE=0; a new conditioning must invalidate the cache."""
+    from oracle import flux_modules as fm
+    tr = tiny_transformer(seed=5)
+    g = torch.Generator().manual_seed(11)
+    B, T, hw = 2, 32, 8
+    N = hw * hw
+    enc, pooled = torch.randn(B, T, 64, generator=g) * 0.5, torch.randn(B, 32, generator=g)
+    ids, tids = fm.prepare_latent_image_ids(hw, hw), torch.zeros(T, 3)
+    cids = ids.clone()
+    cids[:, 2] -= hw
+    conds = [torch.randn(B, N, 64, generator=g) for _ in range(2)]
+    lats = [torch.randn(B, N, 64, generator=g) for _ in range(3)]
+    ts = [torch.tensor([0.9, 0.8]), torch.tensor([0.55, 0.5]), torch.tensor([0.2, 0.1])]
+    guid = torch.full((B,), 3.5)
+    def oracle(cond, lat, t):
+        with torch.no_grad():
+            return fr.tranformer_forward(tr, cond, cids, None, mc, hidden_states=lat, encoder_hidden_states=enc, pooled_projections=pooled,
+                                         timestep=t, img_ids=ids, txt_ids=tids, guidance=guid)[0]
+    d = "cuda"
+    res = {}
+    for cache in ("1", "0"):
+        monkeypatch.setenv("LX_COND_CACHE", cache)
+        eng = _engine(tr)
+        outs = []
+        for ci, cond in enumerate(conds):
+            eng.set_conditioning(enc.to(d), pooled.to(d), guid.to(d), tids.to(d), ids.to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=mc)
+            for k in range(3):
+                assert eng.cond_cached == (cache == "1" and k > 0)
+                outs.append(eng.forward(lats[k].to(d), ts[k].to(d)).float().cpu().clone())
+                assert eng.cond_cache == (cache == "1")
+        res[cache] = outs
+    for ci, cond in enumerate(conds):
+        for k in range(3):
+            want = oracle(cond, lats[k], ts[k])
+            e1, e0 = relerr(res["1"][ci * 3 + k], want), relerr(res["0"][ci * 3 + k], want)
+            assert e1 < TOL and e0 < TOL, (ci, k, e1, e0)
+            assert relerr(res["1"][ci * 3 + k], res["0"][ci * 3 + k]) < 5e-3
+    if mc.get("union_cond_attn", True):                        # (without union attention the image never sees the condition at all)
+        assert relerr(res["1"][0], res["1"][3]) > 1e-3        # the two conditionings differ: the cache really was refreshed
+
+
+def test_condition_cache_is_off_when_the_condition_stream_sees_the_image(G):
+    eng = _engine(tiny_transformer())
+    _run(eng, G)                                              # default union attention: nothing to cache
+    assert not eng.cond_cache and not eng.cond_cached and eng.KC is None

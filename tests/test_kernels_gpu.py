@@ -474,6 +474,51 @@ def test_gemm_qkv_epilogue_matches_projection_plus_qkv_prep(ops, monkeypatch, bm
         assert torch.equal(VTf, VTu)
 
 
+def test_gemm_qkv_epilogue_separate_key_image_and_attention_query_subset(ops):
+    """qkv_k: the k columns go to a separate [M, D] image (C's k columns stay untouched); lx_attn_fwd with n_qseg = 1 of 2 segments
+    computes exactly the first segment's rows of the full call and leaves the other rows of O alone."""
+    B, H, K = 1, 2, 128
+    D = H * 128
+    lens = [64, 96]
+    row0, vt0, vt_ld = _segments(B, lens)
+    M = sum(lens)
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(3 * D, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    bias = rnd(3 * D, seed=3, scale=0.2)
+    w1 = 1 + 0.1 * rnd(128, seed=4)
+    ropes = []
+    for Ls in lens:
+        cs = torch.zeros(Ls, 128)
+        cs[:, 0::2] = 1.0
+        ropes.append(cs.to(DEV))
+    def project(sep):
+        C = torch.full((M, 3 * D), 7.0, dtype=torch.bfloat16, device=DEV)
+        Kimg = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+        VT = torch.zeros(B, H, 128, vt_ld, dtype=torch.bfloat16, device=DEV)
+        probs = []
+        for i, Ls in enumerate(lens):
+            rows = slice(row0[i], row0[i] + Ls)
+            q = dict(norm_q=w1, norm_k=w1, rope=ropes[i], vt=VT, vt_pos0=vt0[i], d=D)
+            if sep:
+                q["k"] = Kimg[rows]
+            probs.append(ops.gemm_desc(A[rows], W, C[rows], bias=bias, rows_per_batch=Ls, qkv=q))
+        ops.gemm(probs)
+        return C, Kimg, VT
+    C0, _, VT0 = project(False)
+    C1, K1, VT1 = project(True)
+    assert torch.equal(K1, C0[:, :D]) and torch.equal(VT0, VT1) and torch.equal(C1[:, 2 * D:], C0[:, 2 * D:])
+    assert float((C1[:, :D].float() - 7.0).abs().max()) == 0.0            # k columns of C untouched
+    kw = dict(q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=lens, seg_vt0=vt0)
+    O_full = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(C1, K1, VT1, O_full, **kw)
+    O_sub = torch.full((M, D), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(C1, K1, VT1, O_sub, n_qseg=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(O_sub[:lens[0]], O_full[:lens[0]])
+    assert float((O_sub[lens[0]:].float() - 3.0).abs().max()) == 0.0
+    assert float(O_full[lens[0]:].float().abs().max()) > 0.0
+
+
 def test_gemm_qkv_epilogue_argument_checks(ops):
     from loongx_amd._lib import LxError
     D, K, Ls = 256, 64, 48
