@@ -106,3 +106,17 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, LX_AMD_LIB=str(tmp_path / "nope.so"), PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", "import loongx_amd.ops"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "ImportError" in r.stderr and "liblx_amd.so not found" in r.stderr and "no CPU/torch fallback" in r.stderr
+
+
+def test_bench_flop_accounting_and_power_sampler_without_a_gpu():
+    """bench.py's algorithmic-flop figures and the hwmon sampler's behaviour where there is no GPU / sysfs."""
+    import bench
+    D, S = 3072, 2560
+    full = bench.flops_per_image(1024, 1024)
+    per_fwd = 57 * (24.0 * S * D * D + 4.0 * S * S * D) - 2.0 * 1536 * 10 * D * D
+    assert abs(full - 28 * per_fwd) / full < 1e-12 and 1.04e15 < full < 1.06e15            # 1.055 PFLOP per image
+    cached = bench.flops_per_image_cond_cached(1024, 1024)
+    assert full / 28 < cached < full and 0.55 < cached / full < 0.65                       # 27 of 28 steps run 60 % of the rows
+    ps = bench.PowerSampler(0)
+    ps.start()
+    assert ps.stop() is None
