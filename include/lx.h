@@ -172,6 +172,12 @@ int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* sca
 typedef struct lx_ln_seg { int32_t row0, n_rows, rows_per_batch, _pad; const float* shift; const float* scale; } lx_ln_seg;
 int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
                         float eps, void* stream);
+/* The same, and for the rows [lora_row0, lora_row0 + lora_rows) of Y (the token streams that run with their adapters on,
+ * lora_controller.py:5-42) also the LoRA down-projection of the row just written: T[row - lora_row0, 0..R) (fp32, ldt) =
+ * Y_row(bf16) . Adown[R, D]^T (bf16), R <= 16 -- what lx_lora_down(Y rows, Adown, T, n_split = 1) computes, without the
+ * second pass over the rows (block.py:24, 299: the q/k/v(/proj_mlp) adapters read the AdaLN-normalised stream). D = 3072 | 256. */
+int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                             float eps, const void* Adown, int R, float* T, int ldt, int lora_row0, int lora_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-head RMSNorm (weight, eps) + interleaved-pair RoPE on Q and K, in place, and V transposed into the

@@ -16,9 +16,15 @@ struct LnSegs {   // up to 3 row segments (token streams), each with its own mod
   const float* scale[3];
 };
 
-template <int NCH>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
+// RQ > 0: the rows [lora_row0, lora_row0 + lora_rows) (the streams that run with the adapter on) also get their LoRA down-projection
+// T[row - lora_row0, 0..R) = Y_row(bf16) . Adown[R, D]^T (R <= 4 RQ) while the normalised row is still in registers: the separate
+// lx_lora_down launch over the same rows (7 us, 57 per denoise step) disappears. Same operands as that kernel (the bf16-rounded row,
+// bf16 Adown), fp32 accumulation in a different order.
+struct LnLora { const uint16_t* A; float* T; int R, ldt, row0, rows; };
+
+template <int NCH, int RQ = 0>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
-                                                          uint16_t* __restrict__ Y, int ldy, int M, int D, float eps) {
+                                                          uint16_t* __restrict__ Y, int ldy, int M, int D, float eps, const LnLora lo = LnLora{}) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   int sg = 0, acc_rows = 0;
@@ -51,6 +57,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   const float* sh = shift + (size_t)b * mod_ld;
   const float* sc = scale + (size_t)b * mod_ld;
   uint16_t* yr = Y + (size_t)row * ldy;
+  const bool with_lora = RQ > 0 && row >= lo.row0 && row < lo.row0 + lo.rows;      // wave-uniform
+  float t[RQ > 0 ? 4 * RQ : 1];
+#pragma unroll
+  for (int j = 0; j < (RQ > 0 ? 4 * RQ : 1); ++j) t[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int col = (i * 64 + lane) * 4;
@@ -63,6 +73,34 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     w[0] = pack_bf16x2(o[0], o[1]);
     w[1] = pack_bf16x2(o[2], o[3]);
     *(u32x2*)(yr + col) = w;
+    if constexpr (RQ > 0) {
+      if (with_lora) {
+        const float y0 = __uint_as_float(w[0] << 16), y1 = __uint_as_float(w[0] & 0xffff0000u);
+        const float y2 = __uint_as_float(w[1] << 16), y3 = __uint_as_float(w[1] & 0xffff0000u);
+        u32x2 ar[4 * RQ];
+#pragma unroll
+        for (int j = 0; j < 4 * RQ; ++j) ar[j] = *(const u32x2*)(lo.A + (size_t)min(j, lo.R - 1) * D + col);
+#pragma unroll
+        for (int j = 0; j < 4 * RQ; ++j) {
+          t[j] = __builtin_fmaf(y0, __uint_as_float(ar[j][0] << 16), t[j]);
+          t[j] = __builtin_fmaf(y1, __uint_as_float(ar[j][0] & 0xffff0000u), t[j]);
+          t[j] = __builtin_fmaf(y2, __uint_as_float(ar[j][1] << 16), t[j]);
+          t[j] = __builtin_fmaf(y3, __uint_as_float(ar[j][1] & 0xffff0000u), t[j]);
+        }
+      }
+    }
+  }
+  if constexpr (RQ > 0) {
+    if (with_lora) {
+#pragma unroll
+      for (int j = 0; j < 4 * RQ; ++j) t[j] = wave_sum(t[j]);
+      if (lane == 0) {
+        float* tp = lo.T + (size_t)(row - lo.row0) * lo.ldt;
+#pragma unroll
+        for (int j = 0; j < 4 * RQ; ++j)
+          if (j < lo.R) tp[j] = t[j];
+      }
+    }
   }
 }
 
@@ -523,7 +561,8 @@ __global__ void convert_kernel(void* __restrict__ dst, int dst_bf16, const void*
 
 }  // namespace
 
-static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, void* Y, int ldy, int D, float eps, void* stream) {
+static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, void* Y, int ldy, int D, float eps, void* stream,
+                     const LnLora* lora = nullptr) {
   int M = 0;
   for (int i = 0; i < segs.n; ++i) {
     LX_CHECK_ARG(segs.shift[i] && segs.scale[i] && segs.n_rows[i] > 0 && segs.rows_per_batch[i] > 0, "lx_ln_modulate: bad segment %d", i);
@@ -537,8 +576,21 @@ static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, vo
   const dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   uint16_t* y = (uint16_t*)Y;
-  if (D == 3072) hipLaunchKernelGGL(ln_modulate_kernel<12>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
-  else if (D == 256) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
+  if (lora) {
+    LX_CHECK_ARG(D == 3072 || D == 256, "lx_ln_modulate_lora_segs: the fused down-projection exists for D = 3072 and 256 (D=%d): use lx_lora_down", D);
+    LX_CHECK_ARG(lora->A && lora->T && lora->R >= 1 && lora->R <= 16 && lora->ldt >= lora->R && lora->rows > 0 && lora->row0 >= 0,
+                 "lx_ln_modulate_lora_segs: bad adapter arguments (R=%d)", lora->R);
+    LX_CHECK_ARG(((uintptr_t)lora->A & 7) == 0, "lx_ln_modulate_lora_segs: Adown must be 8-byte aligned");
+    const int rq = (lora->R + 3) / 4;
+#define LX_LN_LORA(NCH, RQ) hipLaunchKernelGGL((ln_modulate_kernel<NCH, RQ>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora)
+    if (D == 3072) { if (rq == 1) LX_LN_LORA(12, 1); else if (rq == 2) LX_LN_LORA(12, 2); else if (rq == 3) LX_LN_LORA(12, 3); else LX_LN_LORA(12, 4); }
+    else { if (rq == 1) LX_LN_LORA(1, 1); else if (rq == 2) LX_LN_LORA(1, 2); else if (rq == 3) LX_LN_LORA(1, 3); else LX_LN_LORA(1, 4); }
+#undef LX_LN_LORA
+    LX_LAUNCH_CHECK("lx_ln_modulate_lora_segs");
+    return LX_OK;
+  }
+  if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{});
+  else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{});
   else hipLaunchKernelGGL(ln_modulate_generic, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
   LX_LAUNCH_CHECK("lx_ln_modulate");
   return LX_OK;
@@ -563,6 +615,19 @@ extern "C" int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg
     segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
   }
   return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream);
+}
+
+extern "C" int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                                        float eps, const void* Adown, int R, float* T, int ldt, int lora_row0, int lora_rows, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_ln_modulate_lora_segs: 1..3 segments");
+  LnSegs segs;
+  segs.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.n_rows[i] = seg[i].n_rows; segs.rows_per_batch[i] = seg[i].rows_per_batch;
+    segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
+  }
+  const LnLora lo{(const uint16_t*)Adown, T, R, ldt, lora_row0, lora_rows};
+  return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream, &lo);
 }
 
 static int qkv_launch(void* QKV, int ld, int q_col, int k_col, int v_col, QkvSegs& segs, int n_batches, int H, float eps, void* VT,

@@ -70,6 +70,7 @@ class DiTEngine:
         self.cond_cached = False         # the per-layer images hold this conditioning's condition keys / values
         self.cond_skip = False           # the forward being enqueued runs without the condition rows
         self.KC = self.VTC = None        # [layers, M, D] keys / [layers, B, H, 128, vt_ld] V^T, allocated on first use
+XX
         # two-stream single blocks (opt-in, LX_OVERLAP=1): measured +0.3 % -- the step runs at the 1400 W package power cap, so filling
         # the partly idle last rounds of a kernel with another kernel's workgroups buys clock back elsewhere, not time
         self.overlap = os.environ.get("LX_OVERLAP", "0") == "1"
@@ -388,14 +389,29 @@ class DiTEngine:
         self.sched = None
 
     # ------------------------------------------------------------------------------------------ building blocks
-    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
+    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int, lora_name: Optional[str] = None, include_txt: bool = False):
+        """AdaLN LayerNorm + modulation of every stream of this forward into XN. `lora_name`: the adapter whose modules read XN next
+        (q/k/v, + proj_mlp in single blocks): its down-projection of the adapter rows is computed in the same launch (one slab in
+        TL) and returned as (Lora, first row, n_slabs = 1) for _gemm_streams(lora=...); None when there is nothing to project."""
         row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
         segs = []
         for s, L in self._streams():
             mods = self.cmods if s == "cond" else self.mods
             b0 = base_by_stream[s]
             segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
-        ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0))
+        lora = None
+        if lora_name is not None and self.ln_lora and self.cfg.inner_dim in (3072, 256):
+            lo = self.w.lora.get(lora_name)
+            rows = self._lora_rows(include_txt)
+            if lo is not None and rows is not None and not (self.C == 0 and not self.latent_lora) and self.lora_scale != 0.0:
+                r0, n = rows
+                lora = (lo.down, self.TL[r0:r0 + n], r0, n)
+        ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0), lora=lora)
+        if lora is None:
+            return None
+        if self.lora_scale != 1.0:
+            self.TL[lora[2]:lora[2] + lora[3], : lo.down.shape[0]].mul_(self.lora_scale)
+        return lo, lora[2], 1
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
@@ -429,8 +445,11 @@ class DiTEngine:
         first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
         w = self.w
         lora_needed = only is None or "cond" in only or self.latent_lora
-        if lora is not None:               # (Lora, first row) already projected down by the caller (one lx_lora_down for several launches)
-            lo, lr0 = lora if lora_needed else (None, None)
+        nsplit = self.TL_SPLIT
+        if lora is not None:               # (Lora, first row[, slabs]) already projected down by the caller (_ln, or one lx_lora_down for several launches)
+            lo, lr0 = lora[:2] if lora_needed else (None, None)
+            if len(lora) > 2:
+                nsplit = lora[2]
         else:
             lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
         probs = []
@@ -467,7 +486,7 @@ class DiTEngine:
                 row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
                 if row0 >= lr0:
                     kw.update(lora_t=self.TL[row0:row0 + a.shape[0], lora_t_col0:], lora_up=lo.up[c0:c0 + W.shape[0]], lora_mod_cols=lora_mod_cols,
-                              lora_toff_max=lora_toff_max, lora_nsplit=self.TL_SPLIT, lora_split_stride=self.TLs.stride(0))
+                              lora_toff_max=lora_toff_max, lora_nsplit=nsplit, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, W, c, **kw))
         ops.gemm(probs, self.gemm_ws() if ws else None)
 
@@ -552,11 +571,11 @@ class DiTEngine:
         base = {"img": b, "cond": b, "txt": b + 6 * D}
         p = f"d{i}"
         Yq, Ya, Yf = self.Y[:, : 3 * D], self.Y[:, 2 * D: 3 * D], self.Y[:, 3 * D:]
-        self._ln(base, 0, D)                                                               # norm1 / norm1_context
+        lora = self._ln(base, 0, D, lora_name=p + ".qkv")                                  # norm1 / norm1_context (+ the q/k/v adapters' down-projection)
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
         fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2,
-                           qkv=nw + (i,) if fused else None)
+                           qkv=nw + (i,) if fused else None, lora=lora)
         self._attention(*nw, prepped=fused, layer=i)
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
@@ -586,7 +605,7 @@ class DiTEngine:
         b = cfg.mod_base_single(j)
         base = {"img": b, "cond": b, "txt": b}
         p = f"s{j}"
-        self._ln(base, 0, D)
+        ln_lora = self._ln(base, 0, D, lora_name=p + ".fused", include_txt=True)
         kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
         fused = self._qkv_epilogue()
@@ -594,7 +613,7 @@ class DiTEngine:
             # The MLP-up half of the fused projection does not feed the attention: it runs on a second stream beside
             # {q/k/v projection -> attention}, so that the partly filled last rounds of the three kernels (0.41 + 0.88 + 0.94 of a
             # round of 256 CUs) share the chip instead of each waiting for its own stragglers. One lx_lora_down serves both launches.
-            lora = self._lora_t(self.XN, p + ".fused", include_txt=True)
+            lora = ln_lora if ln_lora is not None else self._lora_t(self.XN, p + ".fused", include_txt=True)
             main_s, side = torch.cuda.current_stream(self.device), self.side_stream
             fork, join = torch.cuda.Event(), torch.cuda.Event()
             fork.record(main_s)
@@ -610,7 +629,8 @@ class DiTEngine:
             main_s.wait_event(join)
         else:
             self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None)
+                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None,
+                               lora=ln_lora)
             self._attention(*nw, prepped=fused, layer=cfg.num_layers + j)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,

@@ -250,3 +250,14 @@ def test_condition_cache_is_off_when_the_condition_stream_sees_the_image(G):
     eng = _engine(tiny_transformer())
     _run(eng, G)                                              # default union attention: nothing to cache
     assert not eng.cond_cache and not eng.cond_cached and eng.KC is None
+
+
+def test_lora_down_inside_ln_modulate_matches_the_separate_launch(monkeypatch, G):
+    """LX_LN_LORA=1 (opt-in): T of the q/k/v(/proj_mlp) adapters from lx_ln_modulate_lora_segs instead of lx_lora_down."""
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("LX_LN_LORA", v)
+        eng = _engine(tiny_transformer())
+        assert eng.ln_lora == (v == "1")
+        outs[v] = _run(eng, G)
+    assert relerr(outs["1"], outs["0"]) < 2e-3 and relerr(outs["1"], G["fwd_cond"]) < TOL
