@@ -70,7 +70,10 @@ class DiTEngine:
         self.cond_cached = False         # the per-layer images hold this conditioning's condition keys / values
         self.cond_skip = False           # the forward being enqueued runs without the condition rows
         self.KC = self.VTC = None        # [layers, M, D] keys / [layers, B, H, 128, vt_ld] V^T, allocated on first use
-XX
+        # LoRA down-projection of the AdaLN-normalised stream inside ln_modulate (opt-in, LX_LN_LORA=1). Measured: -1.1 % (1011 vs
+        # 1000 ms per image): 57 lx_lora_down launches of 7 us go, but the 576-768 extra FMAs + 12-16 wave reductions per adapter row
+        # lengthen ln_modulate's condition-row workgroups by more than that. Kept for A/B; the default is the separate launch.
+        self.ln_lora = os.environ.get("LX_LN_LORA", "0") == "1"
         # two-stream single blocks (opt-in, LX_OVERLAP=1): measured +0.3 % -- the step runs at the 1400 W package power cap, so filling
         # the partly idle last rounds of a kernel with another kernel's workgroups buys clock back elsewhere, not time
         self.overlap = os.environ.get("LX_OVERLAP", "0") == "1"
