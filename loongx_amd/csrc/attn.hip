@@ -746,6 +746,345 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 attention, software-pipelined (default; LX_ATTN_FP8_PIPE=0 selects the plain kernel above): the principle of
+// lx_attn_pipe_kernel -- a wave's vector instructions run in the shadow of ITS OWN MFMAs -- on the 8-MFMA fp8 tile, whose
+// bottleneck is the vector pipe (the plain kernel: ~170 vector instructions per key tile and wave against 8 MFMAs of 64 cycles).
+// One iteration t = eight gaps, each {LDS fragment reads for the next gap, a slice of vector work, one MFMA}:
+//   gaps 0-3 : K.Q^T of tile t+1 (scores of the NEXT tile)  beside  exp2 / e4m3 packing of tile t (8 scores per gap)
+//   gaps 4-7 : V^T.P^T of tile t                             beside  row max and rescale decision of tile t+1
+// and what the vector pipe no longer does at all:
+//   * row sums: a ninth MFMA per tile multiplies P^T by a fragment whose row 0 is all ones (e4m3 1.0): lacc[0] of lanes 0-31
+//     accumulates sum_k P[k, q] of the ROUNDED probabilities (the values P.V sees) -- 32 v_add per tile less;
+//   * POW2 (the softmax scale x log2 e x operand descale is an exact power of two 2^-k: ops.py picks the q scale that way): the
+//     score MFMAs run with the MX block scale 2^-k (E8M0 operand of v_mfma_scale_f32_32x32x64_f8f6f4: exact, free) and start from
+//     an accumulator that already holds `bias - running max` (offv: 16 registers, rewritten only when the running max moves), so
+//     a finished score IS the exp2 argument -- 32 v_fma per tile less. The running max a tile is computed against is the one
+//     BEFORE that tile (its own maximum is not known when its MFMAs start); the deferred-rescale rule absorbs that: a tile whose
+//     maximum exceeds the reference by more than 2^DEFER_THR moves the reference and has its 32 scores corrected (rare).
+// Score registers: kb = 1 of tile t+1 is produced (gaps 0-1) while kb = 0 of tile t is consumed, kb = 0 of tile t+1 (gaps 2-3) goes
+// into the registers kb = 0 of tile t just left: three 16-register sets, not four; the other two swap roles every iteration (the
+// loop body is expanded twice). The O rescale of a tile is applied at the head of the iteration that multiplies it in, K(t+2)
+// and V^T(t+1) are staged into the slots K(t) / V^T(t-1) vacated (one 1-KiB LDS-DMA piece per wave and operand), one barrier per
+// tile. Results differ from lx_attn_fp8_kernel only in rounding (row sums of rounded P, reference max one tile later).
+template <bool DEFER, bool POW2>
+__global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs args, float qk_descale, float v_descale, int e8m0) {
+  constexpr int QBLK = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE8_BYTES];      // K slot s at s*STAGE8, V^T slot s at s*STAGE8 + K8
+  const lx_attn_desc& D = args.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int BH = D.B * D.H;
+  const int bh = blockIdx.x % BH;
+  const int qt = blockIdx.x / BH;
+  const int b = bh / D.H, h = bh % D.H;
+  int sq = 0;
+#pragma unroll
+  for (int s = 1; s < 3; ++s)
+    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
+  const int n_seg = D.n_seg;
+  const int len0 = D.seg_len[0], len1 = D.seg_len[1], len2 = D.seg_len[2];
+  const int row00 = D.seg_row0[0], row01 = D.seg_row0[1], row02 = D.seg_row0[2];
+  const int vt00 = D.seg_vt0[0], vt01 = D.seg_vt0[1], vt02 = D.seg_vt0[2];
+  const float bia0 = D.bias[sq][0], bia1 = D.bias[sq][1], bia2 = D.bias[sq][2];
+  auto pick = [](int s, auto x0, auto x1, auto x2) { return s == 0 ? x0 : (s == 1 ? x1 : x2); };
+  auto seg_len = [&](int s) { return pick(s, len0, len1, len2); };
+  const int q_len = seg_len(sq);
+  const int q_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 32 + l31;
+  const bool q_valid = q_in_seg < q_len;
+  const size_t q_row = (size_t)pick(sq, row00, row01, row02) + (size_t)b * q_len + min(q_in_seg, q_len - 1);
+
+  i32x8 qf[2];
+  {
+    const uint8_t* qp = (const uint8_t*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 32;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const u32x4 lo = *(const u32x4*)(qp + hf * 64), hi = *(const u32x4*)(qp + hf * 64 + 16);
+      qf[hf] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    }
+  }
+  const float c2 = D.scale * qk_descale * 1.4426950408889634f;      // (!POW2: multiplies every score; POW2: it is 2^(e8m0 - 127))
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f;
+  f32x16 lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  const int one_w = l31 == 0 ? 0x38383838 : 0;
+  const i32x8 ones_frag = {one_w, one_w, one_w, one_w, one_w, one_w, one_w, one_w};
+
+  const uint8_t* Kbase = (const uint8_t*)D.K + D.k_col + h * DH;
+  const uint8_t* Vbase = (const uint8_t*)D.VT + (size_t)bh * DH * D.vt_ld;
+  const int ldk = D.ldk, vt_ld = D.vt_ld;
+  struct Tile { int krow, vpos, nvalid, nclamp; float bl; };
+  int g_seg = -1, g_left = 0;
+  Tile g_cur = {0, 0, 0, 1, 0.f};
+  auto gen_next = [&]() {
+    if (g_left > 0) {
+      g_cur.krow += KVBLK; g_cur.vpos += KVBLK;
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      do { ++g_seg; } while (g_seg < n_seg && !(pick(g_seg, bia0, bia1, bia2) > -1e37f));
+      if (g_seg >= n_seg) { g_cur.nvalid = 0; g_cur.nclamp = 1; g_left = 0; return; }   // krow / vpos stay on the last real tile
+      g_left = seg_len(g_seg);
+      g_cur.krow = pick(g_seg, row00, row01, row02) + b * g_left;
+      g_cur.vpos = pick(g_seg, vt00, vt01, vt02);
+      g_cur.bl = pick(g_seg, bia0, bia1, bia2) * 1.4426950408889634f;
+    }
+    g_cur.nvalid = min(g_left, KVBLK);
+    g_cur.nclamp = g_cur.nvalid;
+    g_left -= g_cur.nvalid;
+  };
+  gen_next();
+  Tile t0 = g_cur;                  // tile t: exp2 / packing / P.V
+  gen_next();
+  Tile t1 = g_cur;                  // tile t+1: scores, row max, its V^T staged
+  gen_next();
+  Tile t2 = g_cur;                  // tile t+2: its K staged
+
+  // this wave's staging pieces: K = 8 key rows of 128 B (lane -> row lane>>3, slot lane&7), V^T = 16 d rows of 64 B (row lane>>2, slot lane&3)
+  const int k_key = wave * 8 + (lane >> 3);
+  const int k_lslot = (lane & 7) ^ ((k_key >> 1) & 7);
+  const int v_drow = wave * 16 + (lane >> 2);
+  const int v_lslot = (lane & 3) ^ ((v_drow >> 2) & 3);
+  auto stage_k = [&](const Tile& T, int slot) {      // rows past the tile's last valid key are clamped (loaded, masked later)
+    const uint8_t* src = Kbase + (size_t)(T.krow + min(k_key, T.nclamp - 1)) * ldk + k_lslot * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + slot * STAGE8_BYTES + wave * 1024), 16, 0, 0);
+  };
+  auto stage_v = [&](const Tile& T, int slot) {
+    const uint8_t* src = Vbase + (size_t)v_drow * vt_ld + T.vpos + v_lslot * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + slot * STAGE8_BYTES + K8_BYTES + wave * 1024), 16, 0, 0);
+  };
+  const int ksw = (l31 >> 1) & 7, vsw = (l31 >> 2) & 3;
+  auto frag = [&](const char* p0, int slot_a, int sw) {
+    const u32x4 lo = *(const u32x4*)(p0 + ((slot_a ^ sw) * 16)), hi = *(const u32x4*)(p0 + (((slot_a + 1) ^ sw) * 16));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  // fragment of gap g: 0-1 = K(t+1) key block 1 (d half g), 2-3 = K(t+1) key block 0 (d half g-2), 4-7 = V^T(t) d block g-4
+  auto frag_of = [&](int g, const char* kbuf, const char* vbuf) {
+    if (g < 4) return frag(kbuf + ((g < 2 ? 32 : 0) + l31) * 128, (g & 1) * 4 + lhi * 2, ksw);
+    return frag(vbuf + ((g - 4) * 32 + l31) * 64, lhi * 2, vsw);
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 s0, s1a, s1b;              // scores: key block 0 (in place), key block 1 of the current / next tile (swap roles)
+  f32x16 offv = zero16;             // POW2: bias - running max in all 16 slots = the accumulator the score MFMAs start from
+  int pfw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float off = 0.f, alpha = 1.f, mx[4], t_new = 0.f;
+  bool resc = false;                 // wave-uniform: O must be multiplied by alpha before the next P.V
+  auto qk = [&](const i32x8& a, const i32x8& q, const f32x16& c) {
+    if constexpr (POW2) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, q, c, 0, 0, 0, e8m0, 0, 127);
+    else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, q, c, 0, 0, 0, 0, 0, 0);
+  };
+
+#define LX8_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // hipcc linearises pure arithmetic freely inside a basic block (sched_barrier only holds what already sits on either side of it):
+  // every slice takes its inputs through an empty asm at the head of its gap and leaves its results through one at the end, and
+  // the gap's MFMA takes its fragment through one in front of it and hands its result through one behind it -- that is what keeps
+  // {reads, slice, MFMA} in this order.
+  // exp2 / packing of eight scores of tile t: chunk c -> key block c>>1 (SCk), register quads 2*(c&1), 2*(c&1)+1
+#define LX8_SOFT(c, SCk)                                                                                               \
+  {                                                                                                                    \
+    if constexpr (!POW2) { asm volatile("" : "+v"(off)); }                                                             \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                                 \
+      constexpr int kb_ = ((c) >> 1) & 1;                                                                              \
+      const int rq_ = ((c) & 1) * 2 + q_;                                                                              \
+      float pv_[4];                                                                                                    \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                               \
+        if constexpr (POW2) { float x_ = SCk[rq_ * 4 + e_]; asm volatile("" : "+v"(x_)); pv_[e_] = __builtin_amdgcn_exp2f(x_); } \
+        else pv_[e_] = __builtin_amdgcn_exp2f(fmaf(SCk[rq_ * 4 + e_], c2, off));                                       \
+      }                                                                                                                \
+      int w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[0], pv_[1], pfw[kb_ * 4 + rq_], false);   /* (old value: both halves are overwritten; a literal 0 costs a v_mov) */ \
+      w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[2], pv_[3], w_, true);                                                  \
+      pfw[kb_ * 4 + rq_] = w_;                                                                                         \
+      asm volatile("" : "+v"(pfw[kb_ * 4 + rq_]));                                                                     \
+    }                                                                                                                  \
+  }
+  // 8-score v_max3 chains of one key block (4 instructions per 8 scores)
+#define LX8_MAX8(dst, S, h_)                                                                                           \
+  {                                                                                                                    \
+    float m_ = __builtin_fmaxf(__builtin_fmaxf(S[8 * (h_)], S[8 * (h_) + 1]), S[8 * (h_) + 2]);                        \
+    m_ = __builtin_fmaxf(__builtin_fmaxf(m_, S[8 * (h_) + 3]), S[8 * (h_) + 4]);                                       \
+    m_ = __builtin_fmaxf(__builtin_fmaxf(m_, S[8 * (h_) + 5]), S[8 * (h_) + 6]);                                       \
+    dst = __builtin_fmaxf(m_, S[8 * (h_) + 7]);                                                                        \
+  }
+  // row max of tile t+1 (SN0 = key block 0, SN1 = key block 1), rescale decision, reference of tile t+2 -- pieces 0..3 behind gaps 4..7
+#define LX8_MAX(c, SN0, SN1)                                                                                           \
+  if ((c) == 0) {                                                                                                      \
+    LX8_MAX8(mx[2], SN1, 0) LX8_MAX8(mx[3], SN1, 1)                                                                    \
+    asm volatile("" : "+v"(mx[2]), "+v"(mx[3]));                                                                       \
+  } else if ((c) == 1) {                                                                                               \
+    LX8_MAX8(mx[0], SN0, 0) LX8_MAX8(mx[1], SN0, 1)                                                                    \
+    asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));                                                                       \
+  } else if ((c) == 2) {                                                                                               \
+    asm volatile("" : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "+v"(mx[3]));                                             \
+    float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx[0], mx[1]), mx[2]), mx[3]);                          \
+    const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_), __float_as_uint(m_), false, false);         \
+    if constexpr (POW2) t_new = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));      /* already relative to the reference */ \
+    else t_new = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * c2 + t1.bl;                                 \
+    asm volatile("" : "+v"(t_new));                                                                                    \
+  } else {                                                                                                             \
+    asm volatile("" : "+v"(t_new));                                                                                    \
+    if (t1.nvalid > 0) {              /* a tile past the end contributes nothing and must not move the running max */ \
+      if constexpr (POW2) {                                                                                            \
+        bool r_ = __builtin_amdgcn_ballot_w64(t_new > (DEFER ? DEFER_THR : 0.f)) != 0;                                 \
+        if (r_) {                     /* move the reference up by this row's excess and re-reference the tile's scores */ \
+          const float d_ = fmaxf(t_new, 0.f);                                                                          \
+          alpha = __builtin_amdgcn_exp2f(-d_);                                                                         \
+          m_run += d_;                                                                                                 \
+          _Pragma("unroll") for (int r2_ = 0; r2_ < 16; ++r2_) { SN0[r2_] -= d_; SN1[r2_] -= d_; }                     \
+          resc = true;                                                                                                 \
+        }                                                                                                              \
+        if (r_ || t2.bl != t1.bl) {   /* the accumulator tile t+2's scores start from */                              \
+          const float o_ = t2.bl - m_run;                                                                              \
+          _Pragma("unroll") for (int r2_ = 0; r2_ < 16; ++r2_) offv[r2_] = o_;                                         \
+        }                                                                                                              \
+      } else {                                                                                                         \
+        bool r_ = true;                                                                                                \
+        if (DEFER) r_ = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;                                   \
+        if (r_) {                                                                                                      \
+          const float m_new = fmaxf(m_run, t_new);                                                                     \
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                               \
+          m_run = m_new;                                                                                               \
+          resc = true;                                                                                                 \
+        }                                                                                                              \
+        off = t1.bl - m_run;                                                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if constexpr (!POW2) { asm volatile("" : "+v"(off)); }                                                             \
+  }
+  // score MFMA of gap g (0-1: key block 1 -> SN1, 2-3: key block 0 -> SN0) / P.V MFMA of gap g (4-7)
+#define LX8_MM(g, SN0, SN1)                                                                                            \
+  asm volatile("" : "+v"(fr[(g) & 1]));                                                                                \
+  if ((g) < 2) {                                                                                                       \
+    SN1 = qk(fr[(g) & 1], qf[(g) & 1], ((g) & 1) ? SN1 : (POW2 ? offv : zero16));                                      \
+    asm volatile("" : "+v"(SN1));     /* (an MFMA is pure arithmetic to hipcc too: without this it sinks to its first use) */ \
+  } else if ((g) < 4) {                                                                                                \
+    SN0 = qk(fr[(g) & 1], qf[(g) & 1], ((g) & 1) ? SN0 : (POW2 ? offv : zero16));                                      \
+    asm volatile("" : "+v"(SN0));                                                                                      \
+  } else {                                                                                                             \
+    const i32x8 pf_ = {pfw[0], pfw[1], pfw[2], pfw[3], pfw[4], pfw[5], pfw[6], pfw[7]};                                \
+    oacc[((g) - 4) & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fr[(g) & 1], pf_, oacc[((g) - 4) & 3], 0, 0, 0, 0, 0, 0); \
+    asm volatile("" : "+v"(oacc[((g) - 4) & 3]));                                                                      \
+  }
+  // one gap: reads of the NEXT gap's fragment, the vector slice, this gap's MFMA.  S0 = key block 0 (tile t, then t+1 in place),
+  // S1C / S1N = key block 1 of tile t / t+1
+#define LX8_GAP(g, S0, S1C, S1N, PAR)                                                                                  \
+  if ((g) < 7) fr[((g) + 1) & 1] = frag_of((g) + 1, kbuf, vbuf);                                                       \
+  LX8_FENCE();                                                                                                         \
+  if ((g) < 2) { LX8_SOFT((g) & 1, S0) } else if ((g) < 4) { LX8_SOFT(2 + ((g) & 1), S1C) } else { LX8_MAX(((g) - 4) & 3, S0, S1N) } \
+  if ((g) == 1) stage_k(t2, PAR);                                                                                      \
+  if ((g) == 5) stage_v(t1, (PAR) ^ 1);                                                                                \
+  LX8_FENCE();                                                                                                         \
+  LX8_MM(g, S0, S1N)                                                                                                   \
+  LX8_FENCE();
+#define LX8_ITER(S0, S1C, S1N, PAR)    /* PAR = t & 1, a literal: the loop body is expanded once per parity */            \
+  {                                                                                                                    \
+    const char* kbuf = smem + ((PAR) ^ 1) * STAGE8_BYTES;                   /* K(t+1) */                               \
+    const char* vbuf = smem + (PAR) * STAGE8_BYTES + K8_BYTES;              /* V^T(t) */                               \
+    i32x8 fr[2];                                                                                                       \
+    fr[0] = frag_of(0, kbuf, vbuf);                                                                                    \
+    if (resc) {                        /* O of tiles < t was accumulated against the old running max */                \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) oacc[i_][r_] *= alpha; \
+      lacc[0] *= alpha;                                                                                                \
+      resc = false;                                                                                                    \
+    }                                                                                                                  \
+    LX8_FENCE();                                                                                                       \
+    LX8_GAP(0, S0, S1C, S1N, PAR) LX8_GAP(1, S0, S1C, S1N, PAR) LX8_GAP(2, S0, S1C, S1N, PAR) LX8_GAP(3, S0, S1C, S1N, PAR) \
+    if (t1.nvalid > 0 && t1.nvalid < KVBLK) {     /* ragged last tile of a segment: mask keys past its end (rare) */  \
+      LX8_FENCE();                                                                                                     \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                              \
+        const int key_ = 4 * lhi + 8 * (r_ >> 2) + (r_ & 3);                                                           \
+        if (key_ >= t1.nvalid) S0[r_] = -1e30f;                                                                        \
+        if (key_ + 32 >= t1.nvalid) S1N[r_] = -1e30f;                                                                  \
+      }                                                                                                                \
+    }                                                                                                                  \
+    LX8_FENCE();                                                                                                       \
+    LX8_GAP(4, S0, S1C, S1N, PAR) LX8_GAP(5, S0, S1C, S1N, PAR) LX8_GAP(6, S0, S1C, S1N, PAR) LX8_GAP(7, S0, S1C, S1N, PAR) \
+    {                                   /* row sums of the rounded probabilities of tile t */                          \
+      const i32x8 pf_ = {pfw[0], pfw[1], pfw[2], pfw[3], pfw[4], pfw[5], pfw[6], pfw[7]};                              \
+      lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones_frag, pf_, lacc, 0, 0, 0, 0, 0, 0);                  \
+      asm volatile("" : "+v"(lacc));                                                                                   \
+    }                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    LX8_FENCE(); __builtin_amdgcn_s_barrier(); LX8_FENCE();                                                            \
+    t0 = t1; t1 = t2;                                                                                                  \
+    gen_next();                                                                                                        \
+    t2 = g_cur;                                                                                                        \
+  }
+
+  if (t0.nvalid > 0) {
+    stage_k(t0, 0); stage_v(t0, 0); stage_k(t1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // prologue: scores, row max and reference of tile 0 (the running state is empty: no rescale)
+    {
+      const char* kb0 = smem;
+      s0 = qk(frag(kb0 + l31 * 128, 0 + lhi * 2, ksw), qf[0], zero16);
+      s0 = qk(frag(kb0 + l31 * 128, 4 + lhi * 2, ksw), qf[1], s0);
+      s1a = qk(frag(kb0 + (32 + l31) * 128, 0 + lhi * 2, ksw), qf[0], zero16);
+      s1a = qk(frag(kb0 + (32 + l31) * 128, 4 + lhi * 2, ksw), qf[1], s1a);
+      if (t0.nvalid < KVBLK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 4 * lhi + 8 * (r >> 2) + (r & 3);
+          if (key >= t0.nvalid) s0[r] = -1e30f;
+          if (key + 32 >= t0.nvalid) s1a[r] = -1e30f;
+        }
+      }
+      float tmax = fmaxf(s0[0], s1a[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s0[r]), s1a[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      if constexpr (POW2) {
+        m_run = tmax + t0.bl;                              // log2 units already
+        const float o0 = t0.bl - m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] += o0; s1a[r] += o0; }
+        const float o1 = t1.bl - m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) offv[r] = o1;
+      } else {
+        m_run = tmax * c2 + t0.bl;
+        off = t0.bl - m_run;
+      }
+    }
+    while (true) {
+      LX8_ITER(s0, s1a, s1b, 0);
+      if (t0.nvalid == 0) break;
+      LX8_ITER(s0, s1b, s1a, 1);
+      if (t0.nvalid == 0) break;
+    }
+  }
+#undef LX8_ITER
+#undef LX8_GAP
+#undef LX8_MM
+#undef LX8_MAX
+#undef LX8_MAX8
+#undef LX8_SOFT
+#undef LX8_FENCE
+
+  const float l_tot = __shfl(lacc[0], l31, 64);          // lanes 0-31 hold the sum of query l31
+  const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
+  if (q_valid) {
+    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 o;
+        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        *(u32x2*)(op + db * 32 + rq * 8) = o;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
@@ -821,7 +1160,19 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   }
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
-  if (defer) hipLaunchKernelGGL((lx_attn_fp8_kernel<true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
+  static const bool piped = [] { const char* e = getenv("LX_ATTN_FP8_PIPE"); return e ? atoi(e) != 0 : true; }();
+  static const bool pow2_ok = [] { const char* e = getenv("LX_ATTN_FP8_POW2"); return e ? atoi(e) != 0 : true; }();
+  if (piped) {
+    // softmax scale x log2(e) x operand descale an exact power of two 2^-k (ops.py chooses the q scale so)? Then the score MFMAs
+    // apply it as an MX block scale and the scores come out as exp2 arguments (lx_attn_fp8_pipe_kernel, POW2)
+    const double c2 = (double)d->scale * (double)qk_descale * 1.4426950408889634;
+    const int k = (int)lround(-log2(c2));
+    const bool pow2 = pow2_ok && defer && k >= 1 && k <= 60 && fabs(c2 * ldexp(1.0, k) - 1.0) < 1e-5;
+    hipStream_t st = (hipStream_t)stream;
+    if (pow2) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k);
+    else if (defer) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
+    else hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<false, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
+  } else if (defer) hipLaunchKernelGGL((lx_attn_fp8_kernel<true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
   else hipLaunchKernelGGL((lx_attn_fp8_kernel<false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
   LX_LAUNCH_CHECK("lx_attn_fwd_fp8");
   return LX_OK;

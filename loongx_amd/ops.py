@@ -302,7 +302,10 @@ def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_v
 
 # fp8 (e4m3) attention path: fixed operand scales. q and k are RMS-normalised (|x| <= sqrt(128) * |w|), so 16 keeps them inside
 # e4m3's normal range [2^-6, 448] with headroom; v is a raw projection output and is stored unscaled (clamped to +-448).
-FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE = 16.0, 16.0, 1.0
+# q scale: chosen so that (1/sqrt(128)) x log2(e) / (q scale x k scale) = 2^-11 exactly -- the attention kernel then applies the whole
+# factor as an MX block scale of its score MFMAs (attn.hip, lx_attn_fp8_pipe_kernel POW2); 16.32 instead of 16
+FP8_K_SCALE, FP8_V_SCALE = 16.0, 1.0
+FP8_Q_SCALE = 2048.0 * (1.0 / math.sqrt(128.0)) * 1.4426950408889634 / FP8_K_SCALE
 
 
 def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8, eps=1e-6) -> None:
