@@ -515,6 +515,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     LX_PG(0); LX_PG(1); LX_PG(2); LX_PG(3); LX_PG(4); LX_PG(5); LX_PG(6); LX_PG(7);
     LX_PG(8); LX_PG(9); LX_PG(10); LX_PG(11); LX_PG(12); LX_PG(13); LX_PG(14); LX_PG(15);
 #undef LX_PG
+    // Every wave must be done READING K(0) before any wave stages K(2) over it (gap 1 of the first iteration): without this
+    // barrier a wave that runs ~14 gaps behind its workgroup (it shares its SIMD with an older wave) could fetch fragments of tile 2
+    // for its tile-0 scores -- seen as run-to-run differences of single 32-row groups, ~1e-6 per workgroup, only under load
+    // (tools/det_block.py). The iterations themselves end in a barrier; the prologue did not.
+    LX_BARRIER();
     while (true) {
       LX_ITER(sA, sB);
       if (t0.nvalid == 0) break;
@@ -1054,6 +1059,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
         off = t0.bl - m_run;
       }
     }
+    // every wave is done reading K(0) before the first iteration stages K(2) over it (see lx_attn_pipe_kernel)
+    LX8_FENCE(); __builtin_amdgcn_s_barrier(); LX8_FENCE();
     while (true) {
       LX8_ITER(s0, s1a, s1b, 0);
       if (t0.nvalid == 0) break;

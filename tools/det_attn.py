@@ -1,0 +1,28 @@
+"""Run-to-run determinism of the attention kernels at a many-round shape (B x H x q-tiles >> CUs)."""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from loongx_amd import ops
+from tests.test_kernels_gpu import _qkv_buffer, _segments
+dev = "cuda"
+B, H = int(os.environ.get("DET_B", "16")), 24
+lens = (512, 1024, 1024); Dm = H * 128
+buf = _qkv_buffer(B, lens, H, seed=3)
+row0, vt0, vt_len = _segments(B, lens)
+VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=dev)
+ops.qkv_prep_segs(buf, 2 * Dm, 0, Dm, [(row0[i], lens[i], vt0[i], None, None, None, None) for i in range(3)], B, H, VT)
+O = torch.empty(buf.shape[0], Dm, dtype=torch.bfloat16, device=dev)
+def attn():
+    ops.attn_fwd(buf, buf, VT, O, q_col=2 * Dm, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
+    return O
+ref = attn().clone()
+bad = 0
+n = int(os.environ.get("DET_N", "300"))
+for i in range(n):
+    o = attn()
+    if not torch.equal(o, ref):
+        d = (o.float() - ref.float()).abs()
+        rows = (d.amax(-1) > 0).nonzero().flatten()
+        cols = (d.amax(0) > 0).nonzero().flatten()
+        bad += 1
+        print(f"  run {i}: {int((d > 0).sum())} elements differ, max {float(d.max()):.3e}; rows {rows[:3].tolist()}..{rows[-1].item()} ({len(rows)}), cols {cols[0].item()}..{cols[-1].item()} ({len(cols)})")
+print("attention mismatching runs:", bad, "of", n, {k: v for k, v in os.environ.items() if k.startswith(("LX_", "DET_"))})

@@ -33,6 +33,35 @@ for (M, N, K, resid) in ((2560, 3 * D, D, False), (2560, 7 * D, D, False), (2560
             C = torch.empty(M, N, dtype=torch.bfloat16, device=dev); ops.gemm([ops.gemm_desc(A, W, C, bias=bias)]); return C
     same(f"gemm M={M} N={N} K={K} resid={resid}", fn, n=40)
 
+# ---- projection GEMM with the LX_EPI_QKV epilogue (cross-wave sums through LDS, inline-asm table loads with counted vmcnt)
+for Bq in (1, 4):
+    Hq, Dq = 24, 3072
+    lens_q = (512, 1024, 1024)
+    Mq = Bq * sum(lens_q)
+    Aq = torch.randn(Mq, Dq, device=dev).to(torch.bfloat16)
+    Wq = (torch.randn(7 * Dq, Dq, device=dev) * 0.02).to(torch.bfloat16)
+    bq_ = torch.randn(7 * Dq, device=dev) * 0.1
+    wn = 1 + 0.1 * torch.randn(128, device=dev)
+    ropes = []
+    for L_ in lens_q:
+        ang = torch.rand(L_, 64, device=dev) * 6.28
+        cs = torch.empty(L_, 128, device=dev); cs[:, 0::2] = ang.cos(); cs[:, 1::2] = ang.sin()
+        ropes.append(cs)
+    r0, v0, r_, p_ = [], [], 0, 0
+    for L_ in lens_q:
+        r0.append(r_); v0.append(p_); r_ += Bq * L_; p_ += (L_ + 63) // 64 * 64
+    VTq = torch.zeros(Bq, Hq, 128, p_, dtype=torch.bfloat16, device=dev)
+    Cq = torch.zeros(Mq, 7 * Dq, dtype=torch.bfloat16, device=dev)
+    def fnq(Bq=Bq, Aq=Aq, Wq=Wq, bq_=bq_, Cq=Cq, VTq=VTq, r0=r0, v0=v0, ropes=ropes):
+        probs = []
+        for i, L_ in enumerate(lens_q):
+            rows = slice(r0[i], r0[i] + Bq * L_)
+            probs.append(ops.gemm_desc(Aq[rows], Wq, Cq[rows], bias=bq_, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, rows_per_batch=L_,
+                                       gelu_col_start=3 * Dq, qkv=dict(norm_q=wn, norm_k=wn, rope=ropes[i], vt=VTq, vt_pos0=v0[i], d=Dq)))
+        ops.gemm(probs)
+        return torch.cat([Cq.flatten().view(torch.int16).float(), VTq.flatten().view(torch.int16).float()])
+    same(f"gemm LX_EPI_QKV fused single-block projection B={Bq}", fnq, n=40)
+
 # ---- attention (bf16 pipelined, fp8) at the model shape
 B, H = 1, 24
 lens = (512, 1024, 1024); Dm = H * 128
