@@ -459,8 +459,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     off = bl - m_run;                                                                                                  \
     asm volatile("" : "+v"(off));                                                                                      \
   }
+  // the wait of gap g hands the fragment register on ("+v"): the MFMA that consumes it then depends on the WAIT, not only on the
+  // ds_read that was issued five gaps earlier -- otherwise nothing but luck keeps hipcc from hoisting the MFMA above its wait
+#define LX_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LX_GAP(g, SC, SN)                                                                                              \
-  LX_WAITL((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1));                                                         \
+  LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);                                       \
   LX_MM(g, SC, SN, false);                                                                                             \
   LX_RD((g) + LOOK, 32, false);                                                                                        \
   LX_MCHUNK(g, SC)                                                                                                     \
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     // prologue: scores of tile 0
     LX_WAITL(0);
     LX_RDP(0, 16, true); LX_RDP(1, 16, true); LX_RDP(2, 16, true); LX_RDP(3, 16, true); LX_RDP(4, 16, true); LX_RDP(5, 16, true);
-#define LX_PG(g) LX_WAITL((15 - (g)) < (LOOK - 1) ? (15 - (g)) : (LOOK - 1)); LX_MM(g, sA, sA, true); LX_RD((g) + LOOK, 16, true)
+#define LX_PG(g) LX_WAITR((15 - (g)) < (LOOK - 1) ? (15 - (g)) : (LOOK - 1), ring[(g) % LOOK]); LX_MM(g, sA, sA, true); LX_RD((g) + LOOK, 16, true)
     LX_PG(0); LX_PG(1); LX_PG(2); LX_PG(3); LX_PG(4); LX_PG(5); LX_PG(6); LX_PG(7);
     LX_PG(8); LX_PG(9); LX_PG(10); LX_PG(11); LX_PG(12); LX_PG(13); LX_PG(14); LX_PG(15);
 #undef LX_PG
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_RD
 #undef LX_RDP
 #undef LX_WAITL
+#undef LX_WAITR
 #undef LX_DSR
 #undef LX_BARRIER
 #undef LX_FENCE
