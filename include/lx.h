@@ -234,6 +234,9 @@ int lx_attn_fwd(const lx_attn_desc* d, void* stream);
  *            the 32x32x64 f8f6f4 MFMA's B operand wants (attn.hip, lx_attn_fp8_kernel).
  * lx_attn_fwd_fp8 takes the same descriptor as lx_attn_fwd with Q / K / VT pointing at those images (ldq, ldk, q_col, k_col,
  * vt_ld in bytes; O is bf16 as before) plus qk_descale = 1 / (q_scale * k_scale) and v_descale = 1 / v_scale.
+ * When scale * qk_descale * log2(e) is an exact power of two 2^-k (q_scale = 2^k * scale * log2(e) / k_scale: 16.32 for k = 11,
+ * k_scale = 16, the default scale 1/sqrt(128)) the kernel applies the whole factor as the MX block scale of its score MFMAs and
+ * takes exp2 of the scores as they come out of the matrix pipe; any other combination runs the generic path (one fma per score).
  * Softmax statistics and the output accumulators are fp32; P is rounded to e4m3.
  * ------------------------------------------------------------------------------------------------ */
 int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
