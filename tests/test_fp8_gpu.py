@@ -127,3 +127,53 @@ def test_engine_fp8_attention_vs_bf16_path_at_1024sq():
     for i in range(B):
         assert torch.equal(fwd(slice(i, i + 1), {"attn_fp8": True})[0], v8[i])
     assert torch.equal(ref, fwd(slice(None), {}))                        # switching back restores the bf16 path bit for bit
+
+
+@pytest.mark.parametrize("variant", ["pow2", "generic_scale", "plain_kernel", "no_pow2"])
+def test_fp8_attention_kernel_variants_agree(variant):
+    """The pipelined fp8 kernel's two score paths (MX-block-scaled MFMAs with exp2 straight on the result when scale x log2 e x
+    descale is a power of two -- the default, arranged by ops.FP8_Q_SCALE -- and the generic one-fma-per-score path taken for any
+    other softmax scale) and the plain kernel, each in its own process (the switches are read once), against fp32 SDPA."""
+    import os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env["LX_T_SCALE"] = "0.1" if variant == "generic_scale" else ""
+    if variant == "plain_kernel":
+        env["LX_ATTN_FP8_PIPE"] = "0"
+    if variant == "no_pow2":
+        env["LX_ATTN_FP8_POW2"] = "0"
+    code = r'''
+import os, sys, math, torch
+sys.path.insert(0, os.getcwd())
+from loongx_amd import ops
+from tests.test_kernels_gpu import _qkv_buffer, _segments
+from tests.helpers import relerr
+B, H, lens = 2, 2, (64, 200, 320)
+D = H * 128
+buf = _qkv_buffer(B, lens, H, seed=9)
+row0, vt0, vt_len = _segments(B, lens)
+M = buf.shape[0]
+Q8 = torch.zeros(M, D, dtype=torch.uint8, device="cuda"); K8 = torch.zeros_like(Q8)
+VT8 = torch.zeros(B, H, 128, vt_len, dtype=torch.uint8, device="cuda")
+ops.qkv_prep_fp8_segs(buf, 2 * D, 0, D, [(row0[s], lens[s], vt0[s], None, None, None, None) for s in range(3)], B, H, Q8, K8, VT8)
+O = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+sc = float(os.environ["LX_T_SCALE"]) if os.environ.get("LX_T_SCALE") else None
+ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, scale=sc)
+x = buf.float().cpu()
+def gather(col):
+    out = torch.zeros(B, sum(lens), H, 128); p = 0
+    for s, Ls in enumerate(lens):
+        out[:, p:p + Ls] = x[row0[s]: row0[s] + B * Ls, col: col + D].view(B, Ls, H, 128); p += Ls
+    return out.permute(0, 2, 1, 3)
+q, k, v = gather(2 * D), gather(0), gather(D)
+ref = torch.softmax((q @ k.transpose(-1, -2)) * (sc if sc else 1 / math.sqrt(128)), -1) @ v
+got = torch.zeros_like(ref); p = 0
+for s, Ls in enumerate(lens):
+    got[:, :, p:p + Ls] = O.float().cpu()[row0[s]: row0[s] + B * Ls].view(B, Ls, H, 128).permute(0, 2, 1, 3); p += Ls
+e = relerr(got, ref)
+print("RELERR", e)
+assert e < 7e-2, e
+'''
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "RELERR" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
