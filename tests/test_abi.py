@@ -44,3 +44,28 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.lx_gemm_bf16(ctypes.byref(d), 0, None) == -1
     assert b"out of range" in _lib.lib.lx_last_error()
     assert _lib.lib.lx_s4_scan(None, None, None, None, None, 1, 1, 100, 1, None) == -1
+
+
+def test_qkv_epilogue_and_attention_argument_validation_without_gpu():
+    """LX_EPI_QKV / n_qseg are validated on the host before anything is launched (fake, aligned addresses: nothing dereferences them)."""
+    from loongx_amd import _lib
+    d = _lib.GemmDesc()
+    d.A = d.W = d.C = d.bias = 0x10000
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = 96, 768, 64, 64, 64, 768
+    d.rows_per_batch = 48                                  # not a multiple of 32
+    d.epilogue = _lib.LX_EPI_STORE_BF16 | _lib.LX_EPI_QKV
+    d.qkv_norm_q = d.qkv_norm_k = d.qkv_rope = d.qkv_vt = 0x20000
+    d.qkv_d, d.qkv_vt_ld, d.qkv_vt_pos0 = 256, 64, 0
+    assert _lib.lib.lx_gemm_bf16(ctypes.byref(d), 1, None) == -1 and b"rows_per_batch" in _lib.lib.lx_last_error()
+    d.rows_per_batch = 96
+    d.qkv_d = 128                                          # heads must come in pairs (256-column tiles of one kind)
+    assert _lib.lib.lx_gemm_bf16(ctypes.byref(d), 1, None) == -1 and b"qkv_d" in _lib.lib.lx_last_error()
+    d.qkv_d, d.qkv_rope = 256, 0                           # the table is mandatory
+    assert _lib.lib.lx_gemm_bf16(ctypes.byref(d), 1, None) == -1 and b"qkv_rope" in _lib.lib.lx_last_error()
+    a = _lib.AttnDesc()
+    a.Q = a.K = a.VT = a.O = 0x10000
+    a.ldq = a.ldk = a.ldo = 768
+    a.vt_ld, a.B, a.H, a.n_seg = 64, 1, 2, 2
+    a.seg_len[0] = a.seg_len[1] = 32
+    a.n_qseg = 3                                           # more query segments than segments
+    assert _lib.lib.lx_attn_fwd(ctypes.byref(a), None) == -1 and b"n_qseg" in _lib.lib.lx_last_error()
