@@ -96,7 +96,7 @@ class DiTEngine:
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
-        self.TL_SPLIT = 4                                          # K-split slabs of the LoRA down-projection
+        self.TL_SPLIT = int(os.environ.get("LX_TL_SPLIT", "4"))         # K-split slabs of the LoRA down-projection (1/2/8 measured: no better)
         self.TLs = torch.zeros(self.TL_SPLIT, M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]
         self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
