@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32 attention)")
     ap.add_argument("--hw", type=int, default=32, help="packed latent grid side: 32 = 512x512 (the metric's config), 64 = 1024x1024 (configs[4])")
     ap.add_argument("--fp8", action="store_true", help="model_config attn_fp8 / gemm_fp8: the e4m3 MFMA paths of BASELINE configs[4]")
+    ap.add_argument("--attn-fp8", action="store_true", help="model_config attn_fp8 only: e4m3 attention, bf16 GEMMs (what north_star names for configs[4])")
+    ap.add_argument("--gemm-fp8", action="store_true", help="model_config gemm_fp8 only: e4m3 block GEMMs, bf16 attention")
     ap.add_argument("--independent-condition", action="store_true",
                     help="model_config independent_condition (block.py:115-120): the condition queries see only condition keys, so the "
                          "condition stream is step-invariant and the engine computes it once per image (not the metric's configuration)")
@@ -232,7 +234,12 @@ def main():
     if a.precise:
         mc["precise"] = True
     if a.fp8:
-        mc.update(attn_fp8=True, gemm_fp8=True)
+        a.attn_fp8 = a.gemm_fp8 = True
+    if a.attn_fp8:
+        mc["attn_fp8"] = True
+    if a.gemm_fp8:
+        mc["gemm_fp8"] = True
+    a.fp8 = a.gemm_fp8                 # which peak the GEMM roofline / end-to-end fraction is priced against
     if a.independent_condition:
         mc["independent_condition"] = True
     model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
@@ -293,11 +300,11 @@ def main():
         res = {"metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed_ms / a.steps, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16 x2 split (fp32-class)" if a.precise else ("fp8 e4m3 MFMA operands" if a.fp8 else "bf16"), "data": "synthetic",
+               "dtype": "bf16 x2 split (fp32-class)" if a.precise else ("fp8 e4m3 MFMA operands" if a.fp8 else ("bf16 GEMMs, fp8 e4m3 attention" if a.attn_fp8 else "bf16")), "data": "synthetic",
                "config": {"workload": (f"BASELINE configs[{1 if not allmod else (2 if B == 1 else 3)}]: " if hw == 32 and not a.fp8 else "BASELINE configs[4] shape: ") +
                                       ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
                                       f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, "
-                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 paths" if a.fp8 else "") +
+                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 GEMM + attention paths" if (a.fp8 and a.attn_fp8) else ", fp8 GEMM path" if a.fp8 else ", fp8 attention path" if a.attn_fp8 else "") +
                                       (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if a.independent_condition else ""),
                           "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
                           "rccl_ranks": world, "weight_broadcast_GB": round(moved / 1e9, 2), "weight_broadcast_s": round(t_bcast, 2),
@@ -335,8 +342,8 @@ def main():
                 res["roofline"]["frac_at_measured_clock"] = round(ach / pw_rec["mfma_peak_at_measured_clock_TFLOPs"], 4)
             if at:
                 aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                apeak = PEAK_FP8_TFLOPS if a.fp8 else (157.3 if a.precise else PEAK_BF16_TFLOPS)
-                aname = ("lx_attn_fp8_kernel (e4m3 32x32x64 MFMA)" if a.fp8 else "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if a.precise
+                apeak = PEAK_FP8_TFLOPS if a.attn_fp8 else (157.3 if a.precise else PEAK_BF16_TFLOPS)
+                aname = ("lx_attn_fp8_pipe_kernel (e4m3 32x32x64 MFMA)" if a.attn_fp8 else "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if a.precise
                          else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)")
                 res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
                                              "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
@@ -348,7 +355,7 @@ def main():
             del model, pw, batches, out
             torch.cuda.empty_cache()
             try:
-                res["parity"] = parity_check(a.precise, a.fp8, {"independent_condition": True} if a.independent_condition else None)
+                res["parity"] = parity_check(a.precise, False, {k: True for k in ("attn_fp8", "gemm_fp8", "independent_condition") if mc.get(k)})
             except Exception as e:          # the checker must never take the measurement down with it
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))

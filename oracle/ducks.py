@@ -155,3 +155,73 @@ def generate_transformer(seed: int = 4):
                                    pooled_dim=768, guidance_embeds=True, lora=True)
     fm.init_synthetic_(tr, seed=seed, std=0.03, bias_std=0.02, norm_jitter=0.1)
     return tr.eval()
+
+
+# ---- evaluator fixtures (reference test.py) ----------------------------------------------------------------------------
+def tiny_clip(path: str, seed: int = 0):
+    """A randomly initialised `transformers` CLIPModel + CLIPProcessor (byte-level vocabulary, 32-pixel images) saved to a local
+    directory: what the evaluator's CLIP-I / CLIP-T functions consume (the reference loads a local snapshot too, test.py:276-287)."""
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPConfig, CLIPImageProcessor, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPTokenizer, CLIPVisionConfig
+    alpha = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {}
+    for ch in alpha:
+        vocab[ch] = len(vocab)
+    for ch in alpha:
+        vocab[ch + "</w>"] = len(vocab)
+    for w in ("<|startoftext|>", "<|endoftext|>"):
+        vocab[w] = len(vocab)
+    tok = CLIPTokenizer(vocab=vocab, merges=[], model_max_length=77)
+    torch.manual_seed(seed)
+    eos = vocab["<|endoftext|>"]
+    cfg = CLIPConfig(text_config=CLIPTextConfig(vocab_size=len(vocab), hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                                max_position_embeddings=77, eos_token_id=eos, bos_token_id=vocab["<|startoftext|>"], pad_token_id=eos).to_dict(),
+                     vision_config=CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32,
+                                                    patch_size=8).to_dict(), projection_dim=16)
+    model = CLIPModel(cfg).eval()
+    model.save_pretrained(path)
+    CLIPProcessor(image_processor=CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32}), tokenizer=tok).save_pretrained(path)
+    return model
+
+
+def tiny_dino(seed: int = 0):
+    """Stand-in for the DINO ViT-S/16 backbone (torch.hub, needs the network): any module mapping [1,3,224,224] -> [1,F]."""
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 16, 16), torch.nn.Flatten(), torch.nn.Linear(4 * 14 * 14, 8)).eval()
+
+
+def evaluator_images(seed: int = 0):
+    """Synthetic (generated, ground-truth) pairs + captions in the L-Mind layout the reference's test.py walks: generated
+    `<name>_0.png`, ground truth `<name>_1.png` (test.py:241-249), JSONL records with target_image / instruction (test.py:172-178).
+    Sizes differ between the two sides (the evaluator resizes the generated image to the ground truth's size, test.py:31) and one
+    ground truth is non-square with an odd margin (the DINO centre crop's rounding). The caption list holds a decoy whose
+    target_image also ends with img1_1.png and comes first: the reference takes the first match."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    gen, gt = {}, {}
+    shapes = [(40, 48), (301, 263), (64, 64)]
+    for i, (h, w) in enumerate(shapes):
+        a = (rng.random((h, w, 3)) * 255).astype("uint8")
+        gt[f"img{i}_1.png"] = a
+        b = np.clip(a.astype(int) + rng.integers(-30, 30, a.shape), 0, 255).astype("uint8")
+        gen[f"img{i}_0.png"] = b[: max(32, h // 2), : max(32, w // 2)].copy()
+    gen["orphan_0.png"] = gen["img0_0.png"]          # no ground truth: must be skipped
+    caps = [{"source_image": "x/ximg1_0.png", "target_image": "y/ximg1_1.png", "instruction": "decoy: turn it green"}]
+    caps += [{"source_image": f"x/img{i}_0.png", "target_image": f"y/img{i}_1.png", "instruction": f"make it {['red', 'blue', 'a cat'][i]}"} for i in range(3)]
+    return gen, gt, caps
+
+
+def write_evaluator_dirs(root: str, gen, gt, caps):
+    import json
+    import os
+    from PIL import Image
+    gdir, tdir = os.path.join(root, "gen"), os.path.join(root, "gt")
+    os.makedirs(gdir, exist_ok=True); os.makedirs(tdir, exist_ok=True)
+    for n, a in gen.items():
+        Image.fromarray(a).save(os.path.join(gdir, n))
+    for n, a in gt.items():
+        Image.fromarray(a).save(os.path.join(tdir, n))
+    cap = os.path.join(root, "caps.jsonl")
+    with open(cap, "w") as f:
+        f.write("\n".join(json.dumps(c) for c in caps))
+    return gdir, tdir, cap
