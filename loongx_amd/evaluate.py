@@ -21,12 +21,13 @@ def to_tensor(img: Image.Image) -> torch.Tensor:
 
 
 def dino_preprocess(img: Image.Image) -> torch.Tensor:
-    """Resize(256, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet) (test.py:289-294)."""
+    """Resize(256, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet) (test.py:293-298), with torchvision's rounding:
+    the longer edge becomes int(256 * long / short), the crop starts at int(round((edge - 224) / 2.0))."""
     w, h = img.size
-    s = 256 / min(w, h)
-    img = img.resize((max(256, round(w * s)), max(256, round(h * s))), resample=Image.BICUBIC)
+    nw, nh = (256, int(256 * h / w)) if w <= h else (int(256 * w / h), 256)
+    img = img.resize((nw, nh), resample=Image.BICUBIC)
     w, h = img.size
-    l, t = (w - 224) // 2, (h - 224) // 2
+    l, t = int(round((w - 224) / 2.0)), int(round((h - 224) / 2.0))
     x = to_tensor(img.crop((l, t, l + 224, t + 224)))
     mean, std = torch.tensor([0.485, 0.456, 0.406])[:, None, None], torch.tensor([0.229, 0.224, 0.225])[:, None, None]
     return (x - mean) / std

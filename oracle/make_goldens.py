@@ -37,8 +37,10 @@ from oracle import s4 as os4  # noqa: E402
 
 
 def _ns(name, **members):
+    import importlib.machinery
     m = types.ModuleType(name)
     m.__dict__.update(members)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)      # transformers probes find_spec() of optional packages
     sys.modules[name] = m
     return m
 
@@ -349,12 +351,158 @@ def gold_generate():
     print("generate_tiny.npz", len(out), "arrays")
 
 
+def _install_eval_stubs():
+    """torchvision / clip are not installed: the reference's test.py imports them at module level. ToTensor / Compose / Resize /
+    CenterCrop / Normalize are restated with torchvision's semantics (Resize: shorter edge -> size, longer edge int(size * long /
+    short); CenterCrop: top = int(round((h - size) / 2.0))); `clip` is imported by test.py but never used."""
+    from PIL import Image
+
+    class ToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Resize:
+        def __init__(self, size, interpolation=2):
+            self.size, self.interp = size, interpolation
+
+        def __call__(self, img):
+            w, h = img.size
+            short, long = (w, h) if w <= h else (h, w)
+            ns, nl = self.size, int(self.size * long / short)
+            nw, nh = (ns, nl) if w <= h else (nl, ns)
+            return img.resize((nw, nh), resample={2: Image.BILINEAR, 3: Image.BICUBIC}[self.interp])
+
+    class CenterCrop:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            w, h = img.size
+            t, l = int(round((h - self.size) / 2.0)), int(round((w - self.size) / 2.0))
+            return img.crop((l, t, l + self.size, t + self.size))
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m, self.s = torch.tensor(mean)[:, None, None], torch.tensor(std)[:, None, None]
+
+        def __call__(self, x):
+            return (x - self.m) / self.s
+
+    from transformers import CLIPModel, CLIPProcessor  # noqa: F401  (resolve transformers' lazy imports before torchvision is stubbed)
+    tv = _ns("torchvision")
+    tt = _ns("torchvision.transforms.transforms", ToTensor=ToTensor, Compose=Compose, Resize=Resize, CenterCrop=CenterCrop, Normalize=Normalize)
+    tr = _ns("torchvision.transforms", transforms=tt)
+    tr.functional = _ns("torchvision.transforms.functional")
+    tv.transforms = tr
+    _ns("clip")
+    return tt
+
+
+def gold_evaluate():
+    """The reference's evaluator (test.py:17-214 functions, :241-249 pairing, :321-336 result files) on a synthetic image set:
+    L1 / L2, CLIP-I, CLIP-T (incl. the caption lookup) with a tiny seeded CLIP, DINO with a stand-in backbone, and main() with
+    --metric l1,l2. The fixture holds the images, captions, model weights and the reference's outputs."""
+    import contextlib
+    import importlib.util
+    import io
+    import json
+    import tempfile
+    import types as _t
+    from oracle import ducks
+    tt = _install_eval_stubs()
+    spec = importlib.util.spec_from_file_location("ref_test", os.path.join(REF, "test.py"))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    rt.tqdm = lambda x: x
+    gen, gt, caps = ducks.evaluator_images()
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        gdir, tdir, cap = ducks.write_evaluator_dirs(d, gen, gt, caps)
+        from transformers import CLIPModel, CLIPProcessor
+        clip_dir = os.path.join(d, "clip")
+        ducks.tiny_clip(clip_dir)
+        model5, proc = CLIPModel.from_pretrained(clip_dir).eval(), CLIPProcessor.from_pretrained(clip_dir)
+
+        class Clip4x:
+            """The reference is written against transformers 4.x, where get_image_features / get_text_features return the
+            projected feature TENSOR; the installed 5.x returns a model output whose .pooler_output is that tensor (checked:
+            == visual_projection(vision_model(x).pooler_output)). Present the 4.x surface to the reference's functions."""
+            def get_image_features(self, pixel_values):
+                return model5.get_image_features(pixel_values).pooler_output
+
+            def get_text_features(self, input_ids):
+                return model5.get_text_features(input_ids).pooler_output
+
+            def state_dict(self):
+                return model5.state_dict()
+        model = Clip4x()
+        dino = ducks.tiny_dino()
+        # the pairing rule of main() (test.py:241-249)
+        pairs = []
+        for name in sorted(os.listdir(gdir)):
+            if name.endswith((".png", ".jpg")):
+                g = os.path.join(tdir, name.replace("_0", "_1"))
+                if os.path.exists(g):
+                    pairs.append((os.path.join(gdir, name), g))
+        args = _t.SimpleNamespace(device=torch.device("cpu"))
+        names = [os.path.basename(p[0]) for p in pairs]
+        for m in ("l1", "l2"):
+            s, res = rt.eval_distance(pairs, m)
+            out[f"{m}_mean"], out[f"{m}_per_image"] = s, [res[n][m] for n in names]
+        s, res = rt.eval_clip_i(args, pairs, model, proc)
+        out["clip_i_mean"], out["clip_i_per_image"] = s, [res[n]["clip_i"] for n in names]
+        dproc = tt.Compose([tt.Resize(256, interpolation=3), tt.CenterCrop(224), tt.ToTensor(),
+                            tt.Normalize((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))])          # test.py:293-298
+        s, res = rt.eval_dino_i(args, pairs, dino, dproc, metric="dino")
+        out["dino_mean"], out["dino_per_image"] = s, [res[n]["dino"] for n in names]
+        g_t, t_t, res = rt.eval_clip_t(args, pairs, model, proc, caps)
+        out["clip_t_gen"], out["clip_t_gt"], out["clip_t_per_image"] = g_t, t_t, [res[n]["clip-t"] for n in names]
+        # main() end to end with the metrics that need no external weights: pairing + result files
+        save = os.path.join(d, "res")
+        argv = sys.argv
+        sys.argv = ["test.py", "--device", "cpu", "--caption_path", cap, "--generated_path", gdir, "--gt_path", tdir, "--metric", "l1,l2", "--save_path", save]
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                rt.main()
+        finally:
+            sys.argv = argv
+        files = sorted(os.listdir(save))
+        metrics_txt = open(os.path.join(save, "evaluation_metrics.txt")).read()
+        csv_txt = open(os.path.join(save, "per_image_metrics.csv")).read()
+        sd = {k: t2n(v) for k, v in model.state_dict().items()}
+        dsd = {k: t2n(v) for k, v in dino.state_dict().items()}
+    arrays = {k: np.asarray(v, dtype=np.float64) for k, v in out.items()}
+    arrays["pair_names"] = np.array(names)
+    arrays["result_files"] = np.array(files)
+    arrays["metrics_txt"], arrays["csv_txt"] = np.array(metrics_txt), np.array(csv_txt)
+    arrays["captions_json"] = np.array(json.dumps(caps))
+    for n, a in gen.items():
+        arrays["gen/" + n] = a
+    for n, a in gt.items():
+        arrays["gt/" + n] = a
+    for k, v in sd.items():
+        arrays["clip/" + k] = v
+    for k, v in dsd.items():
+        arrays["dino/" + k] = v
+    np.savez_compressed(os.path.join(OUT, "evaluate.npz"), **arrays)
+    print("evaluate.npz", len(arrays), "arrays;", {k: float(np.round(v, 6)) for k, v in out.items() if np.ndim(v) == 0})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"{REF} not found: goldens can only be regenerated in the build container"
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (gold_flux, gold_cs3, gold_encoders, gold_eeg_encoder, gold_condition, gold_generate):
+    for fn in (gold_flux, gold_cs3, gold_encoders, gold_eeg_encoder, gold_condition, gold_generate, gold_evaluate):
         if not only or fn.__name__ in only:
             fn()

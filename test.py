@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Evaluation CLI of the reference (test.py:215-end): L1 / L2 / CLIP-I / DINO / CLIP-T over a directory of generated images against
-the ground truth, results to <save_path>/evaluation_metrics.txt and per_image_results.csv. Same flags; the CLIP snapshot (and an
+the ground truth, results to <save_path>/evaluation_metrics.txt and per_image_metrics.csv (test.py:321-336). Same flags; the CLIP snapshot (and an
 optional TorchScript / torch.save'd DINO backbone) come from LOCAL paths: --clip_path, --dino_path."""
 import argparse
 import json
@@ -74,7 +74,9 @@ def main(argv=None):
         for k, v in out.items():
             f.write(f"{k}: {v}\n")
     import pandas as pd
-    pd.DataFrame.from_dict(per_image, orient="index").to_csv(os.path.join(args.save_path, "per_image_results.csv"))
+    df = pd.DataFrame.from_dict(per_image, orient="index")
+    df.index.name = "image_name"
+    df.to_csv(os.path.join(args.save_path, "per_image_metrics.csv"))
     return out
 
 

@@ -46,25 +46,8 @@ def test_l1_l2_match_numpy(data):
 
 
 def _tiny_clip(path):
-    from tokenizers import pre_tokenizers
-    from transformers import CLIPConfig, CLIPImageProcessor, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPTokenizer, CLIPVisionConfig
-    alpha = sorted(pre_tokenizers.ByteLevel.alphabet())
-    vocab = {}
-    for ch in alpha:
-        vocab[ch] = len(vocab)
-    for ch in alpha:
-        vocab[ch + "</w>"] = len(vocab)
-    for w in ("<|startoftext|>", "<|endoftext|>"):
-        vocab[w] = len(vocab)
-    tok = CLIPTokenizer(vocab=vocab, merges=[], model_max_length=77)
-    torch.manual_seed(0)
-    eos = vocab["<|endoftext|>"]
-    cfg = CLIPConfig(text_config=CLIPTextConfig(vocab_size=len(vocab), hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
-                                                max_position_embeddings=77, eos_token_id=eos, bos_token_id=vocab["<|startoftext|>"], pad_token_id=eos).to_dict(),
-                     vision_config=CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32,
-                                                    patch_size=8).to_dict(), projection_dim=16)
-    CLIPModel(cfg).eval().save_pretrained(path)
-    CLIPProcessor(image_processor=CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32}), tokenizer=tok).save_pretrained(path)
+    from oracle.ducks import tiny_clip
+    tiny_clip(path)
 
 
 def test_clip_and_dino_metrics_and_cli(data, tmp_path):
@@ -82,7 +65,7 @@ def test_clip_and_dino_metrics_and_cli(data, tmp_path):
     txt = (tmp_path / "res" / "evaluation_metrics.txt").read_text()
     assert "clip-i:" in txt and "clip-t_gt:" in txt
     import pandas as pd
-    df = pd.read_csv(tmp_path / "res" / "per_image_results.csv", index_col=0)
+    df = pd.read_csv(tmp_path / "res" / "per_image_metrics.csv", index_col=0)
     assert set(df.columns) >= {"l1", "l2", "clip_i", "dino", "clip-t"} and len(df) == 3
     # identical images score 1 on the feature metrics and 0 on the distances
     from loongx_amd.evaluate import eval_clip_i, eval_distance
@@ -91,3 +74,56 @@ def test_clip_and_dino_metrics_and_cli(data, tmp_path):
     import types
     s, _ = eval_clip_i(types.SimpleNamespace(device=torch.device("cpu")), same, CLIPModel.from_pretrained(clip_dir).eval(), CLIPProcessor.from_pretrained(clip_dir))
     assert abs(s - 1.0) < 1e-5 and eval_distance(same, "l1")[0] == 0.0
+
+
+def test_evaluator_matches_the_reference_golden(tmp_path, golden_dir):
+    """tests/golden/evaluate.npz: the REFERENCE's own test.py functions (eval_distance, eval_clip_i, eval_dino_i, eval_clip_t, and
+    main() with --metric l1,l2) run by oracle/make_goldens.py on a synthetic image set -- images, captions (with a decoy entry that
+    matches first), the tiny CLIP / DINO weights and the reference's outputs are all in the fixture."""
+    import io
+    import types
+
+    import pandas as pd
+    from transformers import CLIPModel, CLIPProcessor
+
+    import test as evalcli
+    from loongx_amd.evaluate import collect_pairs, eval_clip_i, eval_clip_t, eval_dino_i, eval_distance
+    from oracle import ducks
+    z = np.load(os.path.join(golden_dir, "evaluate.npz"))
+    gen = {k[4:]: z[k] for k in z.files if k.startswith("gen/")}
+    gt = {k[3:]: z[k] for k in z.files if k.startswith("gt/")}
+    caps = json.loads(str(z["captions_json"]))
+    gdir, tdir, cap = ducks.write_evaluator_dirs(str(tmp_path), gen, gt, caps)
+    pairs = collect_pairs(gdir, tdir)
+    names = [os.path.basename(p[0]) for p in pairs]
+    assert names == [str(n) for n in z["pair_names"]]                      # `_0` -> `_1` pairing; the orphan is skipped
+    clip_dir = str(tmp_path / "clip")
+    ducks.tiny_clip(clip_dir, seed=123)                                    # architecture / tokenizer files; the weights come from the fixture
+    model, proc = CLIPModel.from_pretrained(clip_dir).eval(), CLIPProcessor.from_pretrained(clip_dir)
+    model.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("clip/")})
+    dino = ducks.tiny_dino(seed=9)
+    dino.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("dino/")})
+    args = types.SimpleNamespace(device=torch.device("cpu"))
+    tol = 2e-6
+    for m in ("l1", "l2"):
+        s, res = eval_distance(pairs, m)
+        assert abs(s - float(z[f"{m}_mean"])) < tol
+        assert np.allclose([res[n][m] for n in names], z[f"{m}_per_image"], atol=tol, rtol=0)
+    s, res = eval_clip_i(args, pairs, model, proc)
+    assert abs(s - float(z["clip_i_mean"])) < tol and np.allclose([res[n]["clip_i"] for n in names], z["clip_i_per_image"], atol=tol, rtol=0)
+    s, res = eval_dino_i(args, pairs, dino)
+    assert abs(s - float(z["dino_mean"])) < tol and np.allclose([res[n]["dino"] for n in names], z["dino_per_image"], atol=tol, rtol=0)
+    g, t, res = eval_clip_t(args, pairs, model, proc, caps)
+    assert abs(g - float(z["clip_t_gen"])) < tol and abs(t - float(z["clip_t_gt"])) < tol
+    assert np.allclose([res[n]["clip-t"] for n in names], z["clip_t_per_image"], atol=tol, rtol=0)
+    # the CLI against the reference's main(): same result files, same numbers
+    save = str(tmp_path / "res")
+    evalcli.main(["--device", "cpu", "--caption_path", cap, "--generated_path", gdir, "--gt_path", tdir, "--metric", "l1,l2", "--save_path", save])
+    assert sorted(os.listdir(save)) == [str(f) for f in z["result_files"]]
+    want = dict(l.split(": ") for l in str(z["metrics_txt"]).strip().splitlines())
+    have = dict(l.split(": ") for l in open(os.path.join(save, "evaluation_metrics.txt")).read().strip().splitlines())
+    assert list(have) == list(want) and all(abs(float(have[k]) - float(want[k])) < tol for k in want)
+    wdf = pd.read_csv(io.StringIO(str(z["csv_txt"])), index_col=0).sort_index()
+    hdf = pd.read_csv(os.path.join(save, "per_image_metrics.csv"), index_col=0).sort_index()
+    assert wdf.index.name == hdf.index.name == "image_name" and list(wdf.columns) == list(hdf.columns) and list(wdf.index) == list(hdf.index)
+    assert np.allclose(wdf.values, hdf.values, atol=tol, rtol=0)

@@ -49,7 +49,7 @@ def test_reference_style_construction_and_checkpoint_load(ckpt):
     assert m32.transformer.engine.precise_default and m32.transformer.engine.w.precise_ready
 
 
-def test_inference_single_image_pil_to_pil_matches_oracle_chain(ckpt, monkeypatch):
+def test_inference_single_image_pil_to_pil_matches_oracle_chain(ckpt, monkeypatch, tmp_path):
     import inference as inf
     from loongx_amd import vae as lxvae
     from oracle import vae as ovae
@@ -85,6 +85,26 @@ def test_inference_single_image_pil_to_pil_matches_oracle_chain(ckpt, monkeypatc
     want = (img / 2 + 0.5).clamp(0, 1)[0].permute(1, 2, 0).numpy()
     got = np.asarray(out).astype(np.float32) / 255.0
     assert np.abs(got - want).mean() < 0.02, float(np.abs(got - want).mean())          # 8-bit pixels, bf16 VAE + DiT vs fp32
+    # the evaluator (reference test.py; loongx_amd/evaluate.py, pinned to the reference by tests/golden/evaluate.npz) scores the
+    # product's image against the oracle chain's image: the `_0` / `_1` pairing, L1 / L2, CLIP-I with a tiny CLIP on the GPU
+    import types
+    from PIL import Image
+    from transformers import CLIPModel, CLIPProcessor
+    from loongx_amd.evaluate import collect_pairs, eval_clip_i, eval_distance
+    from oracle import ducks
+    gdir, tdir = tmp_path / "generated", tmp_path / "gt"
+    gdir.mkdir(); tdir.mkdir()
+    out.save(gdir / "edit_0.png")
+    Image.fromarray((want * 255.0).round().astype("uint8")).save(tdir / "edit_1.png")
+    pairs = collect_pairs(str(gdir), str(tdir))
+    assert len(pairs) == 1
+    l1, _ = eval_distance(pairs, "l1")
+    l2, _ = eval_distance(pairs, "l2")
+    assert l1 < 0.02 and l2 < 0.02 ** 2 * 4, (l1, l2)
+    ducks.tiny_clip(str(tmp_path / "clip"))
+    clip = CLIPModel.from_pretrained(str(tmp_path / "clip")).eval().cuda()
+    ci, _ = eval_clip_i(types.SimpleNamespace(device=torch.device("cuda")), pairs, clip, CLIPProcessor.from_pretrained(str(tmp_path / "clip")))
+    assert ci > 0.99, ci
     # prompt strings reach the model: a different prompt gives a different image
     other = inf.inference_single_image(model, cimg, "a blue cat", condition_type="subject", position_delta=[0, -4], target_size=size,
                                        seed=1, latents=lat0.cuda(), num_inference_steps=steps)
