@@ -242,7 +242,7 @@ def main():
     a.fp8 = a.gemm_fp8                 # which peak the GEMM roofline / end-to-end fraction is priced against
     if a.independent_condition:
         mc["independent_condition"] = True
-    model = OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
+    model = OminiModel.from_pipe(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
 
     B, hw = a.batch, a.hw
     N = hw * hw

@@ -170,7 +170,11 @@ def process_shard(rank, world_size, model, n_items, args, device):
     for idx in range(start, end):
         item = synthetic_item(idx, args.target_size, device, args.seed)
         lat = inference_single(model, item, args.condition_type, [args.position_delta_x, args.position_delta_y], args.target_size)
-        torch.save(lat.cpu(), os.path.join(args.output_dir, item["name"] + ".latent.pt"))
+        host = lat.cpu()                                             # drains the stream
+        eng = getattr(getattr(model, "transformer", None), "engine", None)
+        if eng is not None:
+            eng.check_status(sync=True)                              # a split-K pair time-out invalidates this image: raise before it is saved
+        torch.save(host, os.path.join(args.output_dir, item["name"] + ".latent.pt"))
         if rank == 0 and (idx - start) % 10 == 0:
             print(f"Process {rank}: completed {idx - start + 1}/{end - start} images")
     torch.cuda.synchronize()

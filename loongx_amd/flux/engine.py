@@ -97,7 +97,10 @@ class DiTEngine:
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
         self.TL_SPLIT = int(os.environ.get("LX_TL_SPLIT", "4"))         # K-split slabs of the LoRA down-projection (1/2/8 measured: no better)
-        self.TLs = torch.zeros(self.TL_SPLIT, M, 16, dtype=f32, device=dev)
+        if self.TL_SPLIT < 1:
+            raise ValueError(f"LX_TL_SPLIT={self.TL_SPLIT}: need at least one slab")
+        # precise mode writes one slab per cross term (up to 3: hi.A, lo.A, hi.A_lo) whatever the K-split of the bf16 path is
+        self.TLs = torch.zeros(max(self.TL_SPLIT, 3), M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]
         self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
         self.out = torch.zeros(B * N, cfg.in_channels, dtype=f32, device=dev)
@@ -708,7 +711,7 @@ class DiTEngine:
     def _lora_t8(self, X8: torch.Tensor, act_scale: float, name: str, include_txt: bool = False):
         """LoRA down-projection from an e4m3 operand image (the MLP hidden / [attn | mlp] exist only as fp8 in this mode)."""
         lo = self.w.lora.get(name)
-        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0:
+        if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0 or self._lora_rows(include_txt) is None:
             return None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
@@ -836,7 +839,8 @@ class DiTEngine:
         row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
         if lora_done is not None:
             lo, ns, lr0 = lora_done
-        elif (self.C == 0 and not self.latent_lora) or (only is not None and "cond" not in only and not self.latent_lora):
+        elif ((self.C == 0 and not self.latent_lora) or (only is not None and "cond" not in only and not self.latent_lora)
+              or self._lora_rows(txt is None) is None):
             lo, ns, lr0 = None, 0, 0
         else:
             lr0, n = self._lora_rows(txt is None)
@@ -1058,6 +1062,7 @@ class DiTEngine:
     # (used by the reference-API mirrors in block.py: same arithmetic as forward(), driven one block at a time)
     def load_streams(self, enc: Optional[torch.Tensor], hid: torch.Tensor, cond: Optional[torch.Tensor], dst: str = "X") -> None:
         """Copy [B,L,D] per-stream tensors into the stream-major rows of X (fp32) or XN (bf16)."""
+        self.block_level_entry()
         buf = self.X if dst == "X" else self.XN
         for s, t in (("txt", enc), ("img", hid), ("cond", cond)):
             if t is not None:
@@ -1069,6 +1074,11 @@ class DiTEngine:
         if cols is not None:
             r = r[:, cols]
         return r.float().reshape(self.B, L, -1).clone()
+
+    def block_level_entry(self) -> None:
+        """Block-level calls (the reference-API mirrors in block.py) compute all three streams every time: whatever a previous
+        forward() left in the per-layer condition cache must not be read, and no row may be skipped."""
+        self.cond_cache = self.cond_cached = self.cond_skip = False
 
     def block_mods(self, kind: str, idx: int, temb: torch.Tensor, cond_temb: Optional[torch.Tensor]) -> None:
         """Modulation vectors of ONE block from explicit temb / cond_temb (block.py:191-207, 301-305)."""
@@ -1117,6 +1127,7 @@ class DiTEngine:
         """attn_forward (block.py:7-176) on the normalised activations already in XN: QKV projections, QK-RMSNorm,
         RoPE, joint attention; double blocks also apply to_out / to_add_out into X (plain store)."""
         cfg, w, D = self.cfg, self.w, self.cfg.inner_dim
+        self.block_level_entry()
         if kind == "double":
             p = f"d{idx}"
             self._gemm_streams(self.XN, self.Y[:, : 3 * D], p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16,

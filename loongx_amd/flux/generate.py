@@ -207,6 +207,10 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
         if self.vae is None or self.image_processor is None:
             raise NotImplementedError("decoding to pixels needs a VAE (outside the MI355X hot path): use output_type='latent' "
                                       "or construct LxFluxPipeline(vae=..., image_processor=...)")
+        if hasattr(pipeline.transformer, "engine"):
+            # a split-K pair time-out invalidates this image's latents: find out BEFORE it is decoded and handed back (the decode
+            # drains the stream anyway, so the synchronous check costs one 4-byte read)
+            pipeline.transformer.engine.check_status(sync=True)
         z = self._unpack_latents(latents, height, width, self.vae_scale_factor)
         z = (z / self.vae.config.scaling_factor) + self.vae.config.shift_factor
         image = self.vae.decode(z, return_dict=False)[0]
@@ -216,7 +220,11 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
         pipeline.transformer.c_factor = None
     if hasattr(pipeline.transformer, "invalidate_conditioning"):
         pipeline.transformer.invalidate_conditioning()
-        pipeline.transformer.engine.check_status(sync=False)      # split-K pair time-outs surface here, at most one image late
+        if output_type == "latent":
+            # latents stay on the device and the host runs ahead: no synchronisation here. A pair time-out surfaces at the next
+            # image's check; callers that keep latents must call engine.check_status() once at the end of their loop
+            # (inference.py does, per shard)
+            pipeline.transformer.engine.check_status(sync=False)
     if not return_dict:
         return (image,)
     return FluxPipelineOutput(images=image)

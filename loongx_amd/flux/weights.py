@@ -326,8 +326,11 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
             ranks[m] = q[0].shape[0]
         groups[fname] = len(names)
         n += len(parts)
-        new_lora[fname] = Lora(torch.cat([q[0] for q in parts], 0).to(device=dev, dtype=torch.bfloat16).contiguous(),
-                               torch.cat([q[1] for q in parts], 0).to(device=dev, dtype=torch.float32).contiguous())
+        # a model packed for precise mode keeps the adapters' bf16 rounding residuals too (as pack_state_dict does), so the
+        # same checkpoint gives the same precise-mode numerics whichever way it was loaded
+        down, down_lo = _hi_lo(torch.cat([q[0] for q in parts], 0).to(dev))
+        new_lora[fname] = Lora(down, torch.cat([q[1] for q in parts], 0).to(device=dev, dtype=torch.float32).contiguous(),
+                               down_lo if pw.precise_ready else None)
     mparts = [get(m) for m in mods]
     new_t = {}
     if any(q is not None for q in mparts):
@@ -336,7 +339,9 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
         n += len(mparts)
         for m, q in zip(mods, mparts):
             ranks[m] = q[0].shape[0]
-        new_t["mod.lora_down"] = torch.cat([q[0] for q in mparts], 0).to(device=dev, dtype=torch.bfloat16).contiguous()
+        new_t["mod.lora_down"], dlo = _hi_lo(torch.cat([q[0] for q in mparts], 0).to(dev))
+        if pw.precise_ready and dlo is not None:
+            new_t["mod.lora_down_lo"] = dlo
         for idx, q in enumerate(mparts):
             new_t[f"mod.lora_up.{idx}"] = q[1].to(dev).contiguous()
     unknown = [k for k in sd if k not in used and ".lora_" in k]

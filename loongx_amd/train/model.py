@@ -379,19 +379,21 @@ class OminiModel(CS3DGF):
     (inference.py:46-53: keys `transformer.<diffusers names, optionally PEFT-wrapped>` + `eeg_projection.*`, `fusion1.*`,
     `duan_norm1.*` ...). `dtype=torch.float32` (the reference's shipped config, train/config/seed_512.yaml:2) selects the
     engine's precise mode; bfloat16 the bf16 MFMA mode. `lora_config` supplies the adapter scale alpha / r.
-    (An `LxFluxPipeline` object and a state dict may also be passed positionally -- the form the tests and bench.py use.)"""
+    `OminiModel.from_pipe(pipe, cs3_state_dict, model_config, device)` wraps an existing `LxFluxPipeline` and a CS3 / DGF state
+    dict (the form the tests and bench.py use).
+
+    Brain-side modules: the reference's constructor creates them randomly initialised (model.py:430-462) and a '*lora*' checkpoint
+    (inference.py:43-44 -> load_lora) never fills them. Here they are built by `load_state_dict` / `from_pipe`; when neither has
+    run, the first access builds them from a seeded random state dict with a warning (the reference-equivalent state), instead of
+    failing with an AttributeError in the middle of generate()."""
 
     def __init__(self, flux_pipe_id=None, lora_path=None, lora_config: Optional[dict] = None, device="cuda",
                  dtype: torch.dtype = torch.bfloat16, model_config: Optional[dict] = None, optimizer_config: Optional[dict] = None,
                  gradient_checkpointing: bool = False, use_brain_condition: bool = True, fuse_flag: bool = True, *,
                  flux_config=None):
-        # back-compatible positional form: OminiModel(flux_pipe, cs3_state_dict, model_config, device)
-        pipe_obj = flux_pipe_id if hasattr(flux_pipe_id, "transformer") else None
-        cs3_sd = lora_path if isinstance(lora_path, dict) else None
-        if pipe_obj is not None:
-            if isinstance(lora_config, dict) and model_config is None and "r" not in lora_config and "lora_alpha" not in lora_config:
-                model_config, lora_config = lora_config, None
-            lora_path = None
+        if hasattr(flux_pipe_id, "transformer") or isinstance(lora_path, dict):
+            raise TypeError("OminiModel(flux_pipe_id=<directory>, lora_path=<directory>, ...) takes the reference's arguments; to wrap an existing "
+                            "pipeline object and a CS3 / DGF state dict use OminiModel.from_pipe(pipe, cs3_state_dict, model_config, device)")
         self.device = torch.device(device if not (device == "cuda" and not torch.cuda.is_available()) else "cpu")
         self._dtype = dtype
         self.precise = dtype == torch.float32
@@ -404,16 +406,39 @@ class OminiModel(CS3DGF):
         self.flux_config = flux_config
         self.flux_pipe = self.transformer = None
         self._brain_ready = False
-        if pipe_obj is not None:
-            self._set_pipe(pipe_obj)
-        elif flux_pipe_id not in (None, "", "synthetic"):
+        self._brain_seed = 0
+        if flux_pipe_id not in (None, "", "synthetic"):
             from ..flux.pipeline import LxFluxPipeline
             self._set_pipe(LxFluxPipeline.from_pretrained(flux_pipe_id, device=self.device, dtype=dtype, flux_config=flux_config,
                                                           lora_scale=self.lora_scale))
-        if cs3_sd is not None:
-            self._build_brain(cs3_sd)
         if isinstance(lora_path, str) and lora_path:
             self.load_lora(lora_path)
+
+    _BRAIN_ATTRS = frozenset(("eeg_projection", "ppg_projection", "fnirs_projection", "motion_projection", "fusion1", "fusion2", "fusion3",
+                              "fusion4", "duan_norm1", "duan_norm2", "duan_norm_prompt", "duan_norm_pooled"))
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: the brain-side modules of a model that never got a state dict for them
+        if name in OminiModel._BRAIN_ATTRS and not self.__dict__.get("_brain_ready", True):
+            import warnings
+            warnings.warn("OminiModel: the CS3 encoders / DGF modules were never loaded (no full state dict; load_lora fills only the "
+                          "transformer adapters) -- building them randomly initialised, which is the state the reference's constructor "
+                          "leaves them in (src/train/model.py:430-462)", RuntimeWarning, stacklevel=2)
+            self._build_brain(synthetic_cs3_state_dict(self.__dict__.get("_brain_seed", 0)))
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!s} object has no attribute {name!r}")
+
+    @classmethod
+    def from_pipe(cls, pipe, cs3_state_dict: Optional[Dict[str, torch.Tensor]] = None, model_config: Optional[dict] = None, device="cuda",
+                  dtype: torch.dtype = torch.bfloat16, lora_config: Optional[dict] = None):
+        """Wrap an existing pipeline object (anything with `.transformer`; None for a brain-side-only model) and a CS3 / DGF state
+        dict in the reference's naming (`eeg_projection.*`, `fusion1.*`, `duan_norm1.*` ...)."""
+        m = cls(None, lora_config=lora_config, device=device, dtype=dtype, model_config=model_config)
+        if pipe is not None:
+            m._set_pipe(pipe)
+        if cs3_state_dict is not None:
+            m._build_brain(cs3_state_dict)
+        return m
 
     # ---- construction helpers ---------------------------------------------------------------------------------
     def _set_pipe(self, pipe) -> None:
@@ -475,7 +500,7 @@ class OminiModel(CS3DGF):
         from ..flux.pipeline import LxFluxPipeline
         from ..flux.transformer import LxFluxTransformer
         tr = LxFluxTransformer.synthetic(flux_config, device, seed, precise=dtype == torch.float32)
-        return cls(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device, dtype=dtype)
+        return cls.from_pipe(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device, dtype=dtype)
 
     def load_lora(self, checkpoint_path: str):
         """model.py:463-477: load LoRA weights from a checkpoint directory into the pipeline's transformer."""

@@ -138,7 +138,7 @@ def _mk_model(tr):
     torch.manual_seed(0)
     ref_cs3 = ocs3.CS3DGF(seed=0).eval()
     lxtr = LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, "cuda")
-    return ref_cs3, OminiModel(LxFluxPipeline(lxtr), ref_cs3.state_dict(), {}, "cuda")
+    return ref_cs3, OminiModel.from_pipe(LxFluxPipeline(lxtr), ref_cs3.state_dict(), {}, "cuda")
 
 
 def test_generate_matches_oracle_loop():

@@ -27,7 +27,7 @@ def _model(dev="cuda"):
     from loongx_amd.flux.weights import FluxConfig, synthetic_weights
     from loongx_amd.train.model import OminiModel, synthetic_cs3_state_dict
     pw = synthetic_weights(FluxConfig(num_layers=1, num_single_layers=1), dev, seed=0)
-    return OminiModel(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), {"union_cond_attn": True}, dev)
+    return OminiModel.from_pipe(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), {"union_cond_attn": True}, dev)
 
 
 def test_generate_batch16_all_modalities_equals_single_runs():

@@ -50,6 +50,32 @@ def test_install_lora_equals_packing_the_wrapped_state_dict(monkeypatch):
         install_lora(pw, {"transformer.x_embedder.weight": torch.zeros(2, 2)})
 
 
+def test_install_lora_keeps_the_precise_mode_residuals(monkeypatch):
+    """A model packed with precise=True: install_lora must leave the same adapter residuals (Lora.down_lo, mod.lora_down_lo) that
+    pack_state_dict keeps, so `load_lora(dir)` (the reference's '*lora*' checkpoint branch, inference.py:43-44, under its shipped
+    dtype float32) and a packed full state dict give the same precise-mode operands."""
+    monkeypatch.setenv("LX_TILE_W", "0")
+    from loongx_amd.flux.weights import install_lora, pack_state_dict
+    tr = tiny_transformer()
+    sd = tr.state_dict()
+    cfg = _cfg(tr)
+    want = pack_state_dict(sd, cfg, "cpu", precise=True)
+    base = {k.replace(".base_layer.", "."): v for k, v in sd.items() if ".lora_" not in k}
+    lora = {"transformer." + k.replace(".default.", "."): v for k, v in sd.items() if ".lora_" in k}
+    pw = pack_state_dict(base, cfg, "cpu", precise=True)
+    install_lora(pw, lora)
+    assert pw.precise_ready and any(l.down_lo is not None for l in want.lora.values())      # the synthetic adapters are not bf16-exact
+    for k, l in want.lora.items():
+        assert (pw.lora[k].down_lo is None) == (l.down_lo is None), k
+        assert l.down_lo is None or torch.equal(pw.lora[k].down_lo, l.down_lo), k
+    assert "mod.lora_down_lo" in want.t and torch.equal(pw.t["mod.lora_down_lo"], want.t["mod.lora_down_lo"])
+    assert set(pw.t) == set(want.t)
+    # a model packed WITHOUT residuals gets none from install_lora either
+    pw0 = pack_state_dict(base, cfg, "cpu")
+    install_lora(pw0, lora)
+    assert all(l.down_lo is None for l in pw0.lora.values()) and "mod.lora_down_lo" not in pw0.t
+
+
 def test_sigma_schedule_matches_oracle():
     import numpy as np
     from oracle import flux_modules as fm
@@ -120,3 +146,28 @@ def test_bench_flop_accounting_and_power_sampler_without_a_gpu():
     ps = bench.PowerSampler(0)
     ps.start()
     assert ps.stop() is None
+
+
+def test_ominimodel_constructor_forms_and_lazy_brain_modules():
+    """The constructor takes the reference's arguments only (no dict-key sniffing); OminiModel.from_pipe is the explicit form for
+    a pipeline object + CS3 state dict; brain modules that no state dict ever filled are built randomly initialised on first
+    access with a warning (the reference's constructor state, src/train/model.py:430-462) instead of an AttributeError."""
+    import types
+    import warnings
+    from loongx_amd.train.model import OminiModel, synthetic_cs3_state_dict
+    pipe = types.SimpleNamespace(transformer=types.SimpleNamespace())
+    with pytest.raises(TypeError):
+        OminiModel(pipe, {}, {"union_cond_attn": True}, "cpu")
+    with pytest.raises(TypeError):
+        OminiModel(None, {"eeg_projection.x": torch.zeros(1)})
+    m = OminiModel.from_pipe(pipe, None, {"latent_lora": True}, "cpu", lora_config={"r": 4, "lora_alpha": 8})
+    assert m.flux_pipe is pipe and m.model_config == {"latent_lora": True} and m.lora_scale == 2.0 and not m._brain_ready
+    with pytest.raises(AttributeError):
+        m.no_such_attribute
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        f1 = m.fusion1
+    assert m._brain_ready and f1 is m.fusion1 and any("randomly initialised" in str(x.message) for x in w)
+    assert m.eeg_projection is not None and m.duan_norm_pooled is not None
+    m2 = OminiModel.from_pipe(None, synthetic_cs3_state_dict(0), {}, "cpu")
+    assert m2._brain_ready and m2.flux_pipe is None

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from loongx_amd.train.model import OminiModel, synthetic_cs3_state_dict
 B = int(os.environ.get("DET_B", "16"))
-m = OminiModel(None, synthetic_cs3_state_dict(0), {}, "cuda")
+m = OminiModel.from_pipe(None, synthetic_cs3_state_dict(0), {}, "cuda")
 g = torch.Generator(device="cuda").manual_seed(3)
 r = lambda *s: torch.randn(*s, device="cuda", generator=g)
 x = dict(eeg=r(B, 4, 4096), fnirs=r(B, 6, 512), ppg=r(B, 4, 256), motion=r(B, 6, 128), pe=r(B, 512, 4096) * 0.1, pooled=r(B, 768))
