@@ -14,6 +14,13 @@ draws the weights and broadcasts them over RCCL/xGMI before the timed region.  P
 `python bench.py --gpus N` with N > 1 and no torchrun environment starts its N ranks itself (re-executes under
 `python -m torch.distributed.run`, as the reference's inference.py:432-452 spawns its own workers).
 
+`--config {1,2,3,4}` sets batch / resolution / modalities / fp8-attention from BASELINE.json's configs (per-GPU batch = the
+config's global batch / N), e.g. `bench.py --gpus 8 --config 3` is the literal configs[3] run. With N = 1 and no explicit
+workload flags the line also carries `secondary`: short bounded legs (2 timed batches each, outside the headline's timed region)
+of the other BASELINE configs on this GPU -- configs[2] (batch 16, all four modalities), configs[4]'s per-GPU shape (1024x1024,
+batch 4) in bf16 and with the fp8 attention path, and the precise mode -- each with its own roofline, power and (fp8 / precise)
+full-depth parity figures; `--no-secondary` skips them.
+
 Besides the contract fields the line carries `roofline` (dominant kernel, live HIP events), `cpu_baseline` (the oracle on
 this box's host cores, bounded sample) and `parity` (the engine against the fp32 oracle on identical inputs at
 FULL depth -- 57 blocks x 28 steps -- per-step noise_pred rel-err, final-latent rel-err and cosine; N=1 only).
@@ -79,17 +86,6 @@ def cpu_baseline(threads: int):
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32: 1 double block ({td:.2f}s) + 1 single block ({ts:.2f}s) at full width B=1 S=2560, "
                       f"extrapolated x(19,38) blocks x28 steps"}
-
-
-def parity_check(precise: bool = False, fp8: bool = False, extra_mc=None):
-    """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
-    timed region) at full depth and width on this GPU, in the mode the timed region ran."""
-    from oracle.parity import full_depth_parity
-    mc = {"union_cond_attn": True}
-    if fp8:
-        mc.update(attn_fp8=True, gemm_fp8=True)
-    mc.update(extra_mc or {})
-    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc)
 
 
 def _gemm_traffic_mb():
@@ -180,79 +176,56 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed images (batches) per GPU")
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline-events", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (N=1 only; ~1 min on the GPU)")
-    ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32 attention)")
-    ap.add_argument("--hw", type=int, default=32, help="packed latent grid side: 32 = 512x512 (the metric's config), 64 = 1024x1024 (configs[4])")
-    ap.add_argument("--fp8", action="store_true", help="model_config attn_fp8 / gemm_fp8: the e4m3 MFMA paths of BASELINE configs[4]")
-    ap.add_argument("--attn-fp8", action="store_true", help="model_config attn_fp8 only: e4m3 attention, bf16 GEMMs (what north_star names for configs[4])")
-    ap.add_argument("--gemm-fp8", action="store_true", help="model_config gemm_fp8 only: e4m3 block GEMMs, bf16 attention")
-    ap.add_argument("--independent-condition", action="store_true",
-                    help="model_config independent_condition (block.py:115-120): the condition queries see only condition keys, so the "
-                         "condition stream is step-invariant and the engine computes it once per image (not the metric's configuration)")
-    ap.add_argument("--modalities", type=str, default="eeg", help="eeg (configs[1]) | all (EEG+fNIRS+PPG+motion, CS3+DGF fuse: configs[2]/[3])")
-    a = ap.parse_args()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(_self_launch(a.gpus))
+def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1):
+    """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
+    timed region) at full depth and width on this GPU, in the mode the timed region ran."""
+    from oracle.parity import full_depth_parity
+    mc = {"union_cond_attn": True}
+    mc.update(extra_mc or {})
+    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc, hw=hw, every=every)
 
+
+# BASELINE.json configs -> workload (global batch, latent grid side, modalities, extra model_config)
+CONFIGS = {1: dict(global_batch=1, hw=32, modalities="eeg", mc={}),
+           2: dict(global_batch=16, hw=32, modalities="all", mc={}),
+           3: dict(global_batch=128, hw=32, modalities="all", mc={}),
+           4: dict(global_batch=32, hw=64, modalities="all", mc={"attn_fp8": True})}
+
+
+def workload_name(cfg_no, B, hw, allmod, mc, precise):
+    N = hw * hw
+    tag = f"BASELINE configs[{cfg_no}]" if cfg_no else ("BASELINE configs[4] shape" if hw == 64 else "BASELINE configs[1] shape")
+    return (f"{tag}: " + ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
+            f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, D=3072), "
+            "LoRA r=4 on the condition stream" + (", precise mode" if precise else "") +
+            (", fp8 GEMM + attention paths" if (mc.get("gemm_fp8") and mc.get("attn_fp8")) else ", fp8 GEMM path (lossy: 1e-1 per forward)" if mc.get("gemm_fp8")
+             else ", fp8 (e4m3) attention path, bf16 GEMMs" if mc.get("attn_fp8") else "") +
+            (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if mc.get("independent_condition") else ""))
+
+
+def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, events=True, seed=1234):
+    """Warm-up + timed region of one workload on this rank; returns the measurement record (rank 0) or None."""
     from loongx_amd import dist as lxd
     from loongx_amd import ops
-    rank, local, world = lxd.init()
-    if world != a.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
-        a.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
     from loongx_amd.flux.condition import Condition
     from loongx_amd.flux.generate import generate
     from loongx_amd.flux.pipeline import LxFluxPipeline
     from loongx_amd.flux.transformer import LxFluxTransformer
-    from loongx_amd.flux.weights import FluxConfig, synthetic_weights
     from loongx_amd.train.model import OminiModel, synthetic_cs3_state_dict
-
-    cfg = FluxConfig()
-    t0 = time.time()
-    pw = synthetic_weights(cfg, dev, seed=0 if rank == 0 else 1000 + rank)   # non-zero ranks hold garbage until the broadcast
-    torch.cuda.synchronize()
-    t_draw = time.time() - t0
-    t1 = time.time()
-    moved = lxd.broadcast_packed_weights(pw, src=0)
-    torch.cuda.synchronize()
-    t_bcast = time.time() - t1
-    t_weights = time.time() - t0
-    mc = {"union_cond_attn": True}
-    if a.precise:
+    mc = dict(mc)
+    mc.setdefault("union_cond_attn", True)
+    if precise:
         mc["precise"] = True
-    if a.fp8:
-        a.attn_fp8 = a.gemm_fp8 = True
-    if a.attn_fp8:
-        mc["attn_fp8"] = True
-    if a.gemm_fp8:
-        mc["gemm_fp8"] = True
-    a.fp8 = a.gemm_fp8                 # which peak the GEMM roofline / end-to-end fraction is priced against
-    if a.independent_condition:
-        mc["independent_condition"] = True
     model = OminiModel.from_pipe(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
-
-    B, hw = a.batch, a.hw
     N = hw * hw
-    allmod = a.modalities == "all"
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)     # every rank edits different images
+    g = torch.Generator(device=dev).manual_seed(seed + rank)     # every rank edits different images
+
     def batch():
         return dict(lat=torch.randn(B, N, 64, device=dev, generator=g), cond=torch.randn(B, N, 64, device=dev, generator=g),
                     pe=torch.randn(B, T_TXT, 4096, device=dev, generator=g) * 0.1, pooled=torch.randn(B, 768, device=dev, generator=g),
                     eeg=torch.randn(B, 4, 4096, device=dev, generator=g), fnirs=torch.randn(B, 6, 512, device=dev, generator=g),
                     ppg=torch.randn(B, 4, 256, device=dev, generator=g), motion=torch.randn(B, 6, 128, device=dev, generator=g))
+
     def run(x):
         c = Condition("subject", latents=x["cond"], latent_hw=(hw, hw), position_delta=[0, -hw])
         sig = dict(additional_condition1=x["eeg"])
@@ -263,25 +236,24 @@ def main():
                         default_lora=True, use_brain_condition=True, fuse_flag=allmod,
                         brain_replace="per_stream", **sig).images      # EEG-only conditioning (configs[1]) needs the per-stream rule
 
-    batches = [batch() for _ in range(a.warmup + a.steps)]
-    for i in range(a.warmup):
+    batches = [batch() for _ in range(warmup + steps)]
+    out = None
+    for i in range(warmup):
         out = run(batches[i])
-    timer = None
-    if rank == 0 and not a.no_roofline_events:
-        timer = ops.LaunchTimer(only_calls=ROOFLINE_STEPS)
+    timer = ops.LaunchTimer(only_calls=ROOFLINE_STEPS) if (rank == 0 and events) else None
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    power = PowerSampler(local) if rank == 0 else None
+    power = PowerSampler(dev.index) if rank == 0 else None
     if power is not None:
         power.start()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        # HIP-event brackets around every GEMM / attention launch of ROOFLINE_STEPS denoise steps of the LAST timed image
+    for i in range(steps):
+        # HIP-event brackets around every GEMM / attention launch of ROOFLINE_STEPS denoise steps of the LAST timed batch
         # (events cannot be recorded inside a replayed graph, so those steps run the eager launch path, ~2 % slower; every
         # other step of the timed region replays the captured step graph)
-        ops.TIMER = timer if i == a.steps - 1 else None
-        out = run(batches[a.warmup + i])
+        ops.TIMER = timer if i == steps - 1 else None
+        out = run(batches[warmup + i])
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -290,74 +262,186 @@ def main():
     pw_rec = power.stop() if power is not None else None
     ops.TIMER = None
     elapsed_ms = lxd.barrier_max_ms(elapsed_ms, dev)
+    model.transformer.engine.check_status(sync=True)              # a split-K pair time-out would invalidate the region
     finite = bool(torch.isfinite(out).all())
+    if rank != 0:
+        return None
+    gemm_fp8, attn_fp8 = bool(mc.get("gemm_fp8")), bool(mc.get("attn_fp8"))
+    images = world * B * steps
+    value = images / (elapsed_ms / 1e3)
+    cached = mc.get("independent_condition") and model.flux_pipe.transformer.engine.cond_cache
+    fpi = flops_per_image_cond_cached(N, N) if cached else flops_per_image(N, N)
+    peak_e2e = PEAK_FP8_TFLOPS if gemm_fp8 else PEAK_BF16_TFLOPS
+    res = {"value": round(value, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed_ms / steps, 2),
+           "dtype": ("bf16 x2 split (fp32-class)" if precise else "fp8 e4m3 MFMA operands" if gemm_fp8 else
+                     "bf16 GEMMs, fp8 e4m3 attention" if attn_fp8 else "bf16"),
+           "batch_per_gpu": B, "outputs_finite": finite,
+           "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
+           "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / peak_e2e, 4)}
+    if pw_rec is not None:
+        # the matrix-core peak at the clock the part actually sustained under this load (spec peak is quoted at 2.4 GHz)
+        peak_here = peak_e2e * pw_rec["sclk_MHz_avg"] / 2400.0
+        pw_rec["mfma_peak_at_measured_clock_TFLOPs"] = round(peak_here, 1)
+        pw_rec["mfma_frac_end_to_end_at_measured_clock"] = round(value * fpi / world / 1e12 / peak_here, 4)
+        res["power"] = pw_rec
+    if timer is not None:
+        s = timer.summary()
+        gm, at = s.get("gemm"), s.get("attn")
+        ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+        to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one batch
+        traffic, traffic_src = _gemm_traffic_mb()
+        gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
+                 "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
+                 "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)")
+        if gemm_fp8 or precise or B != 1 or hw != 32:
+            traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels at the headline shape
+        res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
+                           "peak": peak_e2e, "unit": "TFLOP/s", "frac": round(ach / peak_e2e, 4), "traffic": traffic,
+                           "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",
+                           "traffic_source": traffic_src,
+                           "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
+                           "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
+                           "share_of_step_time": round(gm["ms"] * to_image / (elapsed_ms / steps), 3),
+                           "timed": f"HIP events around every launch of denoise steps {list(ROOFLINE_STEPS)} of the last timed batch"}
+        if pw_rec is not None:
+            res["roofline"]["frac_at_measured_clock"] = round(ach / pw_rec["mfma_peak_at_measured_clock_TFLOPs"], 4)
+        if at:
+            aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
+            apeak = PEAK_FP8_TFLOPS if attn_fp8 else (157.3 if precise else PEAK_BF16_TFLOPS)
+            aname = ("lx_attn_fp8_pipe_kernel (e4m3 32x32x64 MFMA)" if attn_fp8 else
+                     "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if precise
+                     else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)")
+            res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
+                                         "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
+                                         "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
+                                         "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / steps), 3)}
+    del model, batches, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed images (batches) per GPU")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4),
+                    help="BASELINE.json configs[n]: sets batch (global batch / --gpus), resolution, modalities and the fp8 attention path")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity legs (N=1 only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (the other BASELINE configs; N=1 default run only)")
+    ap.add_argument("--secondary-steps", type=int, default=2, help="timed batches per secondary leg")
+    ap.add_argument("--precise", action="store_true", help="model_config precise mode (split-bf16 MFMA GEMMs, fp32-class attention)")
+    ap.add_argument("--hw", type=int, default=None, help="packed latent grid side: 32 = 512x512 (the metric's config), 64 = 1024x1024 (configs[4])")
+    ap.add_argument("--fp8", action="store_true", help="model_config attn_fp8 + gemm_fp8 (the e4m3 GEMMs are lossy: 1e-1 per forward)")
+    ap.add_argument("--attn-fp8", action="store_true", help="model_config attn_fp8 only: e4m3 attention, bf16 GEMMs (what north_star names for configs[4])")
+    ap.add_argument("--gemm-fp8", action="store_true", help="model_config gemm_fp8 only: e4m3 block GEMMs, bf16 attention")
+    ap.add_argument("--independent-condition", action="store_true",
+                    help="model_config independent_condition (block.py:115-120): the condition queries see only condition keys, so the "
+                         "condition stream is step-invariant and the engine computes it once per image (not the metric's configuration)")
+    ap.add_argument("--modalities", type=str, default=None, help="eeg (configs[1]) | all (EEG+fNIRS+PPG+motion, CS3+DGF fuse: configs[2]/[3])")
+    a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(a.gpus))
+
+    from loongx_amd import dist as lxd
+    rank, local, world = lxd.init()
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from loongx_amd.flux.weights import FluxConfig, synthetic_weights
+
+    # ---- workload -------------------------------------------------------------------------------------------------------------
+    plain = not (a.config or a.batch or a.hw or a.modalities or a.precise or a.fp8 or a.attn_fp8 or a.gemm_fp8 or a.independent_condition)
+    mc = {"union_cond_attn": True}
+    cfg_no = a.config
+    if a.config:
+        c = CONFIGS[a.config]
+        B = max(1, c["global_batch"] // world) if a.batch is None else a.batch
+        hw = c["hw"] if a.hw is None else a.hw
+        allmod = (c["modalities"] if a.modalities is None else a.modalities) == "all"
+        mc.update(c["mc"])
+    else:
+        B, hw, allmod = a.batch or 1, a.hw or 32, (a.modalities or "eeg") == "all"
+        if plain:
+            cfg_no = 1
+    if a.fp8:
+        a.attn_fp8 = a.gemm_fp8 = True
+    if a.attn_fp8:
+        mc["attn_fp8"] = True
+    if a.gemm_fp8:
+        mc["gemm_fp8"] = True
+    if a.independent_condition:
+        mc["independent_condition"] = True
+
+    cfg = FluxConfig()
+    t0 = time.time()
+    pw = synthetic_weights(cfg, dev, seed=0, fill=(rank == 0))      # the other ranks receive every byte by broadcast
+    torch.cuda.synchronize()
+    t_draw = time.time() - t0
+    t1 = time.time()
+    moved = lxd.broadcast_packed_weights(pw, src=0)
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t1
+    t_weights = time.time() - t0
+
+    rec = run_leg(pw, dev, rank, world, B=B, hw=hw, allmod=allmod, mc=mc, precise=a.precise, steps=a.steps, warmup=a.warmup,
+                  events=not a.no_roofline_events)
 
     if rank == 0:
-        images = world * B * a.steps
-        value = images / (elapsed_ms / 1e3)
-        cached = a.independent_condition and model.flux_pipe.transformer.engine.cond_cache
-        fpi = flops_per_image_cond_cached(N, N) if cached else flops_per_image(N, N)
-        res = {"metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "value": round(value, 4), "unit": "images/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed_ms / a.steps, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16 x2 split (fp32-class)" if a.precise else ("fp8 e4m3 MFMA operands" if a.fp8 else ("bf16 GEMMs, fp8 e4m3 attention" if a.attn_fp8 else "bf16")), "data": "synthetic",
-               "config": {"workload": (f"BASELINE configs[{1 if not allmod else (2 if B == 1 else 3)}]: " if hw == 32 and not a.fp8 else "BASELINE configs[4] shape: ") +
-                                      ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
-                                      f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, "
-                                      "D=3072), LoRA r=4 on the condition stream" + (", precise mode" if a.precise else "") + (", fp8 GEMM + attention paths" if (a.fp8 and a.attn_fp8) else ", fp8 GEMM path" if a.fp8 else ", fp8 attention path" if a.attn_fp8 else "") +
-                                      (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if a.independent_condition else ""),
-                          "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
+        res = {"metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "value": rec.pop("value"), "unit": rec.pop("unit"),
+               "n_gpus": world, "steps": rec.pop("steps"), "warmup": rec.pop("warmup"), "ms_per_step": rec.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": rec.pop("dtype"), "data": "synthetic",
+               "config": {"workload": workload_name(cfg_no, B, hw, allmod, mc, a.precise), "batch_per_gpu": rec.pop("batch_per_gpu"),
+                          "global_batch": world * B, "parallelism": f"dp{world}", "weights": "synthetic N(0,0.02^2)",
                           "rccl_ranks": world, "weight_broadcast_GB": round(moved / 1e9, 2), "weight_broadcast_s": round(t_bcast, 2),
-                          "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)},
-               "outputs_finite": finite,
-               "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
-               "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS), 4)}
-        if pw_rec is not None:
-            # the matrix-core peak at the clock the part actually sustained under this load (spec peak is quoted at 2.4 GHz)
-            peak_here = (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS) * pw_rec["sclk_MHz_avg"] / 2400.0
-            pw_rec["mfma_peak_at_measured_clock_TFLOPs"] = round(peak_here, 1)
-            pw_rec["mfma_frac_end_to_end_at_measured_clock"] = round(value * fpi / world / 1e12 / peak_here, 4)
-            res["power"] = pw_rec
-        if timer is not None:
-            s = timer.summary()
-            gm, at = s.get("gemm"), s.get("attn")
-            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one image
-            traffic, traffic_src = _gemm_traffic_mb()
-            gpeak = PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS
-            gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if a.fp8 else
-                     "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if a.precise else
-                     "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)")
-            if a.fp8 or a.precise:
-                traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels
-            res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
-                               "peak": gpeak, "unit": "TFLOP/s", "frac": round(ach / gpeak, 4), "traffic": traffic,
-                               "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",
-                               "traffic_source": traffic_src,
-                               "traffic_algorithmic": round(gm.get("bytes", 0.0) / max(gm["launches"], 1) / 1e6, 1),
-                               "launches": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 1),
-                               "share_of_step_time": round(gm["ms"] * to_image / (elapsed_ms / a.steps), 3),
-                               "timed": f"HIP events around every launch of denoise steps {list(ROOFLINE_STEPS)} of the last timed image"}
-            if pw_rec is not None:
-                res["roofline"]["frac_at_measured_clock"] = round(ach / pw_rec["mfma_peak_at_measured_clock_TFLOPs"], 4)
-            if at:
-                aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                apeak = PEAK_FP8_TFLOPS if a.attn_fp8 else (157.3 if a.precise else PEAK_BF16_TFLOPS)
-                aname = ("lx_attn_fp8_pipe_kernel (e4m3 32x32x64 MFMA)" if a.attn_fp8 else "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if a.precise
-                         else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)")
-                res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
-                                             "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
-                                             "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
-                                             "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / a.steps), 3)}
+                          "weight_draw_s": round(t_draw, 2), "init_s": round(t_weights, 2)}}
+        res.update(rec)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-        if world == 1 and not a.no_parity and hw == 32:
-            del model, pw, batches, out
-            torch.cuda.empty_cache()
+        xmc = {k: True for k in ("attn_fp8", "gemm_fp8", "independent_condition") if mc.get(k)}
+        if world == 1 and not a.no_parity:
             try:
-                res["parity"] = parity_check(a.precise, False, {k: True for k in ("attn_fp8", "gemm_fp8", "independent_condition") if mc.get(k)})
+                res["parity"] = parity_check(a.precise, xmc, hw=hw, every=1 if hw == 32 else 7)
             except Exception as e:          # the checker must never take the measurement down with it
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and plain and not a.no_secondary:
+            # ---- the other BASELINE configs on this GPU, outside the headline's timed region (bounded: 2 timed batches each) ----
+            legs = [dict(config=2, B=16, hw=32, allmod=True, mc={}, precise=False, parity=None),
+                    dict(config=None, B=4, hw=64, allmod=True, mc={}, precise=False, parity=None),
+                    dict(config=4, B=4, hw=64, allmod=True, mc={"attn_fp8": True}, precise=False, parity=[(32, 1), (64, 7)]),
+                    dict(config=None, B=1, hw=32, allmod=False, mc={}, precise=True, parity=[(32, 4)])]
+            sec = []
+            for lg in legs:
+                t_leg = time.time()
+                try:
+                    r = run_leg(pw, dev, 0, 1, B=lg["B"], hw=lg["hw"], allmod=lg["allmod"], mc=lg["mc"], precise=lg["precise"],
+                                steps=a.secondary_steps, warmup=1, events=not a.no_roofline_events, seed=99)
+                    m2 = dict(lg["mc"]); m2.setdefault("union_cond_attn", True)
+                    r["config"] = {"workload": workload_name(lg["config"], lg["B"], lg["hw"], lg["allmod"], m2, lg["precise"]) +
+                                               (" (per-GPU share of the 8-GPU config: batch 32 / 8)" if lg["config"] == 4 else
+                                                " (bf16 reference line for the fp8-attention leg)" if lg["hw"] == 64 else ""),
+                                   "batch_per_gpu": lg["B"], "global_batch": lg["B"], "parallelism": "dp1"}
+                    if lg["parity"] and not a.no_parity:
+                        r["parity"] = {}
+                        for phw, every in lg["parity"]:
+                            try:
+                                r["parity"][f"{16 * phw}x{16 * phw}"] = parity_check(lg["precise"], {k: True for k in lg["mc"]}, hw=phw, every=every)
+                            except Exception as e:
+                                r["parity"][f"{16 * phw}x{16 * phw}"] = {"error": f"{type(e).__name__}: {e}"}
+                except Exception as e:      # a secondary leg must never take the headline down with it
+                    r = {"error": f"{type(e).__name__}: {e}", "config": {"workload": workload_name(lg["config"], lg["B"], lg["hw"], lg["allmod"], lg["mc"], lg["precise"])}}
+                r["leg_wall_s"] = round(time.time() - t_leg, 1)
+                sec.append(r)
+                torch.cuda.empty_cache()
+            res["secondary"] = sec
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

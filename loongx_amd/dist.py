@@ -89,10 +89,14 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
 
 
 def broadcast_packed_weights(pw, src: int = 0) -> int:
-    """RCCL broadcast of a PackedWeights (flux/weights.py) from rank `src` to all ranks."""
+    """RCCL broadcast of a PackedWeights (flux/weights.py) from rank `src` to all ranks: every tensor the engine dereferences
+    (`pw.t`, and per adapter `down`, `up` and -- models packed for precise mode -- `down_lo`). The receiving ranks hold tensors of
+    the same names and shapes (e.g. synthetic_weights(fill=False), or the same packing of an uninitialised state dict)."""
     flat = dict(pw.t)
     for k, lo in pw.lora.items():
         flat[f"{k}::lora_down"], flat[f"{k}::lora_up"] = lo.down, lo.up
+        if lo.down_lo is not None:
+            flat[f"{k}::lora_down_lo"] = lo.down_lo
     return broadcast_tensors(flat, src)
 
 

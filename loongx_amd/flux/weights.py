@@ -358,9 +358,10 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
     return n
 
 
-def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True) -> PackedWeights:
+def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True, fill: bool = True) -> PackedWeights:
     """Random weights of the fused layout generated on the GPU (full FLUX.1-dev scale = 23.8 GB bf16). Drawn in bf16, hence
-    bf16-representable: precise mode needs no residuals for them."""
+    bf16-representable: precise mode needs no residuals for them. fill=False allocates the same tensors without drawing them
+    (ranks that receive the weights by broadcast: dist.broadcast_packed_weights overwrites every byte)."""
     g = torch.Generator(device=device).manual_seed(seed)
     pw = PackedWeights(cfg)
     pw.precise_ready = True
@@ -368,7 +369,8 @@ def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02,
 
     def rn(*shape, dtype=torch.bfloat16, s=std):
         out = torch.empty(*shape, dtype=dtype, device=device)
-        out.normal_(0.0, s, generator=g)
+        if fill:
+            out.normal_(0.0, s, generator=g)
         return out
 
     def put(name, n_out, n_in, n_lora_mod=0):
