@@ -186,7 +186,11 @@ def setup(rank, world_size):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "12355")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", rank=rank, world_size=world_size)
+    import datetime
+    # "nccl" = RCCL over xGMI on the GPU box (inference.py:183); gloo where there is no GPU (the CPU test of this control flow).
+    # The timeout bounds the final barrier: a worker that died leaves the others blocked forever in the reference (inference.py:255)
+    backend = os.environ.get("LX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=datetime.timedelta(seconds=int(os.environ.get("LX_DIST_TIMEOUT_S", "1800"))))
 
 
 def cleanup():
@@ -196,10 +200,12 @@ def cleanup():
 def distributed_inference_worker(rank, world_size, args, config, model_loaded_event=None):
     """inference.py:194-252. Rank 0's packed DiT weights are broadcast over RCCL/xGMI instead of every rank re-reading and
     re-packing the checkpoint."""
-    torch.cuda.set_device(rank)
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(rank)
     if world_size > 1:
         setup(rank, world_size)
-    device = torch.device("cuda", rank)
+    device = torch.device("cuda", rank) if on_gpu else torch.device("cpu")
     if model_loaded_event is not None:
         model_loaded_event.wait()
     model = load_model("synthetic" if args.synthetic else args.checkpoint, config, device)

@@ -86,3 +86,113 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+# ---- a REAL PackedWeights through the broadcast (what bench.py / inference.py do at start-up) -------------------------------------
+def _tiny_pw(seed, precise=True):
+    from loongx_amd.flux.weights import FluxConfig, pack_state_dict
+    from tests.helpers import tiny_transformer
+    tr = tiny_transformer(seed=seed)
+    c = tr.config
+    cfg = FluxConfig(num_layers=c.num_layers, num_single_layers=c.num_single_layers, num_attention_heads=c.num_attention_heads,
+                     attention_head_dim=c.attention_head_dim, in_channels=c.in_channels, joint_attention_dim=c.joint_attention_dim,
+                     pooled_projection_dim=c.pooled_projection_dim, guidance_embeds=c.guidance_embeds, axes_dims_rope=c.axes_dims_rope)
+    return pack_state_dict(tr.state_dict(), cfg, "cpu", precise=precise)
+
+
+def _pw_tensors(pw):
+    """Every tensor a DiTEngine can dereference through a PackedWeights, found by walking the object (not by a hand-made list)."""
+    out = {}
+    for attr, val in vars(pw).items():
+        if isinstance(val, dict):
+            for k, v in val.items():
+                if isinstance(v, torch.Tensor):
+                    out[f"{attr}.{k}"] = v
+                elif hasattr(v, "__slots__"):
+                    for s_ in v.__slots__:
+                        t = getattr(v, s_)
+                        if isinstance(t, torch.Tensor):
+                            out[f"{attr}.{k}.{s_}"] = t
+        elif isinstance(val, torch.Tensor):
+            out[attr] = val
+    return out
+
+
+def _pw_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from loongx_amd import dist as lxd
+    lxd.init("gloo", timeout_s=120)
+    truth = _pw_tensors(_tiny_pw(0))                       # what rank 0 packs
+    pw = _tiny_pw(0 if rank == 0 else 100 + rank)          # the other ranks: same structure, different (garbage) contents
+    mine = _pw_tensors(pw)
+    differs_before = any(not torch.equal(mine[k], truth[k]) for k in truth)
+    moved = lxd.broadcast_packed_weights(pw, src=0)
+    mine = _pw_tensors(pw)
+    ok = set(mine) == set(truth) and all(torch.equal(mine[k], truth[k]) for k in truth)
+    ok = ok and moved == sum(t.numel() * t.element_size() for t in truth.values())
+    ok = ok and (rank == 0 or differs_before)
+    # tiled GEMM weights keep their layout flag, adapters their residuals
+    ok = ok and all(getattr(pw.t[k], "lx_tiled", False) == getattr(_tiny_pw(0).t[k], "lx_tiled", False) for k in list(pw.t)[:8])
+    ok = ok and any(k.endswith(".down_lo") for k in mine) and "t.mod.lora_down_lo" in mine and "t.mod.w" in mine
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok), len(truth)))
+
+
+def test_gloo_world2_broadcast_of_a_real_packed_weights():
+    """bench.py / inference.py: rank 0 packs (or draws) the weights, the other ranks allocate and receive them. Every tensor
+    reachable from the PackedWeights object -- pre-tiled GEMM images, fused biases, norm weights, the stacked modulation matrix,
+    LoRA down / up slabs and, for a model packed for precise mode, the bf16 rounding residuals -- must arrive bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pw_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)] and res[0][2] > 60
+
+
+# ---- inference.py's own process model (reference inference.py:193-261, 432-452) ----------------------------------------------------
+def _inf_worker(rank, world, port, outdir, ev):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LX_DIST_BACKEND="gloo", LX_DIST_TIMEOUT_S="120")
+    import types
+    import inference as inf
+    pw = _tiny_pw(0 if rank == 0 else 50 + rank, precise=False)
+
+    def load_model(ckpt, config=None, device=None):
+        return types.SimpleNamespace(transformer=types.SimpleNamespace(engine=types.SimpleNamespace(w=pw)), device=device)
+
+    def process_shard(rank_, world_, model, n_items, args, device):
+        from loongx_amd.dist import shard_range
+        s, e = shard_range(n_items, rank_, world_)
+        want = _tiny_pw(0, precise=False)
+        same = all(torch.equal(model.transformer.engine.w.t[k], want.t[k]) for k in want.t)
+        with open(os.path.join(args.output_dir, f"rank{rank_}.txt"), "w") as f:
+            f.write(f"{s} {e} {int(same)} {device.type}")
+        return e - s, 0.0
+    inf.load_model, inf.process_shard = load_model, process_shard
+    args = types.SimpleNamespace(synthetic=True, checkpoint="synthetic", output_dir=outdir, num_images=7)
+    inf.distributed_inference_worker(rank, world, args, {}, ev)
+    assert not dist.is_initialized()                       # cleanup() ran
+
+
+def test_inference_process_model_world2_gloo(tmp_path):
+    """The control flow of inference.py's multi-process branch on CPU: per-rank set-up, weight broadcast from rank 0, the
+    reference's static shard rule, the final barrier and process-group teardown (model loading and the denoise work stubbed)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    ev = ctx.Event()
+    procs = [ctx.Process(target=_inf_worker, args=(r, 2, port, str(tmp_path), ev)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ev.set()
+    for p in procs:
+        p.join(timeout=180)
+    assert [p.exitcode for p in procs] == [0, 0]
+    got = [open(tmp_path / f"rank{r}.txt").read().split() for r in range(2)]
+    assert got == [["0", "3", "1", "cpu"], ["3", "7", "1", "cpu"]]       # 7 items: [0,3) and [3,7); both ranks hold rank 0's weights
