@@ -163,6 +163,19 @@ def gold_flux():
         h, c = rb.single_block_forward(tr.single_transformer_blocks[1], hs, temb, rope_main, cond, ctemb, rope_cond, {})
         out["single_hid"], out["single_cond"] = t2n(h), t2n(c)
         out["single_nocond_hid"] = t2n(rb.single_block_forward(tr.single_transformer_blocks[1], hs, temb, rope_main))
+        # the reference's LoRA switches (src/flux/lora_controller.py:5-75) around its own block functions: adapters off on every
+        # stream, and every adapter term halved
+        from refsrc.flux import lora_controller as rl
+        dblk, sblk = tr.transformer_blocks[1], tr.single_transformer_blocks[1]
+        for name, ctx in {"lora_off": lambda m: rl.enable_lora(m, False), "lora_half": lambda m: rl.set_lora_scale(m, 0.5)}.items():
+            with ctx(list(dblk.modules())):
+                e, h, c = rb.block_forward(dblk, hid, enc, cond, temb, ctemb, rope_cond, rope_main, {})
+            out[f"block_{name}_enc"], out[f"block_{name}_hid"], out[f"block_{name}_cond"] = t2n(e), t2n(h), t2n(c)
+            with ctx(list(sblk.modules())):
+                h, c = rb.single_block_forward(sblk, hs, temb, rope_main, cond, ctemb, rope_cond, {})
+            out[f"single_{name}_hid"], out[f"single_{name}_cond"] = t2n(h), t2n(c)
+        e, h, c = rb.block_forward(dblk, hid, enc, cond, temb, ctemb, rope_cond, rope_main, {})
+        assert np.array_equal(t2n(h), out["block_default_hid"]) and np.array_equal(t2n(c), out["block_default_cond"])   # scales restored on exit
         # full forward
         for name, kw in {"cond": dict(c=True, g=True), "nocond": dict(c=False, g=True)}.items():
             r = rt.tranformer_forward(tr, x["cond"] if kw["c"] else None, x["cond_ids"] if kw["c"] else None,

@@ -93,6 +93,33 @@ def test_block_forward_mirror(G, lx, name, mc):
     assert relerr(c.cpu(), G[f"block_{name}_cond"]) < TOL_BLOCK
 
 
+@pytest.mark.parametrize("name", ["lora_off", "lora_half"])
+def test_lora_controller_switches_against_the_reference(G, lx, name):
+    """src/flux/lora_controller.py:5-75 -- `with enable_lora(modules, False)` (adapters off on every stream) and
+    `with set_lora_scale(modules, 0.5)` around block_forward / single_block_forward, against goldens made by the reference's own
+    context managers around its own block functions; the scale is restored on exit (the default goldens match again)."""
+    from loongx_amd.flux.block import block_forward, single_block_forward
+    from loongx_amd.flux.lora_controller import enable_lora, set_lora_scale
+    tr, m = lx
+    main, cond = _ropes(tr, G)
+    dblk, sblk = m.transformer_blocks[1], m.single_transformer_blocks[1]
+    sblk.text_len = 16
+    ctx = (lambda h: enable_lora(h, False)) if name == "lora_off" else (lambda h: set_lora_scale(h, 0.5))
+    hs = cu(torch.cat([G["enc"], G["hid"]], 1))
+    with ctx([dblk, dblk.attn, object()]):                # non-engine objects are ignored, as the reference ignores non-PEFT modules
+        e, h, c = block_forward(dblk, cu(G["hid"]), cu(G["enc"]), cu(G["cond"]), cu(G["temb"]), cu(G["ctemb"]), cond, main, {})
+        h1, c1 = single_block_forward(sblk, hs, cu(G["temb"]), main, cu(G["cond"]), cu(G["ctemb"]), cond, {})
+    for got, key in ((e, f"block_{name}_enc"), (h, f"block_{name}_hid"), (c, f"block_{name}_cond"), (h1, f"single_{name}_hid"), (c1, f"single_{name}_cond")):
+        assert relerr(got.cpu(), G[key]) < TOL_BLOCK, key
+    # the switch matters (the condition stream moves by 3-8 % between the settings) and is restored on exit
+    assert relerr(c.cpu(), G["block_default_cond"]) > 2 * TOL_BLOCK
+    assert m.engine.lora_scale == 1.0
+    e, h, c = block_forward(dblk, cu(G["hid"]), cu(G["enc"]), cu(G["cond"]), cu(G["temb"]), cu(G["ctemb"]), cond, main, {})
+    assert relerr(c.cpu(), G["block_default_cond"]) < TOL_BLOCK
+    with enable_lora([dblk], True):                       # activated=True: a no-op, as in the reference
+        assert m.engine.lora_scale == 1.0
+
+
 def test_block_forward_mirror_nocond(G, lx):
     from loongx_amd.flux.block import block_forward
     tr, m = lx

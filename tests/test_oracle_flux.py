@@ -90,6 +90,30 @@ def test_single_block_forward(G, tr):
     assert relerr(h2, G["single_nocond_hid"]) < TOL
 
 
+@pytest.mark.parametrize("name,factor", [("lora_off", 0.0), ("lora_half", 0.5)])
+def test_blocks_under_the_reference_lora_switches(G, tr, name, factor):
+    """goldens made by the reference's enable_lora(modules, False) / set_lora_scale(modules, 0.5) (lora_controller.py:5-75) around
+    its block functions; the restatement's blocks with every adapter's scaling multiplied by the same factor must agree."""
+    from oracle import flux_modules as fm
+    main, cond = _ropes(tr, G)
+    dblk, sblk = tr.transformer_blocks[1], tr.single_transformer_blocks[1]
+    layers = [m for b in (dblk, sblk) for m in b.modules() if isinstance(m, fm.LoraLinear)]
+    saved = [dict(m.scaling) for m in layers]
+    try:
+        for m in layers:
+            for a in m.active_adapters:
+                m.scaling[a] *= factor
+        hs = torch.cat([G["enc"], G["hid"]], 1)
+        with torch.no_grad():
+            e, h, c = fr.block_forward(dblk, G["hid"], G["enc"], G["cond"], G["temb"], G["ctemb"], cond, main, {})
+            h1, c1 = fr.single_block_forward(sblk, hs, G["temb"], main, G["cond"], G["ctemb"], cond, {})
+    finally:
+        for m, sc in zip(layers, saved):
+            m.scaling.update(sc)
+    for got, key in ((e, f"block_{name}_enc"), (h, f"block_{name}_hid"), (c, f"block_{name}_cond"), (h1, f"single_{name}_hid"), (c1, f"single_{name}_cond")):
+        assert relerr(got, G[key]) < TOL, key
+
+
 def _fwd(tr, G, cond=True, c_t=0, guidance=True):
     with torch.no_grad():
         return fr.tranformer_forward(tr, G["in_cond"] if cond else None, G["in_cond_ids"] if cond else None, None, {},

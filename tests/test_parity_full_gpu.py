@@ -29,3 +29,46 @@ def test_full_depth_parity_bf16():
     assert rec["noise_pred_relerr_max"] < BF16_NOISE_PRED_MAX, rec
     assert rec["final_latent_relerr"] < BF16_FINAL_LATENT, rec
     assert rec["final_latent_cosine"] > 0.9995, rec
+
+
+# ---- BASELINE configs[4]'s mode: fp8 (e4m3) attention, bf16 GEMMs ------------------------------------------------------------------
+# The reference has no fp8 path (block.py:129 is plain SDPA), so the contract is the bf16 result within a STATED tolerance:
+#   <= 1e-2 per velocity prediction, <= 2e-3 on the final latents (full depth, against the fp32 oracle).
+# Measured on MI355X (round 3, profiles/r03a_bench_attnfp8_512.json): 8.1e-3 mean / 8.9e-3 max per forward, 1.71e-3 final latents.
+# The e4m3 GEMMs (model_config gemm_fp8, `bench.py --fp8`) do NOT hold it -- 1.0e-1 per forward, whatever the scaling recipe
+# (tools/fp8_ablation.py, profiles/r03a_fp8_ablation.json) -- and are kept as an explicitly lossy option.
+FP8_ATTN_NOISE_PRED_MEAN = 1.0e-2
+FP8_ATTN_NOISE_PRED_MAX = 1.1e-2
+FP8_ATTN_FINAL_LATENT = 2.0e-3
+
+
+def test_full_depth_parity_fp8_attention_512():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=3, model_config={"union_cond_attn": True, "attn_fp8": True})
+    print("PARITY_FP8ATTN_512 " + json.dumps(rec))
+    assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= FP8_ATTN_NOISE_PRED_MAX, rec
+    assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT and rec["final_latent_cosine"] > 0.99999, rec
+
+
+def test_full_depth_parity_fp8_attention_1024():
+    """The shape configs[4] names: 1024x1024 (S = 8704), teacher-forced comparison at every 7th step + the free-running loop."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=7, hw=64, model_config={"union_cond_attn": True, "attn_fp8": True})
+    print("PARITY_FP8ATTN_1024 " + json.dumps(rec))
+    assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= 1.2e-2, rec
+    assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT, rec
+
+
+def test_fp8_gemm_mode_is_lossy_and_says_so():
+    """gemm_fp8 (e4m3 operands in every block GEMM): ~1e-1 per forward at full depth. Asserted as a band so that neither a silent
+    regression nor a silent 'improvement' of the documented figure goes unnoticed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=9, model_config={"union_cond_attn": True, "gemm_fp8": True})
+    print("PARITY_FP8GEMM_512 " + json.dumps(rec))
+    assert 5e-2 < rec["noise_pred_relerr_mean"] < 2e-1, rec
