@@ -307,9 +307,11 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
             res["roofline"]["frac_at_measured_clock"] = round(ach / pw_rec["mfma_peak_at_measured_clock_TFLOPs"], 4)
         if at:
             aa = at["flops"] / (at["ms"] * 1e-3) / 1e12
-            apeak = PEAK_FP8_TFLOPS if attn_fp8 else (157.3 if precise else PEAK_BF16_TFLOPS)
+            f32_attn = precise and os.environ.get("LX_PRECISE_ATTN", "split") == "f32"
+            apeak = PEAK_FP8_TFLOPS if attn_fp8 else (157.3 if f32_attn else PEAK_BF16_TFLOPS)
             aname = ("lx_attn_fp8_pipe_kernel (e4m3 32x32x64 MFMA)" if attn_fp8 else
-                     "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if precise
+                     "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if f32_attn else
+                     "attn_split_kernel (bf16 32x32x16 MFMA, 3 cross terms per product: achieved counts ALGORITHMIC flops, the MFMAs do 3x)" if precise
                      else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream)")
             res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
                                          "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],

@@ -109,6 +109,17 @@ typedef struct lx_gemm_desc {
                               * independent_condition / union_cond_attn = False -- then keeps its keys and values across denoise steps) */
   int32_t qkv_d, qkv_vt_ld, qkv_vt_pos0;   /* qkv_vt_ld, qkv_vt_pos0 % 64 == 0 */
   int32_t qkv_k_ld;          /* % 8 == 0, >= qkv_d */
+  /* LX_EPI_QKV with e4m3 outputs, for the fp8 attention path (lx_attn_fwd_fp8; BASELINE configs[4]): when qkv_q8 is non-NULL the
+   * epilogue writes what lx_qkv_prep_fp8_segs would have made of this projection -- q and k (after RMSNorm + RoPE, in fp32) as
+   * bytes e4m3(x * qkv_q_scale) / e4m3(x * qkv_k_scale) into qkv_q8 / qkv_k8 [M, qkv_ld8] (head h at column h*128), v as
+   * e4m3(v * qkv_v_scale) into the byte V^T image qkv_vt8 [B * qkv_d/128, 128, qkv_vt_ld] whose 64-key tiles are in the f8f6f4
+   * MFMA's operand order (byte j = g*32 + p of a tile row: key (p>>4)*32 + 8*((p&15)>>2) + 4*g + (p&3)), at the same slot
+   * qkv_vt_pos0 -- and NOTHING in bf16: C's k / v / q columns, qkv_vt and qkv_k are then not written (qkv_vt may be NULL). */
+  void* qkv_q8;
+  void* qkv_k8;
+  void* qkv_vt8;
+  int32_t qkv_ld8;           /* % 16 == 0, >= qkv_d (the byte V^T image has qkv_vt_ld bytes per row) */
+  float qkv_q_scale, qkv_k_scale, qkv_v_scale;   /* > 0 */
 } lx_gemm_desc;
 
 #define LX_GEMM_MAX_GROUP 4
@@ -271,6 +282,24 @@ typedef struct lx_attn_f32_desc {
   float scale;
 } lx_attn_f32_desc;
 int lx_attn_fwd_f32(const lx_attn_f32_desc* d, void* stream);
+
+/* Precise-mode attention on the bf16 matrix pipe (the default of precise mode since round 3; lx_attn_fwd_f32 stays as the exact
+ * fp32-MFMA reference). Every operand is a bf16 PAIR x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 mantissa bits) and
+ * every product is evaluated as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 into one fp32 accumulation: 3/16 of the
+ * fp32-MFMA cost, relative error ~2^-16 per operand. Replaces F.scaled_dot_product_attention of block.py:129-131 in the reference's
+ * shipped fp32 configuration (train/config/seed_512.yaml:2).
+ *
+ * lx_qkv_prep_split_segs: fp32 projections QKV [M, ld] (q at q_col, k at k_col, v at v_col; head h at + h*128) -> per-head RMSNorm +
+ * RoPE of q and k in fp32 (block.py:38-41,60-67,74-78,92-99; segments as in lx_qkv_prep_segs), written as pairs into QK2 (bf16
+ * [M, ld2]: q_hi at q2_col + h*128, q_lo lo_off columns further; k likewise at k2_col), and v as a pair of V^T images in the layout
+ * lx_attn_fwd reads (VT2: bf16 [B*H, 128, vt_ld] with the 16-key interleave; the lo image vt_lo_off ELEMENTS after the hi image). */
+int lx_qkv_prep_split_segs(const float* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches, int H,
+                           float eps, void* QK2, int ld2, int q2_col, int k2_col, int lo_off, void* VT2, int vt_ld, long long vt_lo_off,
+                           void* stream);
+/* Joint attention (the lx_attn_fwd contract; n_qseg must be 0) on those pairs: d->Q / d->K / d->VT are the hi images (q_col, k_col,
+ * ldq, ldk, vt_ld as in lx_attn_fwd), the lo images sit qk_lo_off columns / vt_lo_off elements further. fp32 online softmax with an
+ * exact running maximum. d->O (bf16, ldo) gets the output as a pair: hi at o_col + h*128 + d, lo o_lo_off columns further (0: hi only). */
+int lx_attn_fwd_split(const lx_attn_desc* d, int qk_lo_off, long long vt_lo_off, int o_lo_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 GEMM path (LX_OPERANDS_FP8; BASELINE configs[4], opt-in model_config["gemm_fp8"]): producers of the e4m3 operand images.

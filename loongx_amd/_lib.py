@@ -34,7 +34,9 @@ class GemmDesc(C.Structure):
                 ("col_scale", C.c_void_p),
                 ("qkv_norm_q", C.c_void_p), ("qkv_norm_k", C.c_void_p), ("qkv_rope", C.c_void_p), ("qkv_vt", C.c_void_p),
                 ("qkv_k", C.c_void_p),
-                ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("qkv_k_ld", C.c_int32)]
+                ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("qkv_k_ld", C.c_int32),
+                ("qkv_q8", C.c_void_p), ("qkv_k8", C.c_void_p), ("qkv_vt8", C.c_void_p),
+                ("qkv_ld8", C.c_int32), ("qkv_q_scale", C.c_float), ("qkv_k_scale", C.c_float), ("qkv_v_scale", C.c_float)]
 
 
 class AttnDesc(C.Structure):
@@ -90,6 +92,8 @@ _SIGS = {
     "lx_ln_modulate_split_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _I, _F, _P]),
     "lx_qkv_prep_f32_segs": (C.c_int, [_P, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P]),
     "lx_attn_fwd_f32": (C.c_int, [C.POINTER(AttnF32Desc), _P]),
+    "lx_qkv_prep_split_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _I, _I, _I, _P, _I, C.c_longlong, _P]),
+    "lx_attn_fwd_split": (C.c_int, [C.POINTER(AttnDesc), _I, C.c_longlong, _I, _P]),
     "lx_groupnorm_workspace_bytes": (_Z, [_I, _I, _I]),
     "lx_groupnorm_silu": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _Z, _P]),
     "lx_im2col3x3": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),

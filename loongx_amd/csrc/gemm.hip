@@ -212,6 +212,34 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 
       }
     __builtin_amdgcn_wave_barrier();
   };
+  const bool f8 = P.qkv_q8 != nullptr;              // e4m3 images for the fp8 attention kernel instead of the bf16 outputs
+  if (kind == 1 && f8) {
+    // v -> byte V^T image: a 32-key block is one half of a 64-key tile row; in the f8f6f4 operand order (byte j = g*32 + p holds key
+    // (p>>4)*32 + 8*((p&15)>>2) + 4g + (p&3)) that half is bytes [half*16, +16) of each 32-byte group g. Lane = head dim: per block
+    // two 16-byte stores per lane; the patch is read down a column (lanes on consecutive addresses: conflict-free).
+    const int h = (nw0 - D) >> 7, d0 = (nw0 - D) & 127, H = D >> 7;
+    const float vs = P.qkv_v_scale;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = mw0 + i * 32;
+      if (mb >= M) continue;
+      to_patch(i);
+      const int gm = m_base + mb, b = gm / L, p0 = gm - b * L;
+      uint8_t* vtb = (uint8_t*)P.qkv_vt8 + ((size_t)(b * H + h) * 128 + d0 + lane) * P.qkv_vt_ld + P.qkv_vt_pos0 + (p0 & ~63) + ((p0 >> 5) & 1) * 16;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float e[16];
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) e[pp] = patch[(8 * (pp >> 2) + 4 * g + (pp & 3)) * EP_LD + lane] * vs;
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack_fp8x4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+        *(u32x4*)(vtb + g * 32) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   if (kind == 1) {
     // v: 32 keys x 64 head dims per block -> V^T rows of 32 slots (64 B), 16 B per lane
     const int h = (nw0 - D) >> 7, d0 = (nw0 - D) & 127, H = D >> 7;
@@ -256,6 +284,8 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 
   const int ncol = nw0 + c8;                         // (k columns start at 0: the same column in a separate key image)
   uint16_t* const out = (kind == 0 && P.qkv_k) ? (uint16_t*)P.qkv_k : (uint16_t*)P.C;
   const int out_ld = (kind == 0 && P.qkv_k) ? P.qkv_k_ld : P.ldc;
+  uint8_t* const out8 = f8 ? (kind == 0 ? (uint8_t*)P.qkv_k8 : (uint8_t*)P.qkv_q8) + (ncol - kind * D) : nullptr;
+  const float sc8 = kind == 0 ? P.qkv_k_scale : P.qkv_q_scale;
   const float* own = ssq + wave * (BM / 2);
   const float* oth = ssq + (wave ^ 1) * (BM / 2);
   // RoPE rows of a 32-row block: 8 x 16 B per lane. vmcnt is one in-order queue of loads AND stores (see gemm_epilogue): the rows
@@ -299,8 +329,13 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const lx_gemm_desc& P, f32x16 
         y[2 * q] = x[2 * q] * co - x[2 * q + 1] * si;
         y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
       }
-      u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-      *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
+      if (f8) {                                      // (tile-uniform; the same four stores per block as the bf16 form: the vmcnt counts hold)
+        u32x2 o8 = {pack_fp8x4(y[0] * sc8, y[1] * sc8, y[2] * sc8, y[3] * sc8), pack_fp8x4(y[4] * sc8, y[5] * sc8, y[6] * sc8, y[7] * sc8)};
+        *(u32x2*)(out8 + (size_t)m * P.qkv_ld8) = o8;
+      } else {
+        u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1147,6 +1182,10 @@ static lx_gemm_desc sub_rows(const lx_gemm_desc& p, int r0, int rows) {   // row
   q.C = epi == LX_EPI_STORE_BF16 ? (void*)((uint16_t*)p.C + (size_t)r0 * p.ldc) : (void*)((float*)p.C + (size_t)r0 * p.ldc);
   if (p.lora_t) q.lora_t = p.lora_t + (size_t)r0 * p.lora_ldt;
   if (p.qkv_k) q.qkv_k = (uint16_t*)p.qkv_k + (size_t)r0 * p.qkv_k_ld;
+  if (p.qkv_q8) {
+    q.qkv_q8 = (uint8_t*)p.qkv_q8 + (size_t)r0 * p.qkv_ld8;
+    q.qkv_k8 = (uint8_t*)p.qkv_k8 + (size_t)r0 * p.qkv_ld8;
+  }
   q.M = rows;
   return q;
 }
@@ -1235,8 +1274,14 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
       LX_CHECK_ARG(!fp8 && segs == 1 && !(p.epilogue & LX_EPI_SPLIT_BF16) && epi == LX_EPI_STORE_BF16, "lx_gemm_bf16[%d]: LX_EPI_QKV goes with plain bf16 operands and LX_EPI_STORE_BF16", i);
       LX_CHECK_ARG(p.qkv_d > 0 && p.qkv_d % BN == 0 && (p.N >= 3 * p.qkv_d || p.N % BN == 0), "lx_gemm_bf16[%d]: LX_EPI_QKV needs qkv_d %% 256 == 0 and whole projection tiles (qkv_d=%d N=%d)", i, p.qkv_d, p.N);
       LX_CHECK_ARG(p.rows_per_batch % 32 == 0 && p.M % 32 == 0, "lx_gemm_bf16[%d]: LX_EPI_QKV needs rows_per_batch %% 32 == 0 and M %% 32 == 0 (%d, %d)", i, p.rows_per_batch, p.M);
-      LX_CHECK_ARG(p.qkv_norm_q && p.qkv_norm_k && p.qkv_vt && p.qkv_rope && ((uintptr_t)p.qkv_norm_q & 15) == 0 && ((uintptr_t)p.qkv_norm_k & 15) == 0 && ((uintptr_t)p.qkv_vt & 15) == 0 &&
+      const bool q8 = p.qkv_q8 != nullptr;
+      LX_CHECK_ARG(p.qkv_norm_q && p.qkv_norm_k && (p.qkv_vt || q8) && p.qkv_rope && ((uintptr_t)p.qkv_norm_q & 15) == 0 && ((uintptr_t)p.qkv_norm_k & 15) == 0 && ((uintptr_t)p.qkv_vt & 15) == 0 &&
                    ((uintptr_t)p.qkv_rope & 15) == 0, "lx_gemm_bf16[%d]: LX_EPI_QKV needs 16-byte aligned qkv_norm_q / qkv_norm_k / qkv_rope / qkv_vt", i);
+      if (q8) {
+        LX_CHECK_ARG(p.qkv_k8 && p.qkv_vt8 && (((uintptr_t)p.qkv_q8 | (uintptr_t)p.qkv_k8 | (uintptr_t)p.qkv_vt8) & 15) == 0 && p.qkv_ld8 % 16 == 0 && p.qkv_ld8 >= p.qkv_d,
+                     "lx_gemm_bf16[%d]: LX_EPI_QKV e4m3 outputs need 16-byte aligned qkv_q8 / qkv_k8 / qkv_vt8 and qkv_ld8 %% 16 == 0, >= qkv_d", i);
+        LX_CHECK_ARG(p.qkv_q_scale > 0.f && p.qkv_k_scale > 0.f && p.qkv_v_scale > 0.f && !p.qkv_k, "lx_gemm_bf16[%d]: LX_EPI_QKV e4m3 outputs need positive scales and no separate bf16 key image", i);
+      }
       LX_CHECK_ARG(p.qkv_vt_ld > 0 && p.qkv_vt_ld % 64 == 0 && p.qkv_vt_pos0 >= 0 && p.qkv_vt_pos0 % 64 == 0 && p.qkv_vt_pos0 + p.rows_per_batch <= p.qkv_vt_ld,
                    "lx_gemm_bf16[%d]: qkv_vt_ld / qkv_vt_pos0 must be multiples of 64 with the stream inside a V^T row", i);
       if (p.qkv_k) LX_CHECK_ARG(((uintptr_t)p.qkv_k & 15) == 0 && p.qkv_k_ld % 8 == 0 && p.qkv_k_ld >= p.qkv_d, "lx_gemm_bf16[%d]: qkv_k must be 16-byte aligned with qkv_k_ld %% 8 == 0, >= qkv_d", i);

@@ -147,6 +147,21 @@ class DiTEngine:
         self.Y32 = torch.zeros(self.M, 3 * D, dtype=torch.float32, device=dev)
         self.YA = torch.zeros(self.M, 10 * D, dtype=bf16, device=dev)
         self.lat2 = torch.zeros(self.B * self.N, 2 * self.cfg.in_channels, dtype=bf16, device=dev)
+        # precise attention on the bf16 matrix pipe (lx_attn_fwd_split): q / k after RMSNorm + RoPE and v^T as bf16 hi / lo pairs
+        #   QK2 bf16 [M, 4D] = [k_hi | k_lo | q_hi | q_lo];  VT2 bf16 [2, B, H, 128, slots] = the hi and the lo V^T image
+        # LX_PRECISE_ATTN=f32: the exact fp32-MFMA kernel (lx_attn_fwd_f32: 1/16 of the bf16 matrix rate, half of a precise step)
+        self.precise_attn_split = os.environ.get("LX_PRECISE_ATTN", "split") != "f32"
+        if self.precise_attn_split:
+            self.QK2 = torch.zeros(self.M, 4 * D, dtype=bf16, device=dev)
+            self.VT2 = torch.zeros((2,) + tuple(self.VT.shape), dtype=bf16, device=dev)
+
+    def _fp8_images(self) -> None:
+        """Q8 / K8 u8 [M, D], VT8 u8 [B, H, 128, slots]: the e4m3 operand images of the fp8 attention path (model_config attn_fp8)."""
+        if self.Q8 is None:
+            u8, D = torch.uint8, self.cfg.inner_dim
+            self.Q8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
+            self.K8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
+            self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
 
     def set_lora_scale(self, s: float) -> None:
         """Multiplier on every adapter term (reference lora_controller.py: scale_layer). Changes what the captured step graphs
@@ -336,11 +351,8 @@ class DiTEngine:
         self.gemm_fp8 = bool(self.model_config.get("gemm_fp8", False)) and not self.precise
         if self.gemm_fp8:
             self._setup_fp8()
-        if self.model_config.get("attn_fp8", False) and not self.precise and self.Q8 is None:      # never first allocated inside a capture
-            u8 = torch.uint8
-            self.Q8 = torch.zeros(self.M, cfg.inner_dim, dtype=u8, device=self.device)
-            self.K8 = torch.zeros(self.M, cfg.inner_dim, dtype=u8, device=self.device)
-            self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
+        if self.model_config.get("attn_fp8", False) and not self.precise:
+            self._fp8_images()                                                                    # never first allocated inside a capture
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
@@ -482,7 +494,10 @@ class DiTEngine:
                 rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
                 kw["qkv"] = dict(norm_q=qkv[2] if s == "txt" else qkv[0], norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
                                  vt=self.VT, vt_pos0=self.vt0[s], d=self.cfg.inner_dim)
-                if self.cond_cache and len(qkv) > 4:      # per-layer key / V^T images: the condition rows' entries outlive the step
+                if self.model_config.get("attn_fp8", False):      # e4m3 q / k / V^T images straight from the accumulators
+                    self._fp8_images()
+                    kw["qkv"].update(q8=self.rows(self.Q8, s), k8=self.rows(self.K8, s), vt=self.VT8)
+                elif self.cond_cache and len(qkv) > 4:      # per-layer key / V^T images: the condition rows' entries outlive the step
                     kw["qkv"].update(k=self.rows(self.KC[qkv[4]], s), vt=self.VTC[qkv[4]])
             if gate_off is not None:
                 mods = self.cmods if s == "cond" else self.mods
@@ -517,7 +532,12 @@ class DiTEngine:
         self.qkv_fused = bool(ok)
 
     def _qkv_epilogue(self) -> bool:
-        return (self.qkv_fused and not self.precise and not self.gemm_fp8 and not self.model_config.get("attn_fp8", False))
+        """The projection launch normalises / rotates k and q and writes V^T itself (LX_EPI_QKV). With model_config attn_fp8 (and bf16
+        GEMMs) the same epilogue emits the e4m3 images the fp8 attention kernel reads instead of the bf16 ones (LX_QKV_FUSED_FP8=0:
+        the separate lx_qkv_prep_fp8_segs pass)."""
+        if not self.qkv_fused or self.precise or self.gemm_fp8:
+            return False
+        return not self.model_config.get("attn_fp8", False) or os.environ.get("LX_QKV_FUSED_FP8", "1") != "0"
 
     def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False, layer: Optional[int] = None) -> None:
         cfg = self.cfg
@@ -545,12 +565,9 @@ class DiTEngine:
         if self.model_config.get("attn_fp8", False):
             # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
-            if self.Q8 is None:
-                u8 = torch.uint8
-                self.Q8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
-                self.K8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
-                self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
-            ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8)
+            self._fp8_images()
+            if not prepped:                # otherwise the projection epilogue already wrote the three byte images
+                ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8)
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                              seg_vt0=seg_vt0, bias=bias)
             return
@@ -885,8 +902,14 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            qsegs.append((row0, L, 0, wq_txt if s_ == "txt" else wq, wk_txt if s_ == "txt" else wk, cos, sin))
+            qsegs.append((row0, L, self.vt0[s_], wq_txt if s_ == "txt" else wq, wk_txt if s_ == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L)
+        if self.precise_attn_split:
+            # split-bf16 attention: hi.hi + hi.lo + lo.hi on the bf16 MFMA (3/16 of the fp32-MFMA cost), fp32 softmax
+            ops.qkv_prep_split_segs(self.Y32, 2 * D, 0, D, qsegs, B, H, self.QK2, q2_col=2 * D, k2_col=0, lo_off=D, VT2=self.VT2)
+            ops.attn_fwd_split(self.QK2, self.VT2, self.YA, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=5 * D, B=B, H=H,
+                               seg_row0=seg_row0, seg_len=seg_len, seg_vt0=[q[2] for q in qsegs], bias=bias)
+            return
         ops.qkv_prep_f32_segs(self.Y32, 2 * D, 0, qsegs, B, H)
         ops.attn_fwd_f32(self.Y32, self.YA, q_col=2 * D, k_col=0, v_col=D, o_col=0, o_lo_off=5 * D, B=B, H=H, seg_row0=seg_row0,
                          seg_len=seg_len, bias=bias)
@@ -1053,7 +1076,8 @@ class DiTEngine:
         """The condition stream is step-invariant and this kernel set can keep its keys / values per layer: condition queries
         masked from text and image keys (block.py:106-120), the fused projection epilogue in use (it writes the per-layer
         images), no add_cond_attn (which also needs the condition stream's attention OUTPUT every step)."""
-        if not (self.cond_cache_enabled and self.C and self._qkv_epilogue()) or self.model_config.get("add_cond_attn", False):
+        if (not (self.cond_cache_enabled and self.C and self._qkv_epilogue()) or self.model_config.get("add_cond_attn", False)
+                or self.model_config.get("attn_fp8", False)):          # (the per-layer images are bf16: the fp8 attention recomputes)
             return False
         ab = self.attn_bias["cond"]
         return ab["txt"] == NEG_INF and ab["img"] == NEG_INF
@@ -1110,6 +1134,8 @@ class DiTEngine:
         self.precise = bool(self.model_config.get("precise", self.precise_default))
         if self.precise:
             self._setup_precise()
+        elif self.model_config.get("attn_fp8", False):
+            self._fp8_images()
         self.attn_bias = self._attn_bias()
         f32 = torch.float32
         if rope_main is not None:

@@ -107,20 +107,29 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         # qkv = dict(norm_q=[128] f32, norm_k=[128] f32, rope=[rows_per_batch, 128] f32 (cos, sin) pairs, vt=V^T image,
         #            vt_pos0=first slot of this stream in a V^T row, d=inner dim)
         _req(qkv["norm_q"], torch.float32, "qkv.norm_q"); _req(qkv["norm_k"], torch.float32, "qkv.norm_k")
-        _req(qkv["vt"], torch.bfloat16, "qkv.vt")
+        f8 = qkv.get("q8") is not None      # e4m3 images for lx_attn_fwd_fp8 instead of the bf16 outputs
+        _req(qkv["vt"], torch.uint8 if f8 else torch.bfloat16, "qkv.vt")
         rope = qkv["rope"]
         _req(rope, torch.float32, "qkv.rope")
         assert rope.is_contiguous() and rope.shape == (d.rows_per_batch, 128), (rope.shape, d.rows_per_batch)
         assert qkv["vt"].is_contiguous()
-        d.qkv_norm_q, d.qkv_norm_k, d.qkv_rope, d.qkv_vt = _p(qkv["norm_q"]), _p(qkv["norm_k"]), _p(rope), _p(qkv["vt"])
+        d.qkv_norm_q, d.qkv_norm_k, d.qkv_rope = _p(qkv["norm_q"]), _p(qkv["norm_k"]), _p(rope)
         d.qkv_d, d.qkv_vt_ld, d.qkv_vt_pos0 = int(qkv["d"]), qkv["vt"].shape[-1], int(qkv["vt_pos0"])
+        if f8:      # qkv = dict(..., q8=[M, ld8] u8, k8=[M, ld8] u8, vt=byte V^T image): the scales are the fp8 attention path's constants
+            q8, k8 = qkv["q8"], qkv["k8"]
+            _req(q8, torch.uint8, "qkv.q8"); _req(k8, torch.uint8, "qkv.k8")
+            assert q8.shape[0] == d.M and k8.shape[0] == d.M and q8.stride(0) == k8.stride(0) and q8.stride(1) == 1 and k8.stride(1) == 1
+            d.qkv_q8, d.qkv_k8, d.qkv_vt8, d.qkv_ld8 = q8.data_ptr(), k8.data_ptr(), qkv["vt"].data_ptr(), q8.stride(0)
+            d.qkv_q_scale, d.qkv_k_scale, d.qkv_v_scale = FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE
+        else:
+            d.qkv_vt = _p(qkv["vt"])
         d.epilogue = epilogue = epilogue | LX_EPI_QKV
         kimg = qkv.get("k")                 # optional separate key image [M, ld]
         if kimg is not None:
             _req(kimg, torch.bfloat16, "qkv.k")
             assert kimg.shape[0] == d.M and kimg.stride(1) == 1
             d.qkv_k, d.qkv_k_ld = kimg.data_ptr(), kimg.stride(0)
-        d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"], kimg)     # the descriptor holds raw pointers: keep temporaries alive until launch
+        d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"], kimg, qkv.get("q8"), qkv.get("k8"))     # the descriptor holds raw pointers: keep temporaries alive until launch
     kind = epilogue & 0xff
     want = torch.bfloat16 if kind == LX_EPI_STORE_BF16 else (torch.uint8 if kind == LX_EPI_STORE_FP8 else torch.float32)
     _req(C_, want, "C")
@@ -407,6 +416,36 @@ def attn_fwd_f32(QKV, O, *, q_col, k_col, v_col, o_col, o_lo_off, B, H, seg_row0
         e.record()
         return
     check(lib.lx_attn_fwd_f32(C.byref(d), _stream()), "lx_attn_fwd_f32")
+
+
+def qkv_prep_split_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, QK2, q2_col, k2_col, lo_off, VT2, eps=1e-6) -> None:
+    """segs as in qkv_prep_segs. QKV fp32 [M, ld] (raw projections) -> QK2 bf16 [M, ld2] (q / k after RMSNorm + RoPE as hi / lo pairs:
+    hi at q2_col / k2_col + h*128, lo lo_off columns further) and VT2 bf16 [2, B, H, 128, Spad] (the hi and the lo V^T image)."""
+    _req(QKV, torch.float32, "QKV"); _req(QK2, torch.bfloat16, "QK2"); _req(VT2, torch.bfloat16, "VT2")
+    assert VT2.dim() == 5 and VT2.shape[0] == 2 and VT2.is_contiguous() and QK2.stride(1) == 1
+    n = len(segs)
+    arr = (L.QkvSeg * n)()
+    for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
+        arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, vt0
+        arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
+    check(lib.lx_qkv_prep_split_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, QK2.data_ptr(), QK2.stride(0),
+                                     q2_col, k2_col, lo_off, VT2.data_ptr(), VT2.shape[-1], VT2.stride(0), _stream()), "lx_qkv_prep_split_segs")
+
+
+def attn_fwd_split(QK2, VT2, O, *, q_col, k_col, qk_lo_off, o_col, o_lo_off, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+    """Precise-mode attention on the bf16 matrix pipe: q / k pairs in QK2 (hi at q_col / k_col, lo qk_lo_off columns further), the two V^T
+    images in VT2 [2, B, H, 128, Spad]; O bf16 gets the output pair (hi at o_col, lo o_lo_off columns further)."""
+    _req(QK2, torch.bfloat16, "QK2"); _req(VT2, torch.bfloat16, "VT2"); _req(O, torch.bfloat16, "O")
+    d = _attn_desc(QK2, QK2, VT2, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
+    args = (C.byref(d), qk_lo_off, VT2.stride(0), o_lo_off, _stream())
+    if TIMER is not None and TIMER.active:
+        S = sum(seg_len)
+        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        s.record()
+        check(lib.lx_attn_fwd_split(*args), "lx_attn_fwd_split")
+        e.record()
+        return
+    check(lib.lx_attn_fwd_split(*args), "lx_attn_fwd_split")
 
 
 def euler_step(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> None:

@@ -11,8 +11,11 @@ from oracle import flux_modules as fm  # noqa: E402
 from oracle import flux_ref as fr  # noqa: E402
 from tests.helpers import load, relerr, tiny_transformer  # noqa: E402
 
-TOL_BLOCK = 1.2e-2    # one block, bf16 GEMM operands vs fp32
-TOL_FWD = 2.5e-2
+# Tolerances = 2x what an MI355X measures against the reference-generated goldens (round-3 audit, LX_TEST_RECORD: gpurun_out/r03b):
+TOL_ATTN = 1.2e-2     # attn_forward mirrors (bf16 q / k / v, one attention + projections): measured 5.2e-3 .. 5.9e-3
+TOL_BLOCK = 3.6e-3    # one whole block on the fp32 residual stream: measured 1.5e-3 .. 1.8e-3
+TOL_FWD = 8.4e-3      # 2 + 2 blocks, embedders, final layer: measured 4.2e-3
+TOL_GEN = 3.2e-3      # 4-step denoise loops (the error of a velocity enters the latents times d sigma): measured 1.2e-3 .. 1.6e-3
 
 
 @pytest.fixture(scope="module")
@@ -58,10 +61,10 @@ def test_attn_forward_mirror(G, lx, mode):
             d.c_factor = s.c_factor = torch.ones(1, 1) * cf
         r = attn_forward(d, cu(G["hid"]), cu(G["enc"]), cu(G["cond"]), None, main, cond, mc)
         for got, key in zip(r, ("hid", "enc", "cond")):
-            assert relerr(got.cpu(), G[f"attn_d_{mode}_{key}"]) < TOL_BLOCK, key
+            assert relerr(got.cpu(), G[f"attn_d_{mode}_{key}"]) < TOL_ATTN, key
         r = attn_forward(s, cu(torch.cat([G["enc"], G["hid"]], 1)), None, cu(G["cond"]), None, main, cond, mc)
         for got, key in zip(r, ("hid", "cond")):
-            assert relerr(got.cpu(), G[f"attn_s_{mode}_{key}"]) < TOL_BLOCK, key
+            assert relerr(got.cpu(), G[f"attn_s_{mode}_{key}"]) < TOL_ATTN, key
     finally:
         for a in (d, s):
             if hasattr(a, "c_factor"):
@@ -73,11 +76,11 @@ def test_attn_forward_mirror_nocond(G, lx):
     tr, m = lx
     main, _ = _ropes(tr, G)
     r = attn_forward(m.transformer_blocks[0].attn, cu(G["hid"]), cu(G["enc"]), None, None, main, None, {})
-    assert len(r) == 2 and relerr(r[0].cpu(), G["attn_d_nocond_hid"]) < TOL_BLOCK and relerr(r[1].cpu(), G["attn_d_nocond_enc"]) < TOL_BLOCK
+    assert len(r) == 2 and relerr(r[0].cpu(), G["attn_d_nocond_hid"]) < TOL_ATTN and relerr(r[1].cpu(), G["attn_d_nocond_enc"]) < TOL_ATTN
     s = m.single_transformer_blocks[0].attn
     s.text_len = 16
     r = attn_forward(s, cu(torch.cat([G["enc"], G["hid"]], 1)), None, None, None, main, None, {})
-    assert relerr(r.cpu(), G["attn_s_nocond_hid"]) < TOL_BLOCK
+    assert relerr(r.cpu(), G["attn_s_nocond_hid"]) < TOL_ATTN
     with pytest.raises(NotImplementedError):
         attn_forward(s, cu(G["hid"]), None, None, torch.ones(1), main, None, {})
 
@@ -207,7 +210,7 @@ def test_generate_matches_oracle_loop():
                        default_lora=True, additional_condition1=sig.get("eeg"), additional_condition2=sig.get("fnirs"),
                        additional_condition3=sig.get("ppg"), additional_condition4=sig.get("motion"),
                        use_brain_condition=bool(sig), fuse_flag=fuse_flag, **({} if rule == "both" else {"brain_replace": rule}))
-        assert relerr(out.images.cpu(), want) < 3e-2, (fuse_flag, list(sig), rule)
+        assert relerr(out.images.cpu(), want) < TOL_GEN, (fuse_flag, list(sig), rule)
         outs[(fuse_flag, tuple(sig), rule)] = out.images.clone()
     # the literal rule ignores a lone EEG (== no signals at all); the per-stream rule does not
     assert torch.equal(outs[(False, ("eeg",), "both")], outs[(False, (), "both")])
@@ -239,7 +242,7 @@ def test_generate_matches_the_reference_generate_goldens(case):
                    additional_condition3=sig["ppg"], additional_condition4=sig["motion"], use_brain_condition=bool(use),
                    fuse_flag=fuse_flag, return_dict=False)
     assert isinstance(out, tuple)
-    assert relerr(out[0].cpu(), G[f"gen_{case}"]) < 3e-2
+    assert relerr(out[0].cpu(), G[f"gen_{case}"]) < TOL_GEN
     assert cond.position_delta == [0, -hw]                      # default subject delta, written back (condition.py:126-127)
     assert model.transformer.c_factor is None                   # removed again on exit (generate.py:384-388)
     assert torch.equal(pipe.scheduler.timesteps.cpu(), G["sched_timesteps"]) and torch.equal(pipe.scheduler.sigmas.cpu(), G["sched_sigmas"])
@@ -294,9 +297,9 @@ def test_generate_edge_cases_batch_nonsquare_callback_nocondition_errors():
               output_type="latent", model_config={}, default_lora=True, use_brain_condition=False)
     c = Condition("subject", latents=cond.cuda(), latent_hw=(H2, W2), position_delta=[0, -W2])
     out = generate(model, pipe, conditions=[c], latents=lat.cuda(), **kw)
-    assert out.images.shape == (B, H2 * W2, 64) and relerr(out.images.cpu(), want) < 3e-2
+    assert out.images.shape == (B, H2 * W2, 64) and relerr(out.images.cpu(), want) < TOL_GEN
     out_nc = generate(model, pipe, conditions=None, latents=lat.cuda(), **kw)
-    assert relerr(out_nc.images.cpu(), want_nc) < 3e-2 and relerr(out_nc.images.cpu(), want) > 1e-3
+    assert relerr(out_nc.images.cpu(), want_nc) < TOL_GEN and relerr(out_nc.images.cpu(), want) > 1e-3
     # callback: sees every step, may replace the latents (here: zero them after the last step)
     seen = []
 

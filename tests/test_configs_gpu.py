@@ -20,7 +20,7 @@ from tests.helpers import relerr  # noqa: E402
 from tests.test_kernels_gpu import BIASES, DEV, _attn_reference, _qkv_buffer, _segments, ops  # noqa: E402,F401
 
 D, H, T = 3072, 24, 512
-TOL_B4_ORACLE = 2e-2      # provisional: set to 2x the measured value
+TOL_B4_ORACLE = 3.1e-3    # 2x the measured 1.53e-3 (4 steps, 1 + 1 full-width blocks, batch 4; round-3 audit)
 
 
 def _model(dev="cuda"):

@@ -8,7 +8,7 @@ from oracle import flux_ref as fr  # noqa: E402
 from tests.helpers import load, relerr, tiny_transformer  # noqa: E402
 
 # bf16 GEMM operands / bf16 attention against an fp32 oracle on a 4-block model
-TOL = 2.5e-2
+TOL = 9e-3      # 2x the measured 4.0e-3 .. 4.5e-3 of a 2 + 2-block forward against the reference goldens (round-3 audit)
 
 
 def _engine(tr, lora_scale=1.0):

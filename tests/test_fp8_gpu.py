@@ -177,3 +177,129 @@ assert e < 7e-2, e
 '''
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "RELERR" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+# ---- LX_EPI_QKV with e4m3 outputs: the projection epilogue writes the fp8 attention kernel's operand images itself ------------------
+def _dq(img8, scale):
+    return img8.view(torch.float8_e4m3fn).float() / scale
+
+
+@pytest.mark.parametrize("bm", [256, 128])
+def test_gemm_qkv_epilogue_e4m3_images(ops, monkeypatch, bm):
+    """The byte images of the fused epilogue (q / k after RMSNorm + RoPE, V^T in the f8f6f4 operand order) against (a) an fp64
+    restatement of block.py:43-99 rounded once to e4m3 and (b) the images lx_qkv_prep_fp8_segs makes from the bf16 projection
+    (two roundings): the fused values are at least as close to (a) as the two-pass ones, the V^T bytes sit where the two-pass
+    kernel puts them, and the bf16 outputs are NOT written."""
+    from oracle.flux_modules import apply_rotary_emb, rope_tables
+    from loongx_amd import _lib
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    _lib.lib.lx_gemm_reload_env()
+    B, H, K = 2, 2, 192
+    D = H * 128
+    N = 3 * D + 512
+    lens = [96, 160]
+    row0, vt0, vt_ld = _segments(B, lens)
+    M = B * sum(lens)
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    Ws = [rnd(N, K, seed=2 + i, scale=K ** -0.5, dtype=torch.bfloat16) for i in range(2)]
+    bias = [rnd(N, seed=4 + i, scale=0.3) for i in range(2)]
+    wq = [1 + 0.1 * rnd(128, seed=6 + i) for i in range(2)]
+    wk = [1 + 0.1 * rnd(128, seed=8 + i) for i in range(2)]
+    tabs, cs_dev = [], []
+    for i, Ls in enumerate(lens):
+        ids = torch.zeros(Ls, 3)
+        ids[:, 1] = torch.arange(Ls) // 8 + i
+        ids[:, 2] = torch.arange(Ls) % 8 - 3 * i
+        cos, sin = rope_tables(ids)
+        tabs.append((cos, sin))
+        cs = torch.empty(Ls, 128)
+        cs[:, 0::2], cs[:, 1::2] = cos[:, 0::2], sin[:, 0::2]
+        cs_dev.append(cs.to(DEV))
+    u8 = torch.uint8
+
+    def run(fused):
+        C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        Q8, K8 = torch.zeros(M, D, dtype=u8, device=DEV), torch.zeros(M, D, dtype=u8, device=DEV)
+        VT8 = torch.zeros(B, H, 128, vt_ld, dtype=u8, device=DEV)
+        probs = []
+        for i, Ls in enumerate(lens):
+            rows = slice(row0[i], row0[i] + B * Ls)
+            kw = {}
+            if fused:
+                kw["qkv"] = dict(norm_q=wq[i], norm_k=wk[i], rope=cs_dev[i], vt=VT8, vt_pos0=vt0[i], d=D, q8=Q8[rows], k8=K8[rows])
+            probs.append(ops.gemm_desc(A[rows], Ws[i], C[rows], bias=bias[i], epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, rows_per_batch=Ls,
+                                       gelu_col_start=3 * D, **kw))
+        ops.gemm(probs)
+        if not fused:
+            segs = [(row0[i], Ls, vt0[i], wq[i], wk[i], tabs[i][0].to(DEV), tabs[i][1].to(DEV)) for i, Ls in enumerate(lens)]
+            ops.qkv_prep_fp8_segs(C, 2 * D, 0, D, segs, B, H, Q8, K8, VT8)
+        torch.cuda.synchronize()
+        return C.float().cpu(), Q8.cpu(), K8.cpu(), VT8.cpu()
+    Cf, Qf, Kf, Vf = run(True)
+    Cu, Qu, Ku, Vu = run(False)
+    assert torch.equal(Cf[:, 3 * D:], Cu[:, 3 * D:])                    # the GELU columns behind the projections: untouched by the flag
+    assert bool((Cf[:, :3 * D] == 7.0).all())                          # no bf16 k / v / q is written in this form
+    e4 = lambda x: x.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    for i, Ls in enumerate(lens):
+        rows = slice(row0[i], row0[i] + B * Ls)
+        y = A[rows].double().cpu() @ Ws[i].double().cpu().T + bias[i].double().cpu()
+        cos, sin = (t.double() for t in tabs[i])
+
+        def ref(x, w):
+            x = x.view(B, Ls, -1, 128).permute(0, 2, 1, 3)
+            x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double().cpu()
+            return apply_rotary_emb(x, (cos, sin)).permute(0, 2, 1, 3).reshape(B * Ls, -1)
+        for img_f, img_u, want, sc in ((Qf, Qu, ref(y[:, 2 * D:3 * D], wq[i]), ops.FP8_Q_SCALE), (Kf, Ku, ref(y[:, :D], wk[i]), ops.FP8_K_SCALE)):
+            ef, eu = relerr(_dq(img_f[rows], sc), want), relerr(_dq(img_u[rows], sc), want)
+            floor = relerr(e4(want.float() * sc) / sc, want)            # one e4m3 rounding of the exact value
+            assert ef < 1.03 * floor + 1e-3 and ef <= eu * 1.02, (ef, eu, floor)
+        # V^T bytes: same positions as the two-pass image; values = e4m3 of the fp32 accumulator (vs of its bf16 rounding)
+        v = y[:, D:2 * D].view(B, Ls, H, 128).float()
+        got, two = _dq(Vf, ops.FP8_V_SCALE), _dq(Vu, ops.FP8_V_SCALE)
+        j = torch.arange(64)
+        g_, p_ = j >> 5, j & 31
+        key = (p_ >> 4) * 32 + 8 * ((p_ & 15) >> 2) + 4 * g_ + (p_ & 3)
+        for t0 in range(0, Ls, 64):
+            valid = key + t0 < Ls
+            want_t = e4(v[:, (key[valid] + t0)]).permute(0, 2, 3, 1)     # [B, H, d, byte]
+            sl = (slice(None), slice(None), slice(None), vt0[i] + t0 + j[valid])
+            assert relerr(got[sl], want_t) < 2e-3 + 1.05 * relerr(two[sl], want_t), t0
+            assert relerr(got[sl], two[sl]) < 4e-2
+
+
+@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
+def test_engine_fp8_attention_with_fused_projection_epilogue(monkeypatch, mc):
+    """model_config attn_fp8 with bf16 GEMMs: the engine takes the e4m3 projection epilogue (no lx_qkv_prep_fp8_segs launch);
+    against the fp32 oracle and against the same engine with LX_QKV_FUSED_FP8=0 (the two-pass path)."""
+    from oracle import flux_modules as fm
+    from oracle import flux_ref as fr
+    from tests.helpers import tiny_transformer
+    from tests.test_engine_gpu import _engine
+    tr = tiny_transformer(seed=5)
+    g = torch.Generator().manual_seed(7)
+    B, T, hw = 2, 32, 8
+    N = hw * hw
+    kw = dict(hidden_states=torch.randn(B, N, 64, generator=g), encoder_hidden_states=torch.randn(B, T, 64, generator=g) * 0.5,
+              pooled_projections=torch.randn(B, 32, generator=g), timestep=torch.tensor([0.8, 0.3]),
+              img_ids=fm.prepare_latent_image_ids(hw, hw), txt_ids=torch.zeros(T, 3), guidance=torch.full((B,), 3.5))
+    cond = torch.randn(B, N, 64, generator=g)
+    cids = fm.prepare_latent_image_ids(hw, hw)
+    cids[:, 2] -= hw
+    with torch.no_grad():
+        want = fr.tranformer_forward(tr, cond, cids, None, mc, **kw)[0]
+    d = "cuda"
+    mc8 = dict(mc, attn_fp8=True)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LX_QKV_FUSED_FP8", fused)
+        eng = _engine(tr)
+        eng.set_conditioning(kw["encoder_hidden_states"].to(d), kw["pooled_projections"].to(d), kw["guidance"].to(d), kw["txt_ids"].to(d),
+                             kw["img_ids"].to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=mc8)
+        assert eng._qkv_epilogue() == (fused == "1")
+        a = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()
+        b = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()      # graph replay
+        assert torch.equal(a, b)
+        outs[fused] = a
+    e1, e0 = relerr(outs["1"], want), relerr(outs["0"], want)
+    assert e1 < TOL_FP8 and e0 < TOL_FP8 and e1 < 1.25 * e0 + 2e-3, (e1, e0)
+    assert relerr(outs["1"], outs["0"]) < TOL_FP8

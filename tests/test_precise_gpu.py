@@ -147,6 +147,98 @@ def test_qkv_prep_f32(ops):
         assert relerr(buf[:, col:col + D].view(B, L, H, 128), ref.float()) < 2e-6
 
 
+def _split_images(ops, buf, B, H, lens, wq=None, wk=None, cos=None, sin=None):
+    """[k | v | q] fp32 -> (QK2 [M, 4D] = [k_hi | k_lo | q_hi | q_lo], VT2 [2, B, H, 128, Spad], row0, vt0)"""
+    D = H * 128
+    row0, vt0, r, v = [], [], 0, 0
+    for L in lens:
+        row0.append(r); vt0.append(v)
+        r += B * L
+        v += (L + 63) // 64 * 64
+    QK2 = torch.zeros(buf.shape[0], 4 * D, dtype=torch.bfloat16, device=DEV)
+    VT2 = torch.zeros(2, B, H, 128, v, dtype=torch.bfloat16, device=DEV)
+    segs = [(row0[i], L, vt0[i], wq, wk, cos[i] if cos else None, sin[i] if sin else None) for i, L in enumerate(lens)]
+    before = buf.clone()
+    ops.qkv_prep_split_segs(buf, 2 * D, 0, D, segs, B, H, QK2, q2_col=2 * D, k2_col=0, lo_off=D, VT2=VT2)
+    assert torch.equal(buf, before)                                   # the fp32 projections are an input only
+    return QK2, VT2, row0, vt0
+
+
+def test_qkv_prep_split(ops):
+    """RMSNorm + RoPE in fp32, then hi / lo pairs that carry 16 mantissa bits; V^T pair images in the attention kernel's layout."""
+    B, L, H = 2, 70, 2
+    D = H * 128
+    buf = rnd(B * L, 3 * D, seed=3)
+    wq, wk = rnd(128, seed=4).abs() + 0.5, rnd(128, seed=5).abs() + 0.5
+    ids = torch.stack([torch.zeros(L), torch.arange(L).float() // 8, torch.arange(L).float() % 8], 1).to(DEV)
+    cos, sin = ops.rope_table(ids)
+    QK2, VT2, row0, vt0 = _split_images(ops, buf, B, H, [L], wq, wk, [cos], [sin])
+    for col2, col, w in ((2 * D, 2 * D, wq), (0, 0, wk)):
+        x = buf[:, col:col + D].view(B, L, H, 128).double()
+        x = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * w.double()
+        xr = torch.stack([-x[..., 1::2], x[..., 0::2]], -1).flatten(-2)
+        ref = (x * cos.double()[None, :, None, :] + xr * sin.double()[None, :, None, :]).float().view(B * L, D)
+        hi, lo = QK2[:, col2:col2 + D].float(), QK2[:, col2 + D:col2 + 2 * D].float()
+        assert relerr(hi + lo, ref) < 2e-6
+        assert torch.equal(lo, ((hi + lo) - hi).to(torch.bfloat16).float()) and relerr(hi, ref) > 1e-4      # a genuine pair, not hi alone
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    v = torch.zeros(B, 128, H, 128, device=DEV)
+    v[:, :L] = buf[:, D:2 * D].view(B, L, H, 128)
+    slots = (torch.arange(128) // 16) * 16 + perm[torch.arange(128) % 16]
+    expect = v[:, slots.to(DEV)].permute(0, 2, 3, 1)                  # [B, H, d, slot]
+    got = VT2[0].float() + VT2[1].float()
+    assert relerr(got, expect) < 2.0 ** -16 and torch.equal(VT2[0].float(), expect.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("lens,mode", [((16, 16, 16), "none"), ((40, 100, 70), "cfactor"), ((512, 1024, 1024), "none"),
+                                       ((512, 1024, 1024), "nounion"), ((96, 200), "none"), ((300,), "none")])
+def test_attention_split_bf16(ops, lens, mode):
+    """lx_attn_fwd_split (hi.hi + hi.lo + lo.hi on the bf16 MFMA, fp32 softmax) against fp64 attention on the same fp32 q / k / v:
+    fp32-class (the exact fp32-MFMA kernel's bound on the same cases is 2e-5), every mask mode, ragged segments."""
+    B, H = (2, 2) if sum(lens) < 1000 else (1, 3)
+    D = H * 128
+    ninf = float("-inf")
+    bias = {"none": [[0.0] * 3] * 3, "cfactor": [[0, 0, math.log(0.5)], [0, 0, math.log(0.5)], [math.log(0.5), math.log(0.5), 0]],
+            "nounion": [[0, 0, ninf], [0, 0, ninf], [ninf, ninf, 0]]}[mode]
+    M = B * sum(lens)
+    buf = rnd(M, 3 * D, seed=7)                                        # [k | v | q]; no norm / RoPE (weights None): q, k pass through
+    QK2, VT2, row0, vt0 = _split_images(ops, buf, B, H, list(lens))
+    O = torch.zeros(M, 2 * D + 64, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd_split(QK2, VT2, O, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=D + 64, B=B, H=H, seg_row0=row0, seg_len=list(lens),
+                       seg_vt0=vt0, bias=bias)
+    got = O[:, :D].float() + O[:, D + 64:2 * D + 64].float()
+
+    def gather(col):        # -> [B, H, S, 128]
+        parts = [buf[row0[i]:row0[i] + B * L, col:col + D].view(B, L, H, 128) for i, L in enumerate(lens)]
+        return torch.cat(parts, 1).permute(0, 2, 1, 3)
+    ref = _attn_ref(gather(2 * D), gather(0), gather(D), lens, bias).permute(0, 2, 1, 3)          # [B, S, H, 128]
+    e = 0
+    for i, L in enumerate(lens):
+        g = got[row0[i]:row0[i] + B * L].view(B, L, H, 128)
+        assert relerr(g, ref[:, e:e + L].float()) < 3e-5, f"segment {i}"
+        e += L
+    again = torch.zeros_like(O)
+    ops.attn_fwd_split(QK2, VT2, again, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=D + 64, B=B, H=H, seg_row0=row0,
+                       seg_len=list(lens), seg_vt0=vt0, bias=bias)
+    assert torch.equal(O, again)                                       # deterministic
+
+
+def test_attention_split_spiked_scores(ops):
+    """An outlier key (raw q.k far above the row's other scores) late in the sequence: the running maximum jumps and every
+    accumulator is rescaled; exact-max softmax must still agree with fp64."""
+    B, H, L = 1, 2, 512
+    D = H * 128
+    buf = rnd(B * L, 3 * D, seed=11)
+    buf[300, :128] = buf[17, 2 * D:2 * D + 128] * 6.0                 # key 300 of head 0 aligned with query 17
+    QK2, VT2, row0, vt0 = _split_images(ops, buf, B, H, [L])
+    O = torch.zeros(B * L, 2 * D, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd_split(QK2, VT2, O, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=D, B=B, H=H, seg_row0=row0, seg_len=[L], seg_vt0=vt0)
+    got = (O[:, :D].float() + O[:, D:].float()).view(B, L, H, 128)
+    q, k, v = (buf[:, c:c + D].view(B, L, H, 128).permute(0, 2, 1, 3) for c in (2 * D, 0, D))
+    ref = _attn_ref(q, k, v, (L,), [[0.0] * 3] * 3).permute(0, 2, 1, 3)
+    assert relerr(got, ref.float()) < 3e-5 and relerr(got[:, 17, 0], ref[:, 17, 0].float()) < 3e-5
+
+
 # ---------------------------------------------------------------------------------------------------- engine
 def _engine(tr, precise=True):
     from loongx_amd.flux.engine import DiTEngine
