@@ -179,7 +179,7 @@ def test_qkv_prep_split(ops):
         xr = torch.stack([-x[..., 1::2], x[..., 0::2]], -1).flatten(-2)
         ref = (x * cos.double()[None, :, None, :] + xr * sin.double()[None, :, None, :]).float().view(B * L, D)
         hi, lo = QK2[:, col2:col2 + D].float(), QK2[:, col2 + D:col2 + 2 * D].float()
-        assert relerr(hi + lo, ref) < 2e-6
+        assert relerr(hi + lo, ref) < 5e-6                           # a bf16 pair carries 16 mantissa bits: <= 2^-17 per element, ~2.5e-6 rms
         assert torch.equal(lo, ((hi + lo) - hi).to(torch.bfloat16).float()) and relerr(hi, ref) > 1e-4      # a genuine pair, not hi alone
     perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
     v = torch.zeros(B, 128, H, 128, device=DEV)
