@@ -33,7 +33,42 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct AttnArgs {
   lx_attn_desc d;
   int qt_start[4];   // prefix of (32*NW)-row query tiles per segment
+  int wide_store;    // O rows and columns are 16-byte aligned: the epilogue stores 16 B per lane (lx_store_o)
+  int prio_young;    // LX_ATTN_PRIO=1: one static s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration; guide T5 static form)
 };
+
+// Epilogue store of one query row per lane pair: O[q, d] = O^T / l; lane (q = lane & 31, half = lane >> 5) holds
+// d = db*32 + 8*rq + 4*half + (0..3), i.e. 8 bytes of bf16 per (db, rq), and the two halves of a row hold ADJACENT 8-byte groups.
+// wide: for each pair of groups (rq, rq+1) one v_permlane32_swap per dword hands the lower half-wave the upper half's group rq and
+// the upper half-wave the lower half's group rq+1: every lane then owns 16 contiguous bytes -> 8 dwordx4 stores per lane instead of
+// 16 dwordx2, same bytes, same addresses (the store tail of a row-per-lane epilogue is store-ISSUE bound: guide T21).
+__device__ __forceinline__ void lx_store_o(uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi, bool wide) {
+  if (wide) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq += 2) {
+        const uint32_t a0 = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        const uint32_t a1 = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        const uint32_t b0 = pack_bf16x2(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv);
+        const uint32_t b1 = pack_bf16x2(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        *(u32x4*)(row + db * 32 + 8 * (rq + lhi)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+  } else {
+    uint16_t* op = row + 4 * lhi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 o;
+        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        *(u32x2*)(op + db * 32 + rq * 8) = o;
+      }
+  }
+}
 
 // LX_ATTN_DEFER: rescale threshold in log2 units for the deferred running-max update (0 = always rescale).
 // While no row of the wave sees its tile maximum grow past the max in use by more than this, the stale max keeps being
@@ -222,18 +257,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const
   // ---- epilogue: O[q, d] = O^T / l ; lane holds d = db*32 + 8*(r>>2) + 4*lhi + (r&3) --------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_valid) {
-    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 o;
-        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
-        *(u32x2*)(op + db * 32 + rq * 8) = o;
-      }
-  }
+  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
 }
 
 
@@ -504,6 +529,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     ++t;                                                                                                               \
   }
 
+  if (args.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);      // wave is an SGPR value (readfirstlane): a real scalar branch
   int t = 0;
   if (t0.nvalid > 0) {
     piece(0, t0.krow, 0, t0.nclamp, 0); piece(1, t0.krow, 0, t0.nclamp, 0);
@@ -546,18 +572,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_valid) {
-    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 o;
-        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
-        *(u32x2*)(op + db * 32 + rq * 8) = o;
-      }
-  }
+  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
 }
 
 
@@ -741,18 +757,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  if (q_valid) {
-    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 o;
-        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
-        *(u32x2*)(op + db * 32 + rq * 8) = o;
-      }
-  }
+  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
 }
 
 
@@ -1082,21 +1088,17 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 
   const float l_tot = __shfl(lacc[0], l31, 64);          // lanes 0-31 hold the sum of query l31
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  if (q_valid) {
-    uint16_t* op = (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH + 4 * lhi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 o;
-        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
-        *(u32x2*)(op + db * 32 + rq * 8) = o;
-      }
-  }
+  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
 }
 
 }  // namespace
+
+// 16-byte epilogue stores need 16-byte aligned output rows and head columns (LX_ATTN_WIDE_STORE=0: always the 8-byte form, A/B)
+static int lx_attn_wide_store(const lx_attn_desc* d) {
+  static const bool on = [] { const char* e = getenv("LX_ATTN_WIDE_STORE"); return e ? atoi(e) != 0 : true; }();
+  return on && d->ldo % 8 == 0 && d->o_col % 8 == 0 && ((uintptr_t)d->O & 15) == 0;
+}
 
 extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG(d && d->Q && d->K && d->VT && d->O, "lx_attn_fwd: NULL operand");
@@ -1114,6 +1116,9 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
   AttnArgs a;
   a.d = *d;
+  a.wide_store = lx_attn_wide_store(d);
+  static const int prio = [] { const char* e = getenv("LX_ATTN_PRIO"); return e ? atoi(e) : 0; }();
+  a.prio_young = prio;
   int t = 0;
   for (int s = 0; s < 3; ++s) {
     a.qt_start[s] = t;
@@ -1156,6 +1161,8 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
   AttnArgs a;
   a.d = *d;
+  a.wide_store = lx_attn_wide_store(d);
+  a.prio_young = 0;
   int t = 0;
   for (int s = 0; s < 3; ++s) {
     a.qt_start[s] = t;
