@@ -47,3 +47,27 @@ def test_condition_unknown_type_raises():
         Condition("eeg+fnirs", condition=ducks.DuckImage(64, 64)).encode(ducks.DuckFluxPipeline(None))
     with pytest.raises(AssertionError):
         Condition("subject")
+
+
+def test_canny_and_depth_condition_types():
+    """condition.py:59-76: `canny` = cv2.Canny(img, 100, 200) (numpy restatement when cv2 is absent: binary 0 / 255 RGB, one-pixel
+    contours on the true boundary, nothing on flat input), `depth` = the transformers depth pipeline from a LOCAL model directory."""
+    import numpy as np
+    import pytest
+    from PIL import Image
+    from loongx_amd.flux.condition import Condition, canny_edges
+    a = np.zeros((64, 64, 3), np.uint8)
+    a[16:48, 16:48] = 200
+    e = np.array(canny_edges(Image.fromarray(a)))
+    assert e.shape == (64, 64, 3) and set(np.unique(e)) == {0, 255} and (e[..., 0] == e[..., 1]).all() and (e[..., 1] == e[..., 2]).all()
+    ys, xs = np.nonzero(e[..., 0])
+    on_boundary = np.minimum.reduce([abs(ys - 15.5), abs(ys - 47.5), abs(xs - 15.5), abs(xs - 47.5)]) <= 1.5
+    assert on_boundary.all() and 100 <= len(ys) <= 140                       # a thin closed contour around the 32 x 32 square (perimeter 128)
+    assert not np.array(canny_edges(Image.fromarray(np.full((32, 32, 3), 90, np.uint8)))).any()
+    weak = np.zeros((32, 32, 3), np.uint8)
+    weak[:, 16:] = 20                                                        # a step below the low threshold (|dx| = 4 * 20 = 80 < 100)
+    assert not np.array(canny_edges(Image.fromarray(weak))).any()
+    c = Condition("canny", raw_img=Image.fromarray(a))
+    assert c.condition.size == (64, 64) and c.condition.mode == "RGB" and c.type_id == Condition.get_type_id("canny")
+    with pytest.raises(FileNotFoundError):
+        Condition("depth", raw_img=Image.fromarray(a))
