@@ -153,6 +153,11 @@ int lx_gemm_workspace_status(void* workspace, void* stream);
  * spreads a tall-skinny product over the whole chip without atomics; the consumer (lx_gemm_bf16) adds the slabs. */
 int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
                  int split_stride, void* stream);
+/* The multi-term form (precise mode: x = x_hi + x_lo, A = A_hi [+ A_lo]): slab s of T (slab_stride floats apart, same row stride) =
+ * X[s][M, K] . Adown[s][R, K]^T over the whole K, for n_terms <= 4 (X, Adown) pairs in ONE launch; the consumer GEMM adds the slabs
+ * (lora_nsplit = n_terms). Same arithmetic per slab as lx_lora_down(X[s], ldx[s], Adown[s], T + s * slab_stride, ..., n_split = 1). */
+int lx_lora_down_terms(const void* const* X, const int* ldx, const void* const* Adown, int n_terms, float* T, int ldt, int M, int K, int R,
+                       int slab_stride, void* stream);
 
 /* Skinny linear for a few rows (AdaLayerNorm modulation linears, time/text embedders:
  * block.py:192-207,301,305; transformer.py:102-114,243).  Weight-streaming, HBM bound; rows are processed four at a

@@ -77,6 +77,7 @@ _SIGS = {
     "lx_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmDesc), _I, _P, _Z, _P]),
     "lx_gemm_workspace_status": (C.c_int, [_P, _P]),
     "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lx_lora_down_terms": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), _I, _P, _I, _I, _I, _I, _I, _P]),
     "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
     "lx_rope_table": (C.c_int, [_P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),

@@ -434,13 +434,25 @@ __global__ __launch_bounds__(256) void qkv_prep_fp8_kernel(const uint16_t* __res
 // Workgroup = 8 waves = 16 rows; the waves split K eight ways and reduce through LDS. A is the MFMA "A"
 // operand (rows = r), X the "B" operand (cols = m): each lane ends with 4 consecutive r of one row m.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void lora_down_mfma_kernel(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ A,
-                                                             float* __restrict__ T, int ldt, int M, int K, int R, int Ks,
+// blockIdx.y = slab: in the K-split form (lx_lora_down) slab s covers K range s; in the multi-term form (lx_lora_down_terms,
+// precise mode) slab s is a different (X, A) pair over the whole K -- the cross terms x_hi.A, x_lo.A, x_hi.A_lo in ONE launch.
+struct LoraTerms {
+  const uint16_t* X[4];
+  const uint16_t* A[4];
+  int ldx[4];
+  int n;                  // 0: K-split form (X[0], A[0]); > 0: one slab per term
+};
+
+__global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms terms, float* __restrict__ T, int ldt, int M, int K, int R, int Ks,
                                                              int split_stride) {
   __shared__ f32x4 red[8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
-  const int kbeg = blockIdx.y * Ks, kend = min(K, kbeg + Ks);
+  const int term = terms.n > 0 ? (int)blockIdx.y : 0;
+  const uint16_t* __restrict__ X = terms.X[term];
+  const uint16_t* __restrict__ A = terms.A[term];
+  const int ldx = terms.ldx[term];
+  const int kbeg = terms.n > 0 ? 0 : blockIdx.y * Ks, kend = terms.n > 0 ? K : min(K, kbeg + Ks);
   T += (size_t)blockIdx.y * split_stride;
   const int l15 = lane & 15, kq = lane >> 4;
   const uint16_t* xp = X + (size_t)min(m0 + l15, M - 1) * ldx + kq * 8;
@@ -713,9 +725,26 @@ extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T,
   LX_CHECK_ARG(n_split >= 1 && n_split <= 16 && (n_split == 1 || split_stride >= (M - 1) * ldt + R) && split_stride % 4 == 0,
                "lx_lora_down: bad n_split=%d / split_stride=%d", n_split, split_stride);
   const int Ks = ((K / 32 + n_split - 1) / n_split) * 32;
-  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)X, ldx,
-                     (const uint16_t*)Adown, T, ldt, M, K, R, Ks, split_stride);
+  LoraTerms lt = {};
+  lt.X[0] = (const uint16_t*)X; lt.A[0] = (const uint16_t*)Adown; lt.ldx[0] = ldx; lt.n = 0;
+  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, Ks, split_stride);
   LX_LAUNCH_CHECK("lx_lora_down");
+  return LX_OK;
+}
+
+extern "C" int lx_lora_down_terms(const void* const* X, const int* ldx, const void* const* Adown, int n_terms, float* T, int ldt, int M, int K,
+                                  int R, int slab_stride, void* stream) {
+  LX_CHECK_ARG(X && ldx && Adown && T && M > 0 && n_terms >= 1 && n_terms <= 4, "lx_lora_down_terms: bad arguments (1..4 terms)");
+  LX_CHECK_ARG(R >= 1 && R <= 16 && K % 32 == 0 && ldt >= R && ((uintptr_t)T & 15) == 0, "lx_lora_down_terms: R in [1,16], K %% 32, ldt >= R, T 16-byte aligned required");
+  LX_CHECK_ARG((n_terms == 1 || slab_stride >= (M - 1) * ldt + R) && slab_stride % 4 == 0, "lx_lora_down_terms: bad slab_stride=%d", slab_stride);
+  LoraTerms lt = {};
+  lt.n = n_terms;
+  for (int i = 0; i < n_terms; ++i) {
+    LX_CHECK_ARG(X[i] && Adown[i] && ldx[i] % 8 == 0 && ((uintptr_t)X[i] & 15) == 0 && ((uintptr_t)Adown[i] & 15) == 0, "lx_lora_down_terms: term %d: NULL / misaligned operand or ldx %% 8", i);
+    lt.X[i] = (const uint16_t*)X[i]; lt.A[i] = (const uint16_t*)Adown[i]; lt.ldx[i] = ldx[i];
+  }
+  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_terms), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, K, slab_stride);
+  LX_LAUNCH_CHECK("lx_lora_down_terms");
   return LX_OK;
 }
 

@@ -816,8 +816,8 @@ class DiTEngine:
         terms = [(A2[r0:r0 + n, :K], lo.down), (A2[r0:r0 + n, a_lo_off:a_lo_off + K], lo.down)]
         if lo.down_lo is not None:
             terms.append((A2[r0:r0 + n, :K], lo.down_lo))
-        for s_, (x, a) in enumerate(terms):
-            ops.lora_down(x, a, self.TLs[s_, r0:r0 + n, :R])
+        # one launch for the cross terms (slab s = term s; the consumer GEMM adds the slabs)
+        ops.lora_down_terms(terms, self.TLs[0, r0:r0 + n, :R], self.TLs.stride(0))
         if self.lora_scale != 1.0:
             self.TLs[: len(terms), r0:r0 + n, :R].mul_(self.lora_scale)
         return lo, len(terms)

@@ -210,6 +210,20 @@ def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor, n_split: in
                            Adown.shape[0], n_split, split_stride, _stream()), "lx_lora_down")
 
 
+def lora_down_terms(terms, T: torch.Tensor, slab_stride: int) -> None:
+    """terms: [(X [M,K] bf16, Adown [R,K] bf16), ...] (<= 4); slab s of T (fp32, slab_stride floats apart) = X_s . Adown_s^T: one launch."""
+    n = len(terms)
+    M, K = terms[0][0].shape
+    R = terms[0][1].shape[0]
+    xs, ls, as_ = (C.c_void_p * n)(), (C.c_int * n)(), (C.c_void_p * n)()
+    for i, (x, a) in enumerate(terms):
+        _req(x, torch.bfloat16, "X"); _req(a, torch.bfloat16, "Adown")
+        assert x.shape == (M, K) and a.shape == (R, K) and a.is_contiguous() and x.stride(1) == 1
+        xs[i], ls[i], as_[i] = x.data_ptr(), x.stride(0), a.data_ptr()
+    _req(T, torch.float32, "T")
+    check(lib.lx_lora_down_terms(xs, ls, as_, n, T.data_ptr(), T.stride(0), M, K, R, slab_stride, _stream()), "lx_lora_down_terms")
+
+
 def linear_skinny(X, W, bias, Y, act_in=0, act_out=0, accumulate=False) -> None:
     _req(X, torch.float32, "X"); _req(W, torch.bfloat16, "W"); _req(Y, torch.float32, "Y")
     check(lib.lx_linear_skinny(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), _p(bias), Y.data_ptr(), Y.stride(0),

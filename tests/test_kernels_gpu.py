@@ -283,6 +283,26 @@ def test_lora_down_ksplit_slabs(ops):
     assert relerr(Cc.cpu(), (A.float() @ W.float().T + t @ Bu.T).cpu()) < 2e-5
 
 
+def test_lora_down_terms_equals_separate_launches(ops):
+    """lx_lora_down_terms (precise mode: the cross terms x_hi.A, x_lo.A, x_hi.A_lo in ONE launch, one slab each) against the same
+    terms as separate lx_lora_down launches: bit for bit; operands as strided views of a wider pair buffer, as the engine passes them."""
+    M, K, r = 300, 1024, 12
+    pair = rnd(M, 2 * K + 64, seed=1, dtype=torch.bfloat16)
+    x_hi, x_lo = pair[:, :K], pair[:, K + 64:]
+    a, a_lo = rnd(r, K, seed=3, scale=0.1, dtype=torch.bfloat16), rnd(r, K, seed=4, scale=1e-3, dtype=torch.bfloat16)
+    terms = [(x_hi, a), (x_lo, a), (x_hi, a_lo)]
+    one = torch.full((4, M, 16), float("nan"), device=DEV)
+    ops.lora_down_terms(terms, one[0, :, :r], one.stride(0))
+    sep = torch.full((4, M, 16), float("nan"), device=DEV)
+    for i, (x, w) in enumerate(terms):
+        ops.lora_down(x, w, sep[i, :, :r])
+    assert torch.equal(one[:3, :, :r], sep[:3, :, :r]) and bool(torch.isnan(one[3]).all()) and bool(torch.isnan(one[:3, :, r:]).all())
+    want = x_hi.double() @ a.double().T + x_lo.double() @ a.double().T + x_hi.double() @ a_lo.double().T
+    assert relerr(one[:3, :, :r].double().sum(0).cpu(), want.cpu()) < 1e-6
+    with pytest.raises(RuntimeError):
+        ops.lora_down_terms(terms + terms, one[0, :, :r], one.stride(0))       # at most 4 terms
+
+
 def test_gemm_rejects_bad_k(ops):
     A = rnd(64, 96, dtype=torch.bfloat16)
     W = rnd(64, 96, dtype=torch.bfloat16)
