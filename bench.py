@@ -203,6 +203,9 @@ def workload_name(cfg_no, B, hw, allmod, mc, precise):
             (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if mc.get("independent_condition") else ""))
 
 
+_CS3_SD = None
+
+
 def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, events=True, seed=1234):
     """Warm-up + timed region of one workload on this rank; returns the measurement record (rank 0) or None."""
     from loongx_amd import dist as lxd
@@ -216,7 +219,10 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
     mc.setdefault("union_cond_attn", True)
     if precise:
         mc["precise"] = True
-    model = OminiModel.from_pipe(LxFluxPipeline(LxFluxTransformer(pw, dev)), synthetic_cs3_state_dict(0), mc, dev)
+    global _CS3_SD
+    if _CS3_SD is None:
+        _CS3_SD = synthetic_cs3_state_dict(0)          # (59 M parameters drawn on the host: once per process, not once per leg)
+    model = OminiModel.from_pipe(LxFluxPipeline(LxFluxTransformer(pw, dev)), _CS3_SD, mc, dev)
     N = hw * hw
     g = torch.Generator(device=dev).manual_seed(seed + rank)     # every rank edits different images
 

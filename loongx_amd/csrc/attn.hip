@@ -402,7 +402,16 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const uint32_t kaddr0 = lds0 + l31 * 256 + ((lhi ^ (l31 & 15)) * 16);
   const uint32_t vaddr0 = lds0 + K_BYTES + l31 * 128 + ((lhi ^ ((l31 >> 1) & 7)) * 16);
 
-  constexpr int LOOK = 5;           // fragments in flight ahead of the MFMA that consumes them (<= 6)
+#ifndef LX_ATTN_LOOK
+#define LX_ATTN_LOOK 5
+#endif
+#ifndef LX_ATTN_PG0                 // gaps behind which the four LDS-DMA pieces of an iteration are issued (A/B knobs; tools/attn_ab.py)
+#define LX_ATTN_PG0 1
+#define LX_ATTN_PG1 3
+#define LX_ATTN_PG2 5
+#define LX_ATTN_PG3 7
+#endif
+  constexpr int LOOK = LX_ATTN_LOOK;           // fragments in flight ahead of the MFMA that consumes them (<= 6)
   bf16x8 ring[LOOK];
   u32x4 pfw[4];
   f32x16 sA[2], sB[2];
@@ -494,10 +503,10 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   LX_MCHUNK(g, SC)                                                                                                     \
   if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
   if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }         \
-  if ((g) == 1) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                              \
-  if ((g) == 3) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                              \
-  if ((g) == 5) piece(2, 0, t1.vpos, 0, vs_slot);                                                                      \
-  if ((g) == 7) piece(3, 0, t1.vpos, 0, vs_slot);                                                                      \
+  if ((g) == LX_ATTN_PG0) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
+  if ((g) == LX_ATTN_PG1) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
+  if ((g) == LX_ATTN_PG2) piece(2, 0, t1.vpos, 0, vs_slot);                                                            \
+  if ((g) == LX_ATTN_PG3) piece(3, 0, t1.vpos, 0, vs_slot);                                                            \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_GAP4(g, SC, SN) LX_GAP(g, SC, SN); LX_GAP((g) + 1, SC, SN); LX_GAP((g) + 2, SC, SN); LX_GAP((g) + 3, SC, SN)
 
@@ -535,7 +544,13 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     piece(0, t0.krow, 0, t0.nclamp, 0); piece(1, t0.krow, 0, t0.nclamp, 0);
     piece(2, 0, t0.vpos, 0, 0); piece(3, 0, t0.vpos, 0, 0);
     piece(0, t1.krow, 0, t1.nclamp, 1); piece(1, t1.krow, 0, t1.nclamp, 1);
+#ifdef LX_ATTN_PROLOGUE_EARLY
+    // the scores of tile 0 need K(0) only: wait for this wave's two K(0) pieces (the four issued behind them -- V^T(0), K(1) --
+    // stay in flight under the 16 prologue MFMAs; guide T20 follow-on: a wait belongs in front of its first consumer)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     LX_BARRIER();
     // prologue: scores of tile 0
     LX_WAITL(0);
@@ -548,6 +563,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     // barrier a wave that runs ~14 gaps behind its workgroup (it shares its SIMD with an older wave) could fetch fragments of tile 2
     // for its tile-0 scores -- seen as run-to-run differences of single 32-row groups, ~1e-6 per workgroup, only under load
     // (tools/det_block.py). The iterations themselves end in a barrier; the prologue did not.
+#ifdef LX_ATTN_PROLOGUE_EARLY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // V^T(0) and K(1) of every wave have landed before anyone reads them
+#endif
     LX_BARRIER();
     while (true) {
       LX_ITER(sA, sB);
@@ -1108,8 +1126,9 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG(d->q_col % 8 == 0 && d->k_col % 8 == 0 && d->o_col % 4 == 0, "lx_attn_fwd: column offsets must be 16-byte aligned");
   // variant: LX_ATTN_PIPE=0|1 (software-pipelined 8-wave kernel), LX_ATTN_NW=4|8 (plain kernel: waves per workgroup),
   // LX_ATTN_DEFER=0|1 (deferred max rescale); defaults 1 / 8 / 1
-  static const bool piped = [] { const char* e = getenv("LX_ATTN_PIPE"); return e ? atoi(e) != 0 : true; }();
-  static const int nw = [] { const char* e = getenv("LX_ATTN_NW"); const int v = e ? atoi(e) : 8; return (v == 4 && !piped) ? 4 : 8; }();
+  static const int pipe_mode = [] { const char* e = getenv("LX_ATTN_PIPE"); return e ? atoi(e) : 1; }();      // 0 plain | 1 pipelined
+  const bool piped = pipe_mode != 0;
+  static const int nw = [] { const char* e = getenv("LX_ATTN_NW"); const int v = e ? atoi(e) : 8; return (v == 4 && pipe_mode == 0) ? 4 : 8; }();
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   const int qblk = nw * 32;
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd: n_qseg=%d must be 0..n_seg", d->n_qseg);
