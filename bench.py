@@ -176,13 +176,13 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1):
+def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1, brain=None):
     """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
     timed region) at full depth and width on this GPU, in the mode the timed region ran."""
     from oracle.parity import full_depth_parity
     mc = {"union_cond_attn": True}
     mc.update(extra_mc or {})
-    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc, hw=hw, every=every)
+    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc, hw=hw, every=every, brain=brain)
 
 
 # BASELINE.json configs -> workload (global batch, latent grid side, modalities, extra model_config)
@@ -417,12 +417,13 @@ def main():
         xmc = {k: True for k in ("attn_fp8", "gemm_fp8", "independent_condition") if mc.get(k)}
         if world == 1 and not a.no_parity:
             try:
-                res["parity"] = parity_check(a.precise, xmc, hw=hw, every=1 if hw == 32 else 7)
+                # the brain side is part of the checked composition, as it is part of the timed workload (batch 1 per checker run)
+                res["parity"] = parity_check(a.precise, xmc, hw=hw, every=1 if hw == 32 else 7, brain="all" if allmod else "eeg")
             except Exception as e:          # the checker must never take the measurement down with it
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and plain and not a.no_secondary:
             # ---- the other BASELINE configs on this GPU, outside the headline's timed region (bounded: 2 timed batches each) ----
-            legs = [dict(config=2, B=16, hw=32, allmod=True, mc={}, precise=False, parity=None),
+            legs = [dict(config=2, B=16, hw=32, allmod=True, mc={}, precise=False, parity=[(32, 4)]),
                     dict(config=None, B=4, hw=64, allmod=True, mc={}, precise=False, parity=None),
                     dict(config=4, B=4, hw=64, allmod=True, mc={"attn_fp8": True}, precise=False, parity=[(32, 1), (64, 7)]),
                     dict(config=None, B=1, hw=32, allmod=False, mc={}, precise=True, parity=[(32, 4)])]
@@ -441,7 +442,8 @@ def main():
                         r["parity"] = {}
                         for phw, every in lg["parity"]:
                             try:
-                                r["parity"][f"{16 * phw}x{16 * phw}"] = parity_check(lg["precise"], {k: True for k in lg["mc"]}, hw=phw, every=every)
+                                r["parity"][f"{16 * phw}x{16 * phw}"] = parity_check(lg["precise"], {k: True for k in lg["mc"]}, hw=phw, every=every,
+                                                                                     brain="all" if lg["allmod"] else "eeg")
                             except Exception as e:
                                 r["parity"][f"{16 * phw}x{16 * phw}"] = {"error": f"{type(e).__name__}: {e}"}
                 except Exception as e:      # a secondary leg must never take the headline down with it

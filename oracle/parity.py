@@ -67,10 +67,15 @@ def build_pair(device, num_layers: int = 19, num_single_layers: int = 38, heads:
 @torch.no_grad()
 def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, num_single_layers: int = 38, hw: int = 32,
                       n_txt: int = 512, seed: int = 0, precise: bool = False, model_config: Optional[Dict] = None,
-                      every: int = 1) -> Dict:
+                      every: int = 1, brain: Optional[str] = None) -> Dict:
     """Runs both sides at batch 1 on identical synthetic inputs (BASELINE.md section 4 shapes) and returns the parity record
     that bench.py prints as `parity`. `every`: compare the teacher-forced noise_pred at every `every`-th step (the oracle still
-    runs all steps)."""
+    runs all steps).
+    `brain`: None = the DiT alone on given text embeddings; "eeg" = BASELINE configs[1] as bench.py times it (EEG-only CS3
+    conditioning, per-stream replacement rule: the EEG encoder's output IS the prompt-embedding stream); "all" = all four modalities
+    through the CS3 encoders + DGF fusion (fuse_flag=True: configs[2]'s composition). The oracle side is oracle/cs3.py (full-size
+    encoders, on the host) feeding oracle/flux_ref.py; the product side is generate() with the signals, i.e. its own CS3 / DGF
+    kernels feeding its own DiT: the free-running figures then cover the COMPOSITION, and `brain_embeds_relerr` the encoders alone."""
     from loongx_amd.flux.condition import Condition
     from loongx_amd.flux.generate import generate
     from loongx_amd.flux.pipeline import LxFluxPipeline
@@ -83,6 +88,24 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
     g = torch.Generator(device=dev).manual_seed(4321 + seed)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)
     lat0, cond, pe, pooled = r(1, N, 64), r(1, N, 64), r(1, n_txt, 4096) * 0.1, r(1, 768)
+    signals, model, brain_rec = {}, None, {}
+    pe_text, pooled_text = pe, pooled
+    if brain is not None:
+        from loongx_amd.flux.pipeline import LxFluxPipeline as _Pipe
+        from loongx_amd.train.model import OminiModel
+        from . import cs3 as ocs3
+        if brain not in ("eeg", "all"):
+            raise ValueError("brain must be None, 'eeg' or 'all'")
+        torch.manual_seed(seed)
+        ref_cs3 = ocs3.CS3DGF(seed=seed).eval()
+        signals = {"eeg": r(1, 4, 4096)}
+        if brain == "all":
+            signals.update(fnirs=r(1, 6, 512), ppg=r(1, 4, 256), motion=r(1, 6, 128))
+        cpu = {k: v.float().cpu() for k, v in signals.items()}
+        rpe, rpool = ref_cs3.brain_embeds(pe.float().cpu(), pooled.float().cpu(), cpu.get("eeg"), cpu.get("fnirs"), cpu.get("ppg"), cpu.get("motion"),
+                                          fuse_flag=brain == "all", per_stream=True)
+        pe, pooled = rpe.to(dev), rpool.to(dev)                 # what the ORACLE's DiT is conditioned on
+        model = OminiModel.from_pipe(_Pipe(lx), ref_cs3.state_dict(), dict(model_config or {"union_cond_attn": True}), dev)
     ids = fm.prepare_latent_image_ids(hw, hw).to(dev)
     cids = ids.clone()
     cids[:, 2] -= hw
@@ -112,11 +135,29 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
 
     # ---- free-running product loop ---------------------------------------------------------------------------------
     lx.invalidate_conditioning()
-    pipe = LxFluxPipeline(lx)
     c = Condition("subject", latents=cond, latent_hw=(hw, hw), position_delta=[0, -hw])
-    final = generate(None, pipe, conditions=[c], height=16 * hw, width=16 * hw, num_inference_steps=steps, latents=lat0.clone(),
-                     prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent", model_config=mc, default_lora=True,
-                     use_brain_condition=False, guidance_scale=3.5).images
+    if brain is None:
+        pipe = LxFluxPipeline(lx)
+        final = generate(None, pipe, conditions=[c], height=16 * hw, width=16 * hw, num_inference_steps=steps, latents=lat0.clone(),
+                         prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent", model_config=mc, default_lora=True,
+                         use_brain_condition=False, guidance_scale=3.5).images
+    else:
+        # the product's own CS3 / DGF kernels make the embeddings from the raw signals (text embeddings in, as bench.py passes them)
+        pipe = model.flux_pipe
+        seen = {}
+
+        def grab(_pipe, i, t, kw):
+            if i == 0:
+                seen["pe"] = kw["prompt_embeds"].float().clone()
+            return {}
+        final = generate(model, pipe, conditions=[c], height=16 * hw, width=16 * hw, num_inference_steps=steps, latents=lat0.clone(),
+                         prompt_embeds=pe_text, pooled_prompt_embeds=pooled_text, output_type="latent", model_config=mc, default_lora=True,
+                         additional_condition1=signals.get("eeg"), additional_condition2=signals.get("fnirs"), additional_condition3=signals.get("ppg"),
+                         additional_condition4=signals.get("motion"), use_brain_condition=True, fuse_flag=brain == "all",
+                         brain_replace="per_stream", guidance_scale=3.5, callback_on_step_end=grab,
+                         callback_on_step_end_tensor_inputs=["prompt_embeds"]).images
+        brain_rec = {"brain": "EEG-only CS3 conditioning (per-stream rule)" if brain == "eeg" else "EEG+fNIRS+PPG+motion CS3 + DGF fusion",
+                     "brain_embeds_relerr": round(relerr(seen["pe"], pe), 8) if "pe" in seen else None}
     errs = [e for _, e in per_step]
     mode = "precise (split-bf16 MFMA, fp32 attention)" if precise else "bf16 MFMA operands, fp32 accumulate / residual"
     if mc.get("gemm_fp8") or mc.get("attn_fp8"):
@@ -129,6 +170,7 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
            "steps_compared": len(errs),
            "final_latent_relerr": round(relerr(final, final_oracle), 6), "final_latent_cosine": round(cosine(final, final_oracle), 8),
            "oracle_s_per_forward": round(t_oracle / len(timesteps), 3), "wall_s": round(time.time() - t0, 1)}
-    del tr, lx, pipe
+    rec.update(brain_rec)
+    del tr, lx, pipe, model
     torch.cuda.empty_cache()
     return rec

@@ -31,6 +31,21 @@ def test_full_depth_parity_bf16():
     assert rec["final_latent_cosine"] > 0.9995, rec
 
 
+@pytest.mark.parametrize("brain", ["eeg", "all"])
+def test_full_depth_parity_bf16_with_the_brain_side(brain):
+    """The composition bench.py times, at full depth: raw signals -> the product's CS3 encoders (+ DGF fusion for "all") -> its
+    57-block DiT over 28 steps, against oracle/cs3.py -> oracle/flux_ref.py. "eeg" = BASELINE configs[1] (EEG-only, per-stream
+    rule), "all" = configs[2]'s four modalities with fuse_flag=True. Same bounds as the DiT-only run; the encoders alone are fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=9, brain=brain)
+    print(f"PARITY_BF16_BRAIN_{brain} " + json.dumps(rec))
+    assert rec["brain_embeds_relerr"] is not None and rec["brain_embeds_relerr"] < 5e-6, rec      # measured 1.1e-6 (eeg) / 9e-8 (all): fp32 kernels
+    assert rec["noise_pred_relerr_max"] < BF16_NOISE_PRED_MAX, rec
+    assert rec["final_latent_relerr"] < BF16_FINAL_LATENT and rec["final_latent_cosine"] > 0.9995, rec
+
+
 # ---- BASELINE configs[4]'s mode: fp8 (e4m3) attention, bf16 GEMMs ------------------------------------------------------------------
 # The reference has no fp8 path (block.py:129 is plain SDPA), so the contract is the bf16 result within a STATED tolerance:
 #   <= 1e-2 per velocity prediction, <= 2e-3 on the final latents (full depth, against the fp32 oracle).
