@@ -21,6 +21,15 @@
 
 namespace {
 
+// A value defined behind an empty asm INSIDE a rarely taken branch cannot be hoisted out of the loop around it. Without it hipcc's
+// LICM turned the 32 key constants of the ragged-tile masks into registers held (or spilled) across the whole tile loop: 30 VGPRs of
+// lx_attn_pipe_kernel (254 -> 224) and 33 spilled registers of lx_attn_fp8_pipe_kernel<true, true> (-> 0).
+#ifdef LX_ATTN_NO_LICM_FIX
+#define LX_PIN_IN_BRANCH(x)
+#else
+#define LX_PIN_IN_BRANCH(x) asm volatile("" : "+v"(x))
+#endif
+
 constexpr int DH = 128;
 constexpr int KVBLK = 64;
 constexpr int K_BYTES = KVBLK * DH * 2;   // 16 KiB
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f;   // (LX_ATTN_LSUM_MFMA: l_run is unused, the row sums live in lacc)
 
   const __bf16* Kbase = (const __bf16*)D.K + D.k_col + h * DH;
   const __bf16* Vbase = (const __bf16*)D.VT + (size_t)bh * DH * D.vt_ld;
@@ -405,6 +414,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #ifndef LX_ATTN_LOOK
 #define LX_ATTN_LOOK 5
 #endif
+#ifndef LX_ATTN_LSUM_MFMA
+#define LX_ATTN_LSUM_MFMA 0
+#endif
 #ifndef LX_ATTN_PG0                 // gaps behind which the four LDS-DMA pieces of an iteration are issued (A/B knobs; tools/attn_ab.py)
 #define LX_ATTN_PG0 1
 #define LX_ATTN_PG1 3
@@ -416,6 +428,14 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   u32x4 pfw[4];
   f32x16 sA[2], sB[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if LX_ATTN_LSUM_MFMA
+  // Row sums on the matrix pipe: behind the last P.V MFMA of a slice, one more MFMA multiplies the slice's P^T fragment by an
+  // all-ones A fragment -- every accumulator register of a lane then holds sum_k P[q, k] of the ROUNDED probabilities (the values
+  // P.V sees; the hardware sums over both half-waves' keys) -- and the 32 v_add per key tile of the half-units go (+4 MFMAs per tile).
+  f32x16 lacc = zero16;
+  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
+#endif
   float mx[4], t_new = 0.f;
   float off = 0.f, p_even[2] = {0.f, 0.f};   // (slices s and s+1 overlap in time: one pending even value per slice parity)
   uint32_t bq = 0, bv = 0;          // LDS byte offsets of the K buffer read by QK and the V buffer read by PV
@@ -439,6 +459,19 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }                                                                                                                    \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_RDP(j, last, QONLY) LX_RD(j, (j) < LOOK ? (last) : 0, QONLY)   /* the LOOK reads that prime the ring */
+#if LX_ATTN_LSUM_MFMA
+#define LX_LSUM(f_)                                                                                                    \
+    if (((f_) & 3) == 3) {                                                                                             \
+      lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, __builtin_bit_cast(bf16x8, pfw[(f_) >> 2]), lacc, 0, 0, 0); \
+      asm volatile("" : "+v"(lacc));                                                                                  \
+    }
+#define LX_LADD(p_)
+#define LX_LPIN
+#else
+#define LX_LSUM(f_)
+#define LX_LADD(p_) l_run += p_;
+#define LX_LPIN , "+v"(l_run)
+#endif
 #define LX_MM(g, SC, SN, QONLY)                                                                                        \
   if ((QONLY) || pipe_is_q(g)) {                                                                                       \
     constexpr int f_ = (QONLY) ? (g) : pipe_idx(g);                                                                    \
@@ -446,6 +479,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   } else {                                                                                                             \
     constexpr int f_ = pipe_idx(g);                                                                                    \
     oacc[f_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(g) % LOOK], __builtin_bit_cast(bf16x8, pfw[f_ >> 2]), oacc[f_ & 3], 0, 0, 0); \
+    LX_LSUM(f_)                                                                                                        \
   }                                                                                                                    \
   __builtin_amdgcn_sched_barrier(0)
   // softmax half-unit hu = slice*8 + value: one score -> one probability and the row sum; odd values also pack the bf16 pair.
@@ -454,12 +488,17 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   {                                                                                                                    \
     constexpr int s_ = (hu) >> 3, r_ = 8 * (s_ & 1) + ((hu) & 7);                                                      \
     const float p_ = __builtin_amdgcn_exp2f(fmaf(SC[s_ >> 1][r_], c2, off));                                           \
-    l_run += p_;                                                                                                       \
-    if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even[s_ & 1], p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]), "+v"(l_run)); } \
-    else { p_even[s_ & 1] = p_; asm volatile("" : "+v"(p_even[s_ & 1]), "+v"(l_run)); }                                \
+    LX_LADD(p_)                                                                                                        \
+    if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even[s_ & 1], p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]) LX_LPIN); } \
+    else { p_even[s_ & 1] = p_; asm volatile("" : "+v"(p_even[s_ & 1]) LX_LPIN); }                                     \
   }
   // row max of tile t and the rescale decision, as vector fillers of gaps 0-3 (they used to run serially at the head of the
   // iteration: 8 us of a 90 us launch with nothing to overlap); four independent v_max3 chains, not one 16-deep chain
+#if LX_ATTN_LSUM_MFMA
+#define LX_LSCALE(a_) lacc[0] *= a_
+#else
+#define LX_LSCALE(a_) l_run *= a_
+#endif
 #define LX_MCHUNK(g, SC)                                                                                               \
   if ((g) == 0) {                                                                                                      \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                    \
@@ -486,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     if (rescale) {                                                                                                     \
       const float m_new = fmaxf(m_run, t_new);                                                                         \
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                       \
-      l_run *= alpha;                                                                                                  \
+      LX_LSCALE(alpha);                                                                                                \
       m_run = m_new;                                                                                                   \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha; \
     }                                                                                                                  \
@@ -522,8 +561,10 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     const float bl = t0.bl;                                                                                            \
     if (t0.nvalid < KVBLK) {                                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* keeps this a wave-uniform branch: if-converted it is ~100 VALU on every tile */ \
+      int lh4_ = 4 * lhi;                                                                                              \
+      LX_PIN_IN_BRANCH(lh4_);     /* defined inside the rare branch: LICM otherwise hoists the 32 key constants into registers held across the loop */ \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {                \
-        const int key = 4 * lhi + kb * 32 + 8 * (r >> 2) + (r & 3);                                                    \
+        const int key = lh4_ + kb * 32 + 8 * (r >> 2) + (r & 3);                                                       \
         if (key >= t0.nvalid) SC[kb][r] = -1e30f;                                                                      \
       }                                                                                                                \
     }                                                                                                                  \
@@ -578,6 +619,10 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_GAP4
 #undef LX_GAP
 #undef LX_MCHUNK
+#undef LX_LSCALE
+#undef LX_LSUM
+#undef LX_LADD
+#undef LX_LPIN
 #undef LX_HALF
 #undef LX_MM
 #undef LX_RD
@@ -588,7 +633,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_BARRIER
 #undef LX_FENCE
 
+#if LX_ATTN_LSUM_MFMA
+  const float l_tot = lacc[0];          // (every register of lacc holds the row's sum; the MFMA summed over both half-waves' keys)
+#else
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#endif
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
   if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
@@ -1031,8 +1080,10 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     LX8_GAP(0, S0, S1C, S1N, PAR) LX8_GAP(1, S0, S1C, S1N, PAR) LX8_GAP(2, S0, S1C, S1N, PAR) LX8_GAP(3, S0, S1C, S1N, PAR) \
     if (t1.nvalid > 0 && t1.nvalid < KVBLK) {     /* ragged last tile of a segment: mask keys past its end (rare) */  \
       LX8_FENCE();                                                                                                     \
+      int lh4_ = 4 * lhi;                                                                                              \
+      LX_PIN_IN_BRANCH(lh4_);    /* defined inside the rare branch: LICM otherwise hoists the 32 key constants into registers (spilled) across the loop */ \
       _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                              \
-        const int key_ = 4 * lhi + 8 * (r_ >> 2) + (r_ & 3);                                                           \
+        const int key_ = lh4_ + 8 * (r_ >> 2) + (r_ & 3);                                                              \
         if (key_ >= t1.nvalid) S0[r_] = -1e30f;                                                                        \
         if (key_ + 32 >= t1.nvalid) S1N[r_] = -1e30f;                                                                  \
       }                                                                                                                \
