@@ -428,7 +428,15 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   u32x4 pfw[4];
   f32x16 sA[2], sB[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if LX_ATTN_LSUM_MFMA
+#if LX_ATTN_LSUM_MFMA == 2
+  // Row sums on the matrix pipe, small form: v_mfma_f32_4x4x4_16b_bf16 is sixteen independent 4x4x4 products, block = lane / 4; with
+  // an all-ones A every lane's four result registers hold the sum of the four bf16 values IT supplied as B. Two of them behind each
+  // P.V slice add the lane's eight rounded probabilities of that slice into lacc4 (a 4-register tuple: the 16-register accumulator
+  // of the 32x32 form does not fit the allocator's tuple budget, 66 spills), and the 32 v_add per key tile of the half-units go.
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  f32x4 lacc4 = {0.f, 0.f, 0.f, 0.f};
+  const s16x4 ones4 = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+#elif LX_ATTN_LSUM_MFMA
   // Row sums on the matrix pipe: behind the last P.V MFMA of a slice, one more MFMA multiplies the slice's P^T fragment by an
   // all-ones A fragment -- every accumulator register of a lane then holds sum_k P[q, k] of the ROUNDED probabilities (the values
   // P.V sees; the hardware sums over both half-waves' keys) -- and the 32 v_add per key tile of the half-units go (+4 MFMAs per tile).
@@ -459,7 +467,16 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }                                                                                                                    \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_RDP(j, last, QONLY) LX_RD(j, (j) < LOOK ? (last) : 0, QONLY)   /* the LOOK reads that prime the ring */
-#if LX_ATTN_LSUM_MFMA
+#if LX_ATTN_LSUM_MFMA == 2
+#define LX_LSUM(f_)                                                                                                    \
+    if (((f_) & 1) == 1) {       /* behind the 2nd and the 4th P.V MFMA of a slice: one half of the slice's P fragment each */ \
+      const u32x2 h_ = {pfw[(f_) >> 2][((f_) & 2)], pfw[(f_) >> 2][((f_) & 2) + 1]};                                    \
+      lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, h_), lacc4, 0, 0, 0);              \
+      asm volatile("" : "+v"(lacc4));                                                                                 \
+    }
+#define LX_LADD(p_)
+#define LX_LPIN
+#elif LX_ATTN_LSUM_MFMA
 #define LX_LSUM(f_)                                                                                                    \
     if (((f_) & 3) == 3) {                                                                                             \
       lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, __builtin_bit_cast(bf16x8, pfw[(f_) >> 2]), lacc, 0, 0, 0); \
@@ -494,7 +511,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }
   // row max of tile t and the rescale decision, as vector fillers of gaps 0-3 (they used to run serially at the head of the
   // iteration: 8 us of a 90 us launch with nothing to overlap); four independent v_max3 chains, not one 16-deep chain
-#if LX_ATTN_LSUM_MFMA
+#if LX_ATTN_LSUM_MFMA == 2
+#define LX_LSCALE(a_) lacc4[0] *= a_
+#elif LX_ATTN_LSUM_MFMA
 #define LX_LSCALE(a_) lacc[0] *= a_
 #else
 #define LX_LSCALE(a_) l_run *= a_
@@ -633,7 +652,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_BARRIER
 #undef LX_FENCE
 
-#if LX_ATTN_LSUM_MFMA
+#if LX_ATTN_LSUM_MFMA == 2
+  const float l_tot = lacc4[0] + __shfl_xor(lacc4[0], 32, 64);     // per lane: its own 32 probabilities per tile, as l_run was
+#elif LX_ATTN_LSUM_MFMA
   const float l_tot = lacc[0];          // (every register of lacc holds the row's sum; the MFMA summed over both half-waves' keys)
 #else
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
