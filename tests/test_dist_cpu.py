@@ -123,8 +123,9 @@ def _pw_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from loongx_amd import dist as lxd
     lxd.init("gloo", timeout_s=120)
-    truth = _pw_tensors(_tiny_pw(0))                       # what rank 0 packs
-    pw = _tiny_pw(0 if rank == 0 else 100 + rank)          # the other ranks: same structure, different (garbage) contents
+    truth_pw = _tiny_pw(0)                                 # what rank 0 packs
+    truth = {k: v.clone() for k, v in _pw_tensors(truth_pw).items()}
+    pw = truth_pw if rank == 0 else _tiny_pw(100 + rank)   # the other ranks: same structure, different (garbage) contents
     mine = _pw_tensors(pw)
     differs_before = any(not torch.equal(mine[k], truth[k]) for k in truth)
     moved = lxd.broadcast_packed_weights(pw, src=0)
@@ -133,7 +134,8 @@ def _pw_worker(rank, world, port, q):
     ok = ok and moved == sum(t.numel() * t.element_size() for t in truth.values())
     ok = ok and (rank == 0 or differs_before)
     # tiled GEMM weights keep their layout flag, adapters their residuals
-    ok = ok and all(getattr(pw.t[k], "lx_tiled", False) == getattr(_tiny_pw(0).t[k], "lx_tiled", False) for k in list(pw.t)[:8])
+    ref_pw = truth_pw if rank != 0 else _tiny_pw(0)
+    ok = ok and all(getattr(pw.t[k], "lx_tiled", False) == getattr(ref_pw.t[k], "lx_tiled", False) for k in pw.t)
     ok = ok and any(k.endswith(".down_lo") for k in mine) and "t.mod.lora_down_lo" in mine and "t.mod.w" in mine
     dist.barrier()
     dist.destroy_process_group()
