@@ -19,6 +19,17 @@
 //   (K: slot ^= key&15, V^T: slot ^= (d>>1)&7) so fragment reads are bank-conflict free.
 #include "common.h"
 
+#ifdef LX_ATTN_PROBE
+// Measurement build only (tools/attn_probe.py through tools/build_variant.sh -DLX_ATTN_PROBE=1): per wave of lx_attn_pipe_kernel,
+// shader-clock cycles spent in the end-of-iteration `s_waitcnt vmcnt(0)` (this wave's LDS-DMA pieces) and `s_barrier` (the other
+// waves), in the iterations as a whole, and in the kernel from entry to exit. s_memtime is a scalar memory read: it is taken only
+// where the iteration has just waited lgkmcnt down to 0, and costs a round trip each time -- the SPLIT is what the numbers are for.
+__device__ unsigned long long lx_attn_probe_buf[4096 * 8 * 4];
+extern "C" int lx_attn_probe_read(unsigned long long* host, size_t n_u64) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(lx_attn_probe_buf), n_u64 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 // A value defined behind an empty asm INSIDE a rarely taken branch cannot be hoisted out of the loop around it. Without it hipcc's
@@ -590,14 +601,27 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     LX_GAP4(0, SC, SN); LX_GAP4(4, SC, SN); LX_GAP4(8, SC, SN); LX_GAP4(12, SC, SN);                                   \
     LX_GAP4(16, SC, SN); LX_GAP4(20, SC, SN); LX_GAP4(24, SC, SN); LX_GAP4(28, SC, SN);                                \
+    LX_PROBE_A();                                                                                                      \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    LX_PROBE_B();                                                                                                      \
     LX_BARRIER();                                                                                                      \
+    LX_PROBE_C();                                                                                                      \
     t0 = t1; t1 = t2;                                                                                                  \
     gen_next();                                                                                                        \
     t2 = g_cur;                                                                                                        \
     ++t;                                                                                                               \
   }
 
+#ifdef LX_ATTN_PROBE
+  unsigned long long pr_t0 = __builtin_amdgcn_s_memtime(), pr_a = 0, pr_b = 0, pr_c = 0, pr_vm = 0, pr_bar = 0, pr_loop0 = 0;
+#define LX_PROBE_A() pr_a = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define LX_PROBE_B() pr_b = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_vm += pr_b - pr_a
+#define LX_PROBE_C() pr_c = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_bar += pr_c - pr_b
+#else
+#define LX_PROBE_A()
+#define LX_PROBE_B()
+#define LX_PROBE_C()
+#endif
   if (args.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);      // wave is an SGPR value (readfirstlane): a real scalar branch
   int t = 0;
   if (t0.nvalid > 0) {
@@ -627,6 +651,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // V^T(0) and K(1) of every wave have landed before anyone reads them
 #endif
     LX_BARRIER();
+#ifdef LX_ATTN_PROBE
+    pr_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
       LX_ITER(sA, sB);
       if (t0.nvalid == 0) break;
@@ -635,6 +662,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     }
   }
 #undef LX_ITER
+#undef LX_PROBE_A
+#undef LX_PROBE_B
+#undef LX_PROBE_C
 #undef LX_GAP4
 #undef LX_GAP
 #undef LX_MCHUNK
@@ -652,6 +682,15 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_BARRIER
 #undef LX_FENCE
 
+#ifdef LX_ATTN_PROBE
+  {
+    const unsigned long long pr_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x < 4096) {
+      unsigned long long* o = lx_attn_probe_buf + ((size_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = pr_end - pr_t0; o[1] = pr_end - pr_loop0; o[2] = pr_vm; o[3] = pr_bar;
+    }
+  }
+#endif
 #if LX_ATTN_LSUM_MFMA == 2
   const float l_tot = lacc4[0] + __shfl_xor(lacc4[0], 32, 64);     // per lane: its own 32 probabilities per tile, as l_run was
 #elif LX_ATTN_LSUM_MFMA

@@ -48,8 +48,11 @@ def test_full_depth_parity_bf16_with_the_brain_side(brain):
 
 # ---- BASELINE configs[4]'s mode: fp8 (e4m3) attention, bf16 GEMMs ------------------------------------------------------------------
 # The reference has no fp8 path (block.py:129 is plain SDPA), so the contract is the bf16 result within a STATED tolerance:
-#   <= 1e-2 per velocity prediction, <= 2e-3 on the final latents (full depth, against the fp32 oracle).
-# Measured on MI355X (round 3, profiles/r03a_bench_attnfp8_512.json): 8.1e-3 mean / 8.9e-3 max per forward, 1.71e-3 final latents.
+#   <= 1e-2 per velocity prediction on average over the trajectory (<= 1.1e-2 at any single step), <= 2e-3 on the final latents
+#   (full depth, against the fp32 oracle).
+# Measured on MI355X (round 3): text-embedding conditioning 8.1e-3 mean / 8.9e-3 max per forward, 1.6e-3 final latents; with the
+# conditioning coming from the CS3 encoders + DGF fusion (brain="all", profiles/r03k_bench_line.json) 9.4e-3 / 1.02e-2 / 1.7e-3;
+# 1024x1024: 6.3e-3 / 6.6e-3 / 1.4e-3.
 # The e4m3 GEMMs (model_config gemm_fp8, `bench.py --fp8`) do NOT hold it -- 1.0e-1 per forward, whatever the scaling recipe
 # (tools/fp8_ablation.py, profiles/r03a_fp8_ablation.json) -- and are kept as an explicitly lossy option.
 FP8_ATTN_NOISE_PRED_MEAN = 1.0e-2
@@ -57,12 +60,13 @@ FP8_ATTN_NOISE_PRED_MAX = 1.1e-2
 FP8_ATTN_FINAL_LATENT = 2.0e-3
 
 
-def test_full_depth_parity_fp8_attention_512():
+@pytest.mark.parametrize("brain", [None, "all"])
+def test_full_depth_parity_fp8_attention_512(brain):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle.parity import full_depth_parity
-    rec = full_depth_parity("cuda:0", steps=28, every=3, model_config={"union_cond_attn": True, "attn_fp8": True})
-    print("PARITY_FP8ATTN_512 " + json.dumps(rec))
+    rec = full_depth_parity("cuda:0", steps=28, every=3, model_config={"union_cond_attn": True, "attn_fp8": True}, brain=brain)
+    print(f"PARITY_FP8ATTN_512_{brain} " + json.dumps(rec))
     assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= FP8_ATTN_NOISE_PRED_MAX, rec
     assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT and rec["final_latent_cosine"] > 0.99999, rec
 
