@@ -564,6 +564,23 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }
   // the wait of gap g hands the fragment register on ("+v"): the MFMA that consumes it then depends on the WAIT, not only on the
   // ds_read that was issued five gaps earlier -- otherwise nothing but luck keeps hipcc from hoisting the MFMA above its wait
+// LX_ATTN_PRIO_FLIP = G > 0 (A/B knob): the two waves of a SIMD trade priority inside every iteration -- waves 4-7 (the younger half,
+// which loses every arbitration by age and is the one the workgroup waits for: tools/attn_probe.py) run gaps [0, G) at priority 1 and
+// the rest at 0, waves 0-3 the other way round -- so that both reach the end-of-iteration barrier together.
+#ifndef LX_ATTN_PRIO_FLIP
+#define LX_ATTN_PRIO_FLIP 0
+#endif
+#if LX_ATTN_PRIO_FLIP > 0
+#define LX_PRIO_AT(g)                                                                                                  \
+  if ((g) == 0) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }                      \
+  if ((g) == LX_ATTN_PRIO_FLIP) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#elif LX_ATTN_PRIO_FLIP < 0
+#define LX_PRIO_AT(g)                                                                                                  \
+  if ((g) == 0) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }                      \
+  if ((g) == -(LX_ATTN_PRIO_FLIP)) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#else
+#define LX_PRIO_AT(g)
+#endif
 #define LX_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LX_GAP(g, SC, SN)                                                                                              \
   LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);                                       \
@@ -572,6 +589,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   LX_MCHUNK(g, SC)                                                                                                     \
   if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
   if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }         \
+  LX_PRIO_AT(g)                                                                                                        \
   if ((g) == LX_ATTN_PG0) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
   if ((g) == LX_ATTN_PG1) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
   if ((g) == LX_ATTN_PG2) piece(2, 0, t1.vpos, 0, vs_slot);                                                            \
@@ -622,6 +640,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #define LX_PROBE_B()
 #define LX_PROBE_C()
 #endif
+  const bool young = wave >= 4;             // (an SGPR condition: the branches of LX_PRIO_AT are scalar)
   if (args.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);      // wave is an SGPR value (readfirstlane): a real scalar branch
   int t = 0;
   if (t0.nvalid > 0) {
@@ -667,6 +686,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_PROBE_C
 #undef LX_GAP4
 #undef LX_GAP
+#undef LX_PRIO_AT
 #undef LX_MCHUNK
 #undef LX_LSCALE
 #undef LX_LSUM
