@@ -225,3 +225,75 @@ def write_evaluator_dirs(root: str, gen, gt, caps):
     with open(cap, "w") as f:
         f.write("\n".join(json.dumps(c) for c in caps))
     return gdir, tdir, cap
+
+
+# ---- inference CLI fixtures (reference inference.py) -------------------------------------------------------------------
+def inference_case(seed: int = 0):
+    """A synthetic L-Mind-style work list for the CLI's host logic: image files, a captions JSONL mixing `speech2text`, `instruction`
+    and neither (-> the default prompt), one record whose source is not an image (skipped), and a brain-data pickle with a different
+    subset of EEG / FNIRS / PPG / Motion per image (reference inference.py:63-74, 124-176, 264-339)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    names = [f"s{i:02d}_0.png" for i in range(5)] + ["x_0.jpg", "y_0.jpeg"]
+    images = {n: (rng.random((16, 24, 3)) * 255).astype("uint8") for n in names}
+    caps = [{"source_image": "imgs/s00_0.png", "target_image": "imgs/s00_1.png", "speech2text": "spoken zero", "instruction": "typed zero"},
+            {"source_image": "imgs/s01_0.png", "instruction": "typed one"},
+            {"source_image": "imgs/s02_0.png"},
+            {"source_image": "deep/er/s03_0.png", "speech2text": "spoken three"},
+            {"source_image": "notes.txt", "instruction": "not an image"},
+            {"source_image": "s04_0.png", "instruction": "typed four"},
+            {"source_image": "x_0.jpg", "speech2text": "spoken x"},
+            {"source_image": "y_0.jpeg", "instruction": "typed y"}]
+    f32 = lambda *s: rng.standard_normal(s).astype("float32")
+    brain = {"s00_0.png": {"EEG": f32(4, 300), "FNIRS": f32(6, 40), "PPG": f32(4, 30), "Motion": f32(6, 20)},
+             "s01_0.png": {"EEG": f32(4, 100)},
+             "s03_0.png": {"FNIRS": f32(6, 64), "Motion": f32(6, 16)},
+             "x_0.jpg": {"PPG": f32(4, 30)},
+             "unused.png": {"EEG": f32(4, 8)}}
+    return images, caps, brain
+
+
+def write_inference_case(root: str, images, caps, brain):
+    import json
+    import os
+    import pickle
+    from PIL import Image
+    idir = os.path.join(root, "in")
+    os.makedirs(idir, exist_ok=True)
+    for n, a in images.items():
+        Image.fromarray(a).save(os.path.join(idir, n))
+    cap = os.path.join(root, "caps.jsonl")
+    with open(cap, "w") as f:
+        f.write("\n".join(json.dumps(c) for c in caps))
+    pkl = os.path.join(root, "brain.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump(brain, f)
+    return idir, cap, pkl
+
+
+class GenerateRecorder:
+    """Stands in for `generate` / `Condition` inside an inference module: records, per call, everything the CLI decided."""
+
+    def __init__(self):
+        self.calls = []
+
+    def condition(self, **kw):
+        from types import SimpleNamespace
+        return SimpleNamespace(**kw)
+
+    def generate(self, model, pipeline, **kw):
+        from types import SimpleNamespace
+        import numpy as np
+        from PIL import Image
+        c = kw["conditions"][0]
+        sig = lambda t: None if t is None else [list(t.shape), str(t.dtype).replace("torch.", ""), round(float(t.double().sum()), 4), t.device.type]
+        self.calls.append(dict(
+            prompt=kw.get("prompt"), height=kw["height"], width=kw["width"], seed=int(kw["generator"].initial_seed()),
+            default_lora=bool(kw["default_lora"]), fuse_flag=bool(kw["fuse_flag"]), use_brain_condition=bool(kw["use_brain_condition"]),
+            model_config=dict(kw["model_config"]), pipeline_is_model_pipe=pipeline is model.flux_pipe,
+            condition_type=c.condition_type, position_delta=list(c.position_delta), condition_size=list(c.condition.size),
+            condition_mode=c.condition.mode, condition_sum=int(np.asarray(c.condition, dtype=np.int64).sum()),
+            cond_signals=[sig(getattr(c, k)) for k in ("eeg", "fnirs", "ppg", "motion")],
+            signals=[sig(kw.get(f"additional_condition{i}")) for i in (1, 2, 3, 4)]))
+        n = len(self.calls)
+        return SimpleNamespace(images=[Image.fromarray(np.full((8, 8, 3), n, np.uint8))])

@@ -510,12 +510,75 @@ def gold_evaluate():
     print("evaluate.npz", len(arrays), "arrays;", {k: float(np.round(v, 6)) for k, v in out.items() if np.ndim(v) == 0})
 
 
+def gold_inference():
+    """The host logic of the reference's inference CLI (inference.py:63-176, 264-339): caption selection, brain-data lookup, what
+    reaches generate() per image, output files, the static shard rule -- the reference's own functions with `generate` / `Condition`
+    replaced by a recorder. The fixture is the recorded decisions (JSON)."""
+    import importlib.util
+    import json
+    import tempfile
+    import types as _t
+    from oracle import ducks
+    _ns("accelerate", init_empty_weights=None, infer_auto_device_map=None)
+    saved = {k: sys.modules.get(k) for k in ("src", "src.flux", "src.flux.condition", "src.flux.generate", "src.train", "src.train.model")}
+    rec = ducks.GenerateRecorder()
+    try:
+        # the reference imports `src.*`: hand it thin modules (its own src would pull the whole stack in; only three names are used)
+        _ns("src"); _ns("src.flux"); _ns("src.train")
+        _ns("src.flux.condition", Condition=lambda **kw: rec.condition(**kw))
+        _ns("src.flux.generate", generate=rec.generate)
+        _ns("src.train.model", OminiModel=object)
+        spec = importlib.util.spec_from_file_location("ref_inference", os.path.join(REF, "inference.py"))
+        ri = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ri)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    ri.tqdm = lambda x, **k: x
+    images, caps, brain = ducks.inference_case()
+    model = _t.SimpleNamespace(device=torch.device("cpu"), flux_pipe=object(), model_config={"union_cond_attn": True, "latent_lora": False})
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        idir, cap, pkl = ducks.write_inference_case(d, images, caps, brain)
+        # (1) batch_inference: one process, every captioned image
+        o1 = os.path.join(d, "out1")
+        ri.batch_inference(model, idir, o1, caption_path=cap, condition_type="subject", target_size=256, position_delta=[0, -16], seed=7,
+                           brain_data_path=pkl)
+        out["batch"] = dict(calls=rec.calls, files=sorted(os.listdir(o1)))
+        # (2) process_image_batch on 2 and 3 ranks: the static shard rule + per-rank outputs
+        bd = ri.load_brain_data(pkl)
+        captions = {}
+        with open(cap) as f:
+            for line in f:
+                item = json.loads(line)
+                name = os.path.basename(item.get("source_image", ""))
+                captions[name] = item["speech2text"] if "speech2text" in item else item.get("instruction", "Edit this image")
+        files = [f for f in captions if f.endswith((".png", ".jpg", ".jpeg"))]
+        out["image_files"] = files
+        for world in (2, 3):
+            per_rank = []
+            for rank in range(world):
+                rec.calls = []
+                o = os.path.join(d, f"out_w{world}_r{rank}")
+                os.makedirs(o)
+                ri.process_image_batch(rank, world, model, files, idir, o, captions, bd, "subject", [0, -16], 256, 11)
+                per_rank.append(dict(calls=rec.calls, files=sorted(os.listdir(o))))
+            out[f"world{world}"] = per_rank
+        out["missing_brain_file"] = ri.load_brain_data(os.path.join(d, "nope.pkl"))
+    with open(os.path.join(OUT, "inference_cli.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("inference_cli.json:", len(out["batch"]["calls"]), "batch calls;", [len(r["calls"]) for r in out["world2"]], [len(r["calls"]) for r in out["world3"]])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"{REF} not found: goldens can only be regenerated in the build container"
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (gold_flux, gold_cs3, gold_encoders, gold_eeg_encoder, gold_condition, gold_generate, gold_evaluate):
+    for fn in (gold_flux, gold_cs3, gold_encoders, gold_eeg_encoder, gold_condition, gold_generate, gold_evaluate, gold_inference):
         if not only or fn.__name__ in only:
             fn()
