@@ -16,7 +16,10 @@ import torch.distributed as dist
 
 
 def env_rank() -> Tuple[int, int, int]:
-    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    """(rank, local device index, world size) from the torchrun environment. LX_DIST_ONE_DEVICE=1 maps every rank to device 0 (a
+    rehearsal of the N > 1 control flow on a one-GPU box, with LX_DIST_BACKEND=gloo: RCCL refuses two ranks on one device)."""
+    local = 0 if os.environ.get("LX_DIST_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", 0))
+    return int(os.environ.get("RANK", 0)), local, int(os.environ.get("WORLD_SIZE", 1))
 
 
 def init(backend: Optional[str] = None, timeout_s: int = 600) -> Tuple[int, int, int]:
@@ -27,7 +30,7 @@ def init(backend: Optional[str] = None, timeout_s: int = 600) -> Tuple[int, int,
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("LX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
