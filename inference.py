@@ -201,11 +201,12 @@ def distributed_inference_worker(rank, world_size, args, config, model_loaded_ev
     """inference.py:194-252. Rank 0's packed DiT weights are broadcast over RCCL/xGMI instead of every rank re-reading and
     re-packing the checkpoint."""
     on_gpu = torch.cuda.is_available()
+    dev_index = 0 if os.environ.get("LX_DIST_ONE_DEVICE") == "1" else rank      # (rehearsal on a one-GPU box: every rank on device 0, gloo)
     if on_gpu:
-        torch.cuda.set_device(rank)
+        torch.cuda.set_device(dev_index)
     if world_size > 1:
         setup(rank, world_size)
-    device = torch.device("cuda", rank) if on_gpu else torch.device("cpu")
+    device = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
     if model_loaded_event is not None:
         model_loaded_event.wait()
     model = load_model("synthetic" if args.synthetic else args.checkpoint, config, device)
@@ -271,6 +272,8 @@ def main(argv=None):
     if not args.synthetic and not args.input_dir:
         p.error("--input_dir (and --caption_path) are required unless --synthetic or --single_image/--prompt is given")
     world = max(1, min(args.num_gpus, torch.cuda.device_count()))
+    if os.environ.get("LX_DIST_ONE_DEVICE") == "1":
+        world = max(1, args.num_gpus)
     if world == 1:
         if args.synthetic:
             distributed_inference_worker(0, 1, args, config)
