@@ -61,3 +61,35 @@ def test_inference_cli_two_workers_rehearsal_on_one_gpu(tmp_path):
     lat = [torch.load(os.path.join(out, f)) for f in files]
     assert all(x.shape == (256, 64) and torch.isfinite(x).all() for x in lat) and not torch.equal(lat[0], lat[3])
     assert "Running distributed inference on 2 GPUs" in r.stdout
+
+
+def test_rccl_backend_single_rank_smoke():
+    """RCCL itself on the box (backend "nccl" = RCCL on ROCm) with a one-rank communicator: the collectives loongx_amd.dist issues --
+    broadcast of bf16 / fp32 weight buckets, all_reduce(MAX) of the fp64 timing word, all_gather of result batches, barrier -- create
+    their communicator and run their kernels; with N = 1 there is nothing to exchange, but library loading, communicator set-up,
+    dtype support and stream semantics are the same code as for N > 1."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from loongx_amd import dist as lxd
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+t = {"w": torch.randn(1 << 20, device="cuda").to(torch.bfloat16), "b": torch.randn(4096, device="cuda"), "big": torch.randn(1 << 24, device="cuda").to(torch.bfloat16)}
+ref = {k: v.clone() for k, v in t.items()}
+# (lxd.broadcast_tensors short-circuits for world size 1: call the collectives it is made of directly)
+for k in t: dist.broadcast(t[k], 0)
+flat = torch.cat([t["w"].reshape(-1), t["big"].reshape(-1)]); dist.broadcast(flat, 0)
+x = torch.tensor([12.5], dtype=torch.float64, device="cuda"); dist.all_reduce(x, op=dist.ReduceOp.MAX)
+out = [torch.empty(3, 5, device="cuda")]; dist.all_gather(out, torch.arange(15.0, device="cuda").view(3, 5))
+dist.barrier(); torch.cuda.synchronize()
+assert all(torch.equal(t[k], ref[k]) for k in t) and float(x) == 12.5 and torch.equal(out[0].cpu(), torch.arange(15.0).view(3, 5))
+dist.destroy_process_group()
+print("RCCL_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
