@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 200 /* 0.2.0: + caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
+#define LX_VERSION 300 /* 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
+                          * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {
   LX_OK = 0,
