@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 300 /* 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
+#define LX_VERSION 301 /* 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
                           * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {
@@ -239,7 +239,16 @@ typedef struct lx_attn_desc {
   float scale;
   int32_t n_qseg;        /* 0 / n_seg: every segment has queries. k < n_seg: only segments 0..k-1 do (keys and values of all n_seg segments
                           * are still attended to): the rows of the other segments of O are not written */
+  int32_t flags;         /* LX_ATTN_* below (0 = the plain contract above) */
 } lx_attn_desc;
+/* LX_ATTN_Q_LOG2: q already carries scale * log2(e) (e.g. folded into the norm_q weight handed to LX_EPI_QKV / lx_qkv_prep): the kernel
+ * takes q.k as the exp2 argument as it is (`scale` is ignored).
+ * LX_ATTN_BOUNDED (needs LX_ATTN_Q_LOG2): the CALLER guarantees |q.k (log2 units) + bias * log2(e)| <= 100 for every (query, key) --
+ * true whenever q and k come out of the per-head RMSNorm of block.py:38-41,60-67 with 16.4 * max|norm_q| * max|norm_k| + |bias| * 1.45 <=
+ * 100: a normalised head vector has length <= sqrt(128) * max|w|, RoPE is a rotation. Softmax is shift-invariant and exp2 of such an
+ * argument neither overflows nor leaves fp32's normal range over 2^16 keys, so the kernel keeps NO running maximum: no row max, no
+ * rescale, no per-score multiply-add -- p = exp2(q.k [+ bias]). Results differ from the max-tracking form by rounding only. */
+enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2 };
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -45,7 +45,10 @@ class AttnDesc(C.Structure):
                 ("q_col", C.c_int32), ("k_col", C.c_int32), ("o_col", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
                 ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
-                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32)]
+                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32), ("flags", C.c_int32)]
+
+
+LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED = 1, 2
 
 
 class AttnF32Desc(C.Structure):

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
-  const float c2 = D.scale * 1.4426950408889634f;  // scores are kept in log2 units
+  const float c2 = (D.flags & LX_ATTN_Q_LOG2) ? 1.0f : D.scale * 1.4426950408889634f;  // scores are kept in log2 units
 
   f32x16 oacc[4];
 #pragma unroll
@@ -314,7 +314,11 @@ constexpr int pipe_half(int g, int k) {   // k-th (0/1) softmax half-unit (slice
   return -1;
 }
 
-template <bool DEFER>
+// MODE 0: online softmax with a running maximum (the general contract). MODE 1 / 2 (LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED, include/lx.h):
+// q carries scale * log2 e and the caller bounds every score, so there is no running maximum at all -- the row-max chunks of gaps 0-3
+// and the per-score v_fma go: p = exp2(s) (MODE 1: every unmasked segment pair has bias 0) or exp2(s + bias) (MODE 2). Measured with
+// elimination builds (profiles/r03s_attn_elim_*.txt): -5.8 % at S = 2560, -6.9 % at S = 8704.
+template <bool DEFER, int MODE>
 __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs args) {
   constexpr int NW = 8, QBLK = 256;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
-  const float c2 = D.scale * 1.4426950408889634f;
+  const float c2 = (D.flags & LX_ATTN_Q_LOG2) ? 1.0f : D.scale * 1.4426950408889634f;
 
   f32x16 oacc[4];
 #pragma unroll
@@ -436,7 +440,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #endif
   constexpr int LOOK = LX_ATTN_LOOK;           // fragments in flight ahead of the MFMA that consumes them (<= 6)
   bf16x8 ring[LOOK];
+#ifdef LX_ATTN_ELIM_SOFT
+  u32x4 pfw[4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}};
+#else
   u32x4 pfw[4];
+#endif
   f32x16 sA[2], sB[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if LX_ATTN_LSUM_MFMA == 2
@@ -461,7 +469,13 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 
 #define LX_FENCE() asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LX_BARRIER() LX_FENCE(); __builtin_amdgcn_s_barrier(); LX_FENCE()
+  // LX_ATTN_ELIM_*: timing experiments only (WRONG numbers): what one class of instructions costs the stream -- DSR the fragment reads,
+  // DMA the LDS-DMA pieces, EXP the exp2, SOFT the whole softmax half-units, BAR the end-of-iteration barrier (tools/run_r03u.sh)
+#ifdef LX_ATTN_ELIM_DSR
+#define LX_DSR(dst, addr, offs) asm volatile("" : "+v"(dst) : "v"(addr))
+#else
 #define LX_DSR(dst, addr, offs) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offs))
+#endif
 #define LX_WAITL(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
   // read of the fragment consumed at gap j (gaps >= last do not exist); QONLY: prologue stream of the 16 K fragments
 #define LX_RD(j, last, QONLY)                                                                                          \
@@ -512,10 +526,16 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   __builtin_amdgcn_sched_barrier(0)
   // softmax half-unit hu = slice*8 + value: one score -> one probability and the row sum; odd values also pack the bf16 pair.
   // The empty asm keeps it in ITS gap (hipcc sinks the arithmetic to the first use otherwise).
+#ifdef LX_ATTN_ELIM_EXP
+#define LX_EXP2(x) (x)
+#else
+#define LX_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#define LX_SCORE_ARG(x) (MODE == 0 ? fmaf(x, c2, off) : MODE == 1 ? (x) : (x) + off)
 #define LX_HALF(hu, SC)                                                                                                \
   {                                                                                                                    \
     constexpr int s_ = (hu) >> 3, r_ = 8 * (s_ & 1) + ((hu) & 7);                                                      \
-    const float p_ = __builtin_amdgcn_exp2f(fmaf(SC[s_ >> 1][r_], c2, off));                                           \
+    const float p_ = LX_EXP2(LX_SCORE_ARG(SC[s_ >> 1][r_]));                                                           \
     LX_LADD(p_)                                                                                                        \
     if ((hu) & 1) { pfw[s_][((hu) & 7) >> 1] = pack_bf16x2(p_even[s_ & 1], p_); asm volatile("" : "+v"(pfw[s_][((hu) & 7) >> 1]) LX_LPIN); } \
     else { p_even[s_ & 1] = p_; asm volatile("" : "+v"(p_even[s_ & 1]) LX_LPIN); }                                     \
@@ -582,22 +602,40 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #define LX_PRIO_AT(g)
 #endif
 #define LX_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
+#define LX_MCHUNK_MAYBE(g, SC) if constexpr (MODE == 0) { LX_MCHUNK(g, SC) }
+#ifdef LX_ATTN_ELIM_SOFT
+#define LX_HALVES(g, SC)
+#else
+#define LX_HALVES(g, SC)                                                                                               \
+  if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
+  if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }
+#endif
+#ifdef LX_ATTN_ELIM_DMA
+#define LX_PIECES(g)
+#else
+#define LX_PIECES(g)                                                                                                   \
+  if ((g) == LX_ATTN_PG0) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
+  if ((g) == LX_ATTN_PG1) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
+  if ((g) == LX_ATTN_PG2) piece(2, 0, t1.vpos, 0, vs_slot);                                                            \
+  if ((g) == LX_ATTN_PG3) piece(3, 0, t1.vpos, 0, vs_slot);
+#endif
 #define LX_GAP(g, SC, SN)                                                                                              \
   LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);                                       \
   LX_MM(g, SC, SN, false);                                                                                             \
   LX_RD((g) + LOOK, 32, false);                                                                                        \
-  LX_MCHUNK(g, SC)                                                                                                     \
-  if (pipe_half(g, 0) >= 0) { constexpr int h_ = pipe_half(g, 0) < 0 ? 0 : pipe_half(g, 0); LX_HALF(h_, SC); }         \
-  if (pipe_half(g, 1) >= 0) { constexpr int h_ = pipe_half(g, 1) < 0 ? 0 : pipe_half(g, 1); LX_HALF(h_, SC); }         \
+  LX_MCHUNK_MAYBE(g, SC)                                                                                               \
+  LX_HALVES(g, SC)                                                                                                     \
   LX_PRIO_AT(g)                                                                                                        \
-  if ((g) == LX_ATTN_PG0) piece(0, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
-  if ((g) == LX_ATTN_PG1) piece(1, t2.krow, 0, t2.nclamp, ks_slot);                                                    \
-  if ((g) == LX_ATTN_PG2) piece(2, 0, t1.vpos, 0, vs_slot);                                                            \
-  if ((g) == LX_ATTN_PG3) piece(3, 0, t1.vpos, 0, vs_slot);                                                            \
+  LX_PIECES(g)                                                                                                         \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_GAP4(g, SC, SN) LX_GAP(g, SC, SN); LX_GAP((g) + 1, SC, SN); LX_GAP((g) + 2, SC, SN); LX_GAP((g) + 3, SC, SN)
 
   // One iteration: softmax(t) + PV(t) + QK(t+1).  SC = scores of tile t (complete), SN = scores of tile t+1 (written).
+#ifdef LX_ATTN_ELIM_BAR
+#define LX_ITER_BARRIER()
+#else
+#define LX_ITER_BARRIER() LX_BARRIER()
+#endif
 #define LX_ITER(SC, SN)                                                                                                \
   {                                                                                                                    \
     const int ks_slot = t & 1, vs_slot = (t + 1) & 1;                                                                  \
@@ -607,6 +645,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     LX_RDP(0, 32, false); LX_RDP(1, 32, false); LX_RDP(2, 32, false); LX_RDP(3, 32, false); LX_RDP(4, 32, false); LX_RDP(5, 32, false); \
     /* ---- ragged last tile of the segment: mask keys past its end (rare, before the stream) ---- */                  \
     const float bl = t0.bl;                                                                                            \
+    if constexpr (MODE == 2) { off = bl; asm volatile("" : "+v"(off)); }   /* the segment pair's bias is the whole offset */ \
     if (t0.nvalid < KVBLK) {                                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* keeps this a wave-uniform branch: if-converted it is ~100 VALU on every tile */ \
       int lh4_ = 4 * lhi;                                                                                              \
@@ -622,7 +661,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     LX_PROBE_A();                                                                                                      \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
     LX_PROBE_B();                                                                                                      \
-    LX_BARRIER();                                                                                                      \
+    LX_ITER_BARRIER();                                                                                                 \
     LX_PROBE_C();                                                                                                      \
     t0 = t1; t1 = t2;                                                                                                  \
     gen_next();                                                                                                        \
@@ -688,6 +727,12 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_GAP
 #undef LX_PRIO_AT
 #undef LX_MCHUNK
+#undef LX_MCHUNK_MAYBE
+#undef LX_HALVES
+#undef LX_PIECES
+#undef LX_ITER_BARRIER
+#undef LX_EXP2
+#undef LX_SCORE_ARG
 #undef LX_LSCALE
 #undef LX_LSUM
 #undef LX_LADD
@@ -1175,13 +1220,26 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
       lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones_frag, pf_, lacc, 0, 0, 0, 0, 0, 0);                  \
       asm volatile("" : "+v"(lacc));                                                                                   \
     }                                                                                                                  \
+    LX8_PROBE_A();                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    LX8_PROBE_B();                                                                                                     \
     LX8_FENCE(); __builtin_amdgcn_s_barrier(); LX8_FENCE();                                                            \
+    LX8_PROBE_C();                                                                                                     \
     t0 = t1; t1 = t2;                                                                                                  \
     gen_next();                                                                                                        \
     t2 = g_cur;                                                                                                        \
   }
 
+#ifdef LX_ATTN_PROBE
+  unsigned long long pr_t0 = __builtin_amdgcn_s_memtime(), pr_a = 0, pr_b = 0, pr_c = 0, pr_vm = 0, pr_bar = 0, pr_loop0 = 0;
+#define LX8_PROBE_A() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_a = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define LX8_PROBE_B() pr_b = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_vm += pr_b - pr_a
+#define LX8_PROBE_C() pr_c = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pr_bar += pr_c - pr_b
+#else
+#define LX8_PROBE_A()
+#define LX8_PROBE_B()
+#define LX8_PROBE_C()
+#endif
   if (t0.nvalid > 0) {
     stage_k(t0, 0); stage_v(t0, 0); stage_k(t1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1220,6 +1278,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     }
     // every wave is done reading K(0) before the first iteration stages K(2) over it (see lx_attn_pipe_kernel)
     LX8_FENCE(); __builtin_amdgcn_s_barrier(); LX8_FENCE();
+#ifdef LX_ATTN_PROBE
+    pr_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
       LX8_ITER(s0, s1a, s1b, 0);
       if (t0.nvalid == 0) break;
@@ -1228,6 +1289,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     }
   }
 #undef LX8_ITER
+#undef LX8_PROBE_A
+#undef LX8_PROBE_B
+#undef LX8_PROBE_C
 #undef LX8_GAP
 #undef LX8_MM
 #undef LX8_MAX
@@ -1235,6 +1299,15 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 #undef LX8_SOFT
 #undef LX8_FENCE
 
+#ifdef LX_ATTN_PROBE
+  {
+    const unsigned long long pr_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x < 4096) {
+      unsigned long long* o = lx_attn_probe_buf + ((size_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = pr_end - pr_t0; o[1] = pr_end - pr_loop0; o[2] = pr_vm; o[3] = pr_bar;
+    }
+  }
+#endif
   const float l_tot = __shfl(lacc[0], l31, 64);          // lanes 0-31 hold the sum of query l31
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
   // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
@@ -1285,9 +1358,18 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
   hipStream_t st = (hipStream_t)stream;
-  if (piped) {
-    if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false>), dim3(grid), dim3(512), 0, st, a);
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
+               "lx_attn_fwd: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
+  bool any_bias = false;                       // a finite non-zero bias on a pair that is attended to
+  for (int s = 0; s < nq; ++s)
+    for (int k = 0; k < d->n_seg; ++k) any_bias |= d->bias[s][k] > -1e37f && d->bias[s][k] != 0.f;
+  static const bool nomax_ok = [] { const char* e = getenv("LX_ATTN_NOMAX"); return e ? atoi(e) != 0 : true; }();
+  if (piped && (d->flags & LX_ATTN_BOUNDED) && nomax_ok) {
+    if (any_bias) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 2>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 1>), dim3(grid), dim3(512), 0, st, a);
+  } else if (piped) {
+    if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 0>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false, 0>), dim3(grid), dim3(512), 0, st, a);
   } else if (nw == 8) {
     if (defer) hipLaunchKernelGGL((lx_attn_kernel<8, true>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((lx_attn_kernel<8, false>), dim3(grid), dim3(512), 0, st, a);
@@ -1306,6 +1388,7 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG(d->ldq % 16 == 0 && d->ldk % 16 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd_fp8: ldq/ldk %% 16 (bytes), ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
+  LX_CHECK_ARG(d->flags == 0, "lx_attn_fwd_fp8: flags must be 0 (the e4m3 kernels fold their own scales)");
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
   const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;

@@ -56,6 +56,7 @@ class DiTEngine:
         # Precise mode (model_config["precise"], default `precise_default`): fp32-class arithmetic for the reference's shipped
         # fp32 configuration -- split-bf16 MFMA GEMMs (2 or 3 K-segments), fp32 q/k/v, fp32 attention (csrc/precise.hip).
         self.precise_default = False
+        self.attn_nomax = False
         self.precise = False
         # fp8 GEMM path (model_config["gemm_fp8"]; BASELINE configs[4]): e4m3 operand images on the 64-deep f8f6f4 MFMA
         self.gemm_fp8 = False
@@ -312,6 +313,40 @@ class DiTEngine:
             self._compute_mods(temb_all, mods_all, lora=True, lora_only=True)
         self.sched = (host if host is not None else tuple(float(v) for v in t.tolist()), mods_all.view(n, B, cfg.n_mod))
 
+    def _setup_nomax(self) -> None:
+        """Bounded-score attention (include/lx.h LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED). q and k leave the per-head RMSNorm (block.py:60-67)
+        with |q| <= sqrt(128) max|norm_q|, and RoPE is a rotation, so |q.k| / sqrt(128) * log2 e <= 16.33 max|norm_q| max|norm_k|: when
+        that plus the largest finite bias stays under 100 the softmax needs no running maximum (exp2 cannot overflow, nor can a row sum
+        leave fp32's normal range), and with scale * log2 e folded into the norm_q weights the kernel's exp2 argument is the score MFMA's
+        output itself. The scaled weights and the bound are made once per weight set (outside any capture); LX_ATTN_NOMAX=0 disables."""
+        self.attn_nomax = False
+        if self.precise or self.model_config.get("attn_fp8", False) or os.environ.get("LX_ATTN_NOMAX", "1") == "0":
+            return
+        w = self.w
+        tab = getattr(w, "q_log2", None)
+        if tab is None:
+            qn = [n for n in w.t if n.endswith(".wq") or n.endswith(".wq_txt")]
+            kn = [n for n in w.t if n.endswith(".wk") or n.endswith(".wk_txt")]
+            if not qn or not kn:
+                return
+            qmax = max(float(w.t[n].abs().max()) for n in qn)
+            kmax = max(float(w.t[n].abs().max()) for n in kn)
+            tab = {"bound": 128.0 * ops.Q_LOG2_FACTOR * qmax * kmax,
+                   "q": {w.t[n].data_ptr(): (w.t[n], (w.t[n] * ops.Q_LOG2_FACTOR).contiguous()) for n in qn}}
+            w.q_log2 = tab
+        fin = [abs(v) for row in self.attn_bias.values() for v in row.values() if v > -1e37]
+        self.attn_nomax = tab["bound"] + max(fin, default=0.0) * 1.4426950408889634 <= 100.0
+
+    def _qn(self, wq: torch.Tensor) -> torch.Tensor:
+        """The norm_q weight an attention launch of this forward is fed: scale * log2 e folded in when the bounded-score kernel runs."""
+        if not self.attn_nomax:
+            return wq
+        e = self.w.q_log2["q"].get(wq.data_ptr())
+        if e is None or e[0] is not wq:               # a norm weight installed after the table was made
+            e = (wq, (wq * ops.Q_LOG2_FACTOR).contiguous())
+            self.w.q_log2["q"][wq.data_ptr()] = e
+        return e[1]
+
     def _attn_bias(self) -> Dict[str, Dict[str, float]]:
         """block.py:106-128 as a (query stream, key stream) table: 0, log(c_factor) or -inf."""
         names = ("txt", "img", "cond")
@@ -402,6 +437,7 @@ class DiTEngine:
             self._time_text_embed(ct, self.cond_temb, self.temb_base)
             self._compute_mods(self.cond_temb, self.cmods, lora=True)
         self.attn_bias = self._attn_bias()
+        self._setup_nomax()
         self.cond_ready = True
         self.cond_cached = False          # a new condition stream: the per-layer key / value images are stale
         self.sched = None
@@ -492,7 +528,7 @@ class DiTEngine:
             kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
             if qkv is not None:                # (wq, wk, wq_txt, wk_txt[, layer]): RMSNorm + RoPE + V^T in this launch's epilogue
                 rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
-                kw["qkv"] = dict(norm_q=qkv[2] if s == "txt" else qkv[0], norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
+                kw["qkv"] = dict(norm_q=self._qn(qkv[2] if s == "txt" else qkv[0]), norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
                                  vt=self.VT, vt_pos0=self.vt0[s], d=self.cfg.inner_dim)
                 if self.model_config.get("attn_fp8", False):      # e4m3 q / k / V^T images straight from the accumulators
                     self._fp8_images()
@@ -560,8 +596,9 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            qsegs.append((row0, L, self.vt0[s], wq_txt if s == "txt" else wq, wk_txt if s == "txt" else wk, cos, sin))
+            qsegs.append((row0, L, self.vt0[s], self._qn(wq_txt if s == "txt" else wq), wk_txt if s == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
+        flags = (ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self.attn_nomax else 0
         if self.model_config.get("attn_fp8", False):
             # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
@@ -575,12 +612,12 @@ class DiTEngine:
             # keys from the layer's key image, V^T from the layer's V^T image (the condition stream's part written by the first
             # forward of this conditioning); in a cond_skip forward only the text / image segments have queries
             ops.attn_fwd(Y, self.KC[layer], self.VTC[layer], Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0,
-                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0)
+                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0, flags=flags)
             return
         if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
             ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
-                     seg_vt0=seg_vt0, bias=bias)
+                     seg_vt0=seg_vt0, bias=bias, flags=flags)
 
     # ------------------------------------------------------------------------------------------ blocks
     def double_block(self, i: int) -> None:
@@ -1137,6 +1174,7 @@ class DiTEngine:
         elif self.model_config.get("attn_fp8", False):
             self._fp8_images()
         self.attn_bias = self._attn_bias()
+        self._setup_nomax()
         f32 = torch.float32
         if rope_main is not None:
             self.cos_main, self.sin_main = (t.to(self.device, f32).contiguous() for t in rope_main)

@@ -308,10 +308,16 @@ def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt
     return d
 
 
-def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0) -> None:
-    """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values)."""
+ATTN_Q_LOG2, ATTN_BOUNDED = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED
+Q_LOG2_FACTOR = (1.0 / math.sqrt(128.0)) * 1.4426950408889634       # what LX_ATTN_Q_LOG2 expects q to carry already
+
+
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0, flags=0) -> None:
+    """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values).
+    flags: ATTN_Q_LOG2 [| ATTN_BOUNDED] (include/lx.h): q carries scale * log2 e; the caller bounds the scores -> no running max."""
     d = _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
     d.n_qseg = n_qseg
+    d.flags = flags
     if TIMER is not None:
         S = sum(seg_len)
         Sq = sum(seg_len[:n_qseg]) if n_qseg else S

@@ -655,6 +655,45 @@ def test_attention_single_segment_spike(ops):
     assert relerr(buf.float().cpu()[:, 2 * D:].view(1, Ls, 1, 128), ref) < 6e-3
 
 
+@pytest.mark.parametrize("mode", ["none", "cfactor", "independent"])
+@pytest.mark.parametrize("lens,gain", [((16, 16, 16), 1.0), ((64, 128, 200), 2.2), ((512, 1024, 1024), 1.5)])
+def test_attention_bounded_scores(ops, lens, gain, mode):
+    """LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED (include/lx.h): q RMS-normalised with scale * log2 e folded into norm_q, no running maximum in
+    the kernel. gain = max|norm_q| = max|norm_k|: 16.33 * 2.2^2 = 79 (+ |log 0.5| * 1.45) is close to the bound of 100 the caller
+    must keep. Checked against fp32 SDPA on the same (prepped) q / k / v and against the max-tracking kernel on the same buffer."""
+    B, H = (1, 2) if lens[0] == 512 else (2, 3)
+    D = H * 128
+    buf = _qkv_buffer(B, lens, H, seed=11)
+    row0, vt0, vt_len = _segments(B, lens)
+    VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    wk = ((torch.rand(128, generator=g) * 0.5 + 0.5) * gain).to(DEV)
+    wk[5] = gain
+    wq = wk.flip(0).contiguous()
+    assert 128 * ops.Q_LOG2_FACTOR * float(wq.max()) * float(wk.max()) + 1.0 <= 100.0
+    for s, Ls in enumerate(lens):
+        ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=row0[s], n_rows=B * Ls, rows_per_batch=Ls, H=H,
+                     wq=(wq * ops.Q_LOG2_FACTOR).contiguous(), wk=wk, cos=None, sin=None, VT=VT, vt_pos0=vt0[s])
+    prepped = buf.clone()
+    bias = BIASES[mode]
+    kw = dict(q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=bias)
+    ops.attn_fwd(buf, buf, VT, buf, flags=ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED, **kw)
+    tracked = prepped.clone()
+    ops.attn_fwd(tracked, tracked, VT, tracked, flags=ops.ATTN_Q_LOG2, **kw)
+    refbuf = prepped.float()
+    refbuf[:, 2 * D:] *= math.log(2.0) * math.sqrt(128.0)              # SDPA's own 1/sqrt(128) and base e
+    ref, edges = _attn_reference(refbuf, B, H, lens, bias, 2 * D, 0, D)
+    got, trk = buf.float().cpu(), tracked.float().cpu()
+    for s, Ls in enumerate(lens):
+        sl = slice(row0[s], row0[s] + B * Ls)
+        o = got[sl, 2 * D: 3 * D].view(B, Ls, H, 128)
+        assert relerr(o, ref[:, edges[s]:edges[s + 1]]) < 6e-3, f"segment {s}"
+        assert relerr(got[sl, 2 * D:], trk[sl, 2 * D:]) < 6e-3, f"segment {s} vs the max-tracking kernel"
+    assert torch.equal(buf[:, : 2 * D], prepped[:, : 2 * D])
+    with pytest.raises(LxError):                      # BOUNDED without Q_LOG2
+        ops.attn_fwd(buf, buf, VT, buf, flags=ops.ATTN_BOUNDED, **kw)
+
+
 # ------------------------------------------------------------------------------------------ CS3 / DGF
 @pytest.mark.parametrize("H,N,L", [(4, 4, 256), (6, 6, 512), (6, 6, 128), (64, 64, 4096)])
 def test_s4_scan_and_conv(ops, H, N, L):

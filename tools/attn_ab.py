@@ -19,7 +19,11 @@ M = B * sum(lens)
 g = torch.Generator(device=dev).manual_seed(0)
 buf = torch.randn(M, 3 * D, device=dev, generator=g).to(torch.bfloat16)
 row0 = [0, B * lens[0], B * (lens[0] + lens[1])]; vt0 = [0, lens[0], lens[0] + lens[1]]
-segs = [(row0[i], lens[i], vt0[i], None, None, None, None) for i in range(3)]
+import os
+flags = int(os.environ.get("AB_FLAGS", "0"))          # AB_NORM=1: RMS-normalised q / k (what the engine feeds); AB_FLAGS=3: + the bounded-score kernel
+one = torch.ones(128, device=dev) if (flags or os.environ.get("AB_NORM")) else None
+oneq = one * ops.Q_LOG2_FACTOR if flags else one
+segs = [(row0[i], lens[i], vt0[i], oneq, one, None, None) for i in range(3)]
 O = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
 if fp8:
     Q8 = torch.zeros(M, D, dtype=torch.uint8, device=dev); K8 = torch.zeros_like(Q8)
@@ -30,7 +34,7 @@ else:
     VT = torch.zeros(B, H, 128, sum(lens), dtype=torch.bfloat16, device=dev)
     q = buf.clone()
     ops.qkv_prep_segs(q, 2 * D, 0, D, segs, B, H, VT)
-    run = lambda: ops.attn_fwd(q, q, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
+    run = lambda: ops.attn_fwd(q, q, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=flags)
 for _ in range(10): run()
 torch.cuda.synchronize()
 best = 1e9

@@ -13,6 +13,7 @@ from loongx_amd import ops
 from loongx_amd._lib import lib
 
 big = "--big" in sys.argv
+fp8 = "--fp8" in sys.argv
 dev = "cuda"; B, H = 1, 24; lens = (512, 4096, 4096) if big else (512, 1024, 1024); D = H * 128
 M = B * sum(lens)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -23,6 +24,11 @@ O = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
 VT = torch.zeros(B, H, 128, sum(lens), dtype=torch.bfloat16, device=dev)
 ops.qkv_prep_segs(buf, 2 * D, 0, D, segs, B, H, VT)
 run = lambda: ops.attn_fwd(buf, buf, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
+if fp8:
+    Q8 = torch.zeros(M, D, dtype=torch.uint8, device=dev); K8 = torch.zeros_like(Q8)
+    VT8 = torch.zeros(B, H, 128, sum(lens), dtype=torch.uint8, device=dev)
+    ops.qkv_prep_fp8_segs(buf, 2 * D, 0, D, segs, B, H, Q8, K8, VT8)
+    run = lambda: ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
 for _ in range(5):
     run()
 torch.cuda.synchronize()
