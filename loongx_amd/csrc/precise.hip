@@ -404,6 +404,9 @@ constexpr int SP_KV = 64, SP_DH = 128;
 constexpr int SP_TILE = SP_KV * SP_DH * 2;     // one operand tile: 16 KiB
 constexpr int SP_STAGE = 4 * SP_TILE;          // K_hi | K_lo | V^T_hi | V^T_lo
 
+// BOUNDED (LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED, include/lx.h): q carries scale * log2 e and the caller bounds the scores: no running
+// maximum, no rescale of O -- p = exp2(s + bias)
+template <bool BOUNDED>
 __global__ __launch_bounds__(512, 1) void attn_split_kernel(const AttnSplitArgs args) {
   constexpr int NW = 8, QBLK = 256, PIECES = 2;
   __shared__ __attribute__((aligned(1024))) char smem[2 * SP_STAGE];
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void attn_split_kernel(const AttnSplitArgs 
       ql[ks] = *(const bf16x8*)(qp + args.qk_lo_off + ks * 16);
     }
   }
-  const float c2 = D.scale * 1.4426950408889634f;   // scores are kept in log2 units
+  const float c2 = (D.flags & LX_ATTN_Q_LOG2) ? 1.0f : D.scale * 1.4426950408889634f;   // scores are kept in log2 units
   f32x16 oacc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -523,27 +526,30 @@ __global__ __launch_bounds__(512, 1) void attn_split_kernel(const AttnSplitArgs 
           if (key >= klen) sacc[kb][r] = -1e30f;
         }
     }
-    float tmax = fmaxf(sacc[0][0], sacc[0][1]);
+    float off = bl;
+    if constexpr (!BOUNDED) {
+      float tmax = fmaxf(sacc[0][0], sacc[0][1]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax * c2 + bl);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    l_run *= alpha;
-    m_run = m_new;
+        for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax * c2 + bl);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    const float off = bl - m_run;
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      off = bl - m_run;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, off));
+        const float p = __builtin_amdgcn_exp2f(BOUNDED ? sacc[kb][r] + off : fmaf(sacc[kb][r], c2, off));
         sacc[kb][r] = p;
         psum += p;
       }
@@ -737,7 +743,10 @@ extern "C" int lx_attn_fwd_split(const lx_attn_desc* d, int qk_lo_off, long long
     }
   }
   a.qt_start[3] = t;
-  hipLaunchKernelGGL(attn_split_kernel, dim3(t * d->B * d->H), dim3(512), 0, (hipStream_t)stream, a);
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
+               "lx_attn_fwd_split: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
+  if (d->flags & LX_ATTN_BOUNDED) hipLaunchKernelGGL(attn_split_kernel<true>, dim3(t * d->B * d->H), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_split_kernel<false>, dim3(t * d->B * d->H), dim3(512), 0, (hipStream_t)stream, a);
   LX_LAUNCH_CHECK("lx_attn_fwd_split");
   return LX_OK;
 }

@@ -320,7 +320,9 @@ class DiTEngine:
         leave fp32's normal range), and with scale * log2 e folded into the norm_q weights the kernel's exp2 argument is the score MFMA's
         output itself. The scaled weights and the bound are made once per weight set (outside any capture); LX_ATTN_NOMAX=0 disables."""
         self.attn_nomax = False
-        if self.precise or self.model_config.get("attn_fp8", False) or os.environ.get("LX_ATTN_NOMAX", "1") == "0":
+        if self.model_config.get("attn_fp8", False) and not self.precise:
+            return                                                 # (e4m3 probabilities need the running maximum: their range is 2^17)
+        if (self.precise and not getattr(self, "precise_attn_split", False)) or os.environ.get("LX_ATTN_NOMAX", "1") == "0":
             return
         w = self.w
         tab = getattr(w, "q_log2", None)
@@ -939,13 +941,14 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            qsegs.append((row0, L, self.vt0[s_], wq_txt if s_ == "txt" else wq, wk_txt if s_ == "txt" else wk, cos, sin))
+            qsegs.append((row0, L, self.vt0[s_], self._qn(wq_txt if s_ == "txt" else wq), wk_txt if s_ == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L)
         if self.precise_attn_split:
             # split-bf16 attention: hi.hi + hi.lo + lo.hi on the bf16 MFMA (3/16 of the fp32-MFMA cost), fp32 softmax
             ops.qkv_prep_split_segs(self.Y32, 2 * D, 0, D, qsegs, B, H, self.QK2, q2_col=2 * D, k2_col=0, lo_off=D, VT2=self.VT2)
             ops.attn_fwd_split(self.QK2, self.VT2, self.YA, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=5 * D, B=B, H=H,
-                               seg_row0=seg_row0, seg_len=seg_len, seg_vt0=[q[2] for q in qsegs], bias=bias)
+                               seg_row0=seg_row0, seg_len=seg_len, seg_vt0=[q[2] for q in qsegs], bias=bias,
+                               flags=(ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self.attn_nomax else 0)
             return
         ops.qkv_prep_f32_segs(self.Y32, 2 * D, 0, qsegs, B, H)
         ops.attn_fwd_f32(self.Y32, self.YA, q_col=2 * D, k_col=0, v_col=D, o_col=0, o_lo_off=5 * D, B=B, H=H, seg_row0=seg_row0,

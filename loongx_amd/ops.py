@@ -452,11 +452,13 @@ def qkv_prep_split_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, QK2, q2_co
                                      q2_col, k2_col, lo_off, VT2.data_ptr(), VT2.shape[-1], VT2.stride(0), _stream()), "lx_qkv_prep_split_segs")
 
 
-def attn_fwd_split(QK2, VT2, O, *, q_col, k_col, qk_lo_off, o_col, o_lo_off, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+def attn_fwd_split(QK2, VT2, O, *, q_col, k_col, qk_lo_off, o_col, o_lo_off, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None,
+                   flags=0) -> None:
     """Precise-mode attention on the bf16 matrix pipe: q / k pairs in QK2 (hi at q_col / k_col, lo qk_lo_off columns further), the two V^T
     images in VT2 [2, B, H, 128, Spad]; O bf16 gets the output pair (hi at o_col, lo o_lo_off columns further)."""
     _req(QK2, torch.bfloat16, "QK2"); _req(VT2, torch.bfloat16, "VT2"); _req(O, torch.bfloat16, "O")
     d = _attn_desc(QK2, QK2, VT2, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
+    d.flags = flags
     args = (C.byref(d), qk_lo_off, VT2.stride(0), o_lo_off, _stream())
     if TIMER is not None and TIMER.active:
         S = sum(seg_len)

@@ -690,6 +690,7 @@ def test_attention_bounded_scores(ops, lens, gain, mode):
         assert relerr(o, ref[:, edges[s]:edges[s + 1]]) < 6e-3, f"segment {s}"
         assert relerr(got[sl, 2 * D:], trk[sl, 2 * D:]) < 6e-3, f"segment {s} vs the max-tracking kernel"
     assert torch.equal(buf[:, : 2 * D], prepped[:, : 2 * D])
+    from loongx_amd._lib import LxError
     with pytest.raises(LxError):                      # BOUNDED without Q_LOG2
         ops.attn_fwd(buf, buf, VT, buf, flags=ops.ATTN_BOUNDED, **kw)
 

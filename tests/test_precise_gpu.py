@@ -223,6 +223,37 @@ def test_attention_split_bf16(ops, lens, mode):
     assert torch.equal(O, again)                                       # deterministic
 
 
+@pytest.mark.parametrize("lens,mode", [((40, 100, 70), "cfactor"), ((512, 1024, 1024), "none"), ((512, 1024, 1024), "nounion"), ((300,), "none")])
+def test_attention_split_bounded_scores(ops, lens, mode):
+    """LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED on the split-bf16 kernel: q carries scale * log2 e (folded in fp32 before the hi / lo split),
+    no running maximum, no rescale of O; the same fp32-class bound against fp64 attention as the max-tracking form."""
+    B, H = (2, 2) if sum(lens) < 1000 else (1, 3)
+    D = H * 128
+    ninf = float("-inf")
+    bias = {"none": [[0.0] * 3] * 3, "cfactor": [[0, 0, math.log(0.5)], [0, 0, math.log(0.5)], [math.log(0.5), math.log(0.5), 0]],
+            "nounion": [[0, 0, ninf], [0, 0, ninf], [ninf, ninf, 0]]}[mode]
+    M = B * sum(lens)
+    buf = rnd(M, 3 * D, seed=13)
+    buf[:, 2 * D:] *= 0.7                                              # |q.k| / sqrt(128) * log2 e stays far below the bound of 100
+    scaled = buf.clone()
+    scaled[:, 2 * D:] *= ops.Q_LOG2_FACTOR
+    QK2, VT2, row0, vt0 = _split_images(ops, scaled, B, H, list(lens))
+    O = torch.zeros(M, 2 * D, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd_split(QK2, VT2, O, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=D, B=B, H=H, seg_row0=row0, seg_len=list(lens),
+                       seg_vt0=vt0, bias=bias, flags=ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED)
+    got = O[:, :D].float() + O[:, D:].float()
+
+    def gather(col):
+        parts = [buf[row0[i]:row0[i] + B * L, col:col + D].view(B, L, H, 128) for i, L in enumerate(lens)]
+        return torch.cat(parts, 1).permute(0, 2, 1, 3)
+    ref = _attn_ref(gather(2 * D), gather(0), gather(D), lens, bias).permute(0, 2, 1, 3)
+    e = 0
+    for i, L in enumerate(lens):
+        g = got[row0[i]:row0[i] + B * L].view(B, L, H, 128)
+        assert relerr(g, ref[:, e:e + L].float()) < 3e-5, f"segment {i}"
+        e += L
+
+
 def test_attention_split_spiked_scores(ops):
     """An outlier key (raw q.k far above the row's other scores) late in the sequence: the running maximum jumps and every
     accumulator is rescaled; exact-max softmax must still agree with fp64."""
