@@ -319,7 +319,7 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
                      "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if f32_attn else
                      "attn_split_kernel (bf16 32x32x16 MFMA, 3 cross terms per product: achieved counts ALGORITHMIC flops, the MFMAs do 3x)" if precise
                      else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream"
-                          + (", bounded-score softmax: no running maximum)" if os.environ.get("LX_ATTN_NOMAX", "1") != "0" else ")"))
+                          + (", bounded-score softmax: no running maximum)" if model.transformer.engine.attn_nomax else ")"))
             res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
                                          "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
                                          "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),

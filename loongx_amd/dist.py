@@ -100,7 +100,10 @@ def broadcast_packed_weights(pw, src: int = 0) -> int:
         flat[f"{k}::lora_down"], flat[f"{k}::lora_up"] = lo.down, lo.up
         if lo.down_lo is not None:
             flat[f"{k}::lora_down_lo"] = lo.down_lo
-    return broadcast_tensors(flat, src)
+    n = broadcast_tensors(flat, src)
+    if hasattr(pw, "q_log2"):          # derived from the norm weights that were just overwritten (engine._setup_nomax rebuilds it)
+        del pw.q_log2
+    return n
 
 
 def gather_batches(local: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor]:

@@ -318,7 +318,9 @@ class DiTEngine:
         with |q| <= sqrt(128) max|norm_q|, and RoPE is a rotation, so |q.k| / sqrt(128) * log2 e <= 16.33 max|norm_q| max|norm_k|: when
         that plus the largest finite bias stays under 100 the softmax needs no running maximum (exp2 cannot overflow, nor can a row sum
         leave fp32's normal range), and with scale * log2 e folded into the norm_q weights the kernel's exp2 argument is the score MFMA's
-        output itself. The scaled weights and the bound are made once per weight set (outside any capture); LX_ATTN_NOMAX=0 disables."""
+        output itself. Decided PER LAYER (the joint attention of a double block mixes both streams' norms: the larger of each pair
+        counts); a layer whose weights break the bound keeps the max-tracking kernel. The scaled weights and the bounds are made once per
+        weight set (one host sync, outside any capture); LX_ATTN_NOMAX=0 disables."""
         self.attn_nomax = False
         if self.model_config.get("attn_fp8", False) and not self.precise:
             return                                                 # (e4m3 probabilities need the running maximum: their range is 2^17)
@@ -327,27 +329,35 @@ class DiTEngine:
         w = self.w
         tab = getattr(w, "q_log2", None)
         if tab is None:
-            qn = [n for n in w.t if n.endswith(".wq") or n.endswith(".wq_txt")]
-            kn = [n for n in w.t if n.endswith(".wk") or n.endswith(".wk_txt")]
-            if not qn or not kn:
+            layers = []
+            for n in w.t:
+                if n.endswith(".wq"):
+                    p = n[:-3]
+                    layers.append((w.t[n], w.t[p + ".wk"], w.t.get(p + ".wq_txt", w.t[n]), w.t.get(p + ".wk_txt", w.t[p + ".wk"])))
+            if not layers:
                 return
-            qmax = max(float(w.t[n].abs().max()) for n in qn)
-            kmax = max(float(w.t[n].abs().max()) for n in kn)
-            tab = {"bound": 128.0 * ops.Q_LOG2_FACTOR * qmax * kmax,
-                   "q": {w.t[n].data_ptr(): (w.t[n], (w.t[n] * ops.Q_LOG2_FACTOR).contiguous()) for n in qn}}
+            mx = torch.stack([torch.stack([torch.maximum(a.abs().max(), c.abs().max()), torch.maximum(b.abs().max(), d.abs().max())])
+                              for a, b, c, d in layers]).tolist()
+            tab = {}
+            for (a, b, c, d), (qm, km) in zip(layers, mx):
+                tab[a.data_ptr()] = {"wq": a, "bound": 128.0 * ops.Q_LOG2_FACTOR * qm * km,
+                                     "scaled": {a.data_ptr(): (a * ops.Q_LOG2_FACTOR).contiguous(), c.data_ptr(): (c * ops.Q_LOG2_FACTOR).contiguous()}}
             w.q_log2 = tab
         fin = [abs(v) for row in self.attn_bias.values() for v in row.values() if v > -1e37]
-        self.attn_nomax = tab["bound"] + max(fin, default=0.0) * 1.4426950408889634 <= 100.0
+        self._nomax_room = 100.0 - max(fin, default=0.0) * 1.4426950408889634
+        self.attn_nomax = any(e["bound"] <= self._nomax_room for e in tab.values())      # (some layer of this forward runs the bounded kernel)
 
-    def _qn(self, wq: torch.Tensor) -> torch.Tensor:
-        """The norm_q weight an attention launch of this forward is fed: scale * log2 e folded in when the bounded-score kernel runs."""
+    def _layer_nomax(self, wq: torch.Tensor) -> bool:
+        """Does the layer whose image-stream norm_q weight is `wq` run the bounded-score kernel in this forward?"""
         if not self.attn_nomax:
-            return wq
-        e = self.w.q_log2["q"].get(wq.data_ptr())
-        if e is None or e[0] is not wq:               # a norm weight installed after the table was made
-            e = (wq, (wq * ops.Q_LOG2_FACTOR).contiguous())
-            self.w.q_log2["q"][wq.data_ptr()] = e
-        return e[1]
+            return False
+        e = self.w.q_log2.get(wq.data_ptr())
+        return e is not None and e["wq"] is wq and e["bound"] <= self._nomax_room       # (an unknown / replaced weight: max tracking)
+
+    def _qn(self, w_q: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
+        """The norm_q weight (`w_q`: the layer's image- or text-stream one) an attention launch of this forward is fed: with scale * log2 e
+        folded in when the layer (named by its image-stream weight `wq`) runs the bounded-score kernel."""
+        return self.w.q_log2[wq.data_ptr()]["scaled"][w_q.data_ptr()] if self._layer_nomax(wq) else w_q
 
     def _attn_bias(self) -> Dict[str, Dict[str, float]]:
         """block.py:106-128 as a (query stream, key stream) table: 0, log(c_factor) or -inf."""
@@ -530,7 +540,7 @@ class DiTEngine:
             kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
             if qkv is not None:                # (wq, wk, wq_txt, wk_txt[, layer]): RMSNorm + RoPE + V^T in this launch's epilogue
                 rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
-                kw["qkv"] = dict(norm_q=self._qn(qkv[2] if s == "txt" else qkv[0]), norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
+                kw["qkv"] = dict(norm_q=self._qn(qkv[2] if s == "txt" else qkv[0], qkv[0]), norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
                                  vt=self.VT, vt_pos0=self.vt0[s], d=self.cfg.inner_dim)
                 if self.model_config.get("attn_fp8", False):      # e4m3 q / k / V^T images straight from the accumulators
                     self._fp8_images()
@@ -598,9 +608,9 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            qsegs.append((row0, L, self.vt0[s], self._qn(wq_txt if s == "txt" else wq), wk_txt if s == "txt" else wk, cos, sin))
+            qsegs.append((row0, L, self.vt0[s], self._qn(wq_txt if s == "txt" else wq, wq), wk_txt if s == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
-        flags = (ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self.attn_nomax else 0
+        flags = (ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self._layer_nomax(wq) else 0
         if self.model_config.get("attn_fp8", False):
             # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
@@ -941,14 +951,14 @@ class DiTEngine:
             else:
                 cos, sin = self.cos_main[off:off + L], self.sin_main[off:off + L]
                 off += L
-            qsegs.append((row0, L, self.vt0[s_], self._qn(wq_txt if s_ == "txt" else wq), wk_txt if s_ == "txt" else wk, cos, sin))
+            qsegs.append((row0, L, self.vt0[s_], self._qn(wq_txt if s_ == "txt" else wq, wq), wk_txt if s_ == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L)
         if self.precise_attn_split:
             # split-bf16 attention: hi.hi + hi.lo + lo.hi on the bf16 MFMA (3/16 of the fp32-MFMA cost), fp32 softmax
             ops.qkv_prep_split_segs(self.Y32, 2 * D, 0, D, qsegs, B, H, self.QK2, q2_col=2 * D, k2_col=0, lo_off=D, VT2=self.VT2)
             ops.attn_fwd_split(self.QK2, self.VT2, self.YA, q_col=2 * D, k_col=0, qk_lo_off=D, o_col=0, o_lo_off=5 * D, B=B, H=H,
                                seg_row0=seg_row0, seg_len=seg_len, seg_vt0=[q[2] for q in qsegs], bias=bias,
-                               flags=(ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self.attn_nomax else 0)
+                               flags=(ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self._layer_nomax(wq) else 0)
             return
         ops.qkv_prep_f32_segs(self.Y32, 2 * D, 0, qsegs, B, H)
         ops.attn_fwd_f32(self.Y32, self.YA, q_col=2 * D, k_col=0, v_col=D, o_col=0, o_lo_off=5 * D, B=B, H=H, seg_row0=seg_row0,

@@ -44,6 +44,34 @@ def test_forward_matches_reference_goldens(G):
     assert relerr(_run(eng, G), G["fwd_cond"]) < TOL      # shape/conditioning switches leave no stale state
 
 
+def test_bounded_score_attention_is_decided_per_layer(G, monkeypatch):
+    """The engine runs the no-running-maximum attention kernel (engine._setup_nomax) only on layers whose norm_q / norm_k weights keep
+    16.33 max|norm_q| max|norm_k| + bias under 100; a layer outside the bound keeps the max-tracking kernel. Either way the forward
+    agrees with the fp32 oracle, and with the engine that never uses the bounded kernel (LX_ATTN_NOMAX=0)."""
+    tr = tiny_transformer()
+    blk = tr.transformer_blocks[1]
+    with torch.no_grad():
+        blk.attn.norm_q.weight.mul_(4.0)           # 16.33 x 4 x 2.5 = 163 > 100: this layer must fall back
+        blk.attn.norm_k.weight.mul_(2.5)
+        ref = fr.tranformer_forward(tr, G["in_cond"], G["in_cond_ids"], None, {}, hidden_states=G["in_latents"],
+                                    encoder_hidden_states=G["in_enc"], pooled_projections=G["in_pooled"], timestep=G["in_timestep"],
+                                    img_ids=G["in_img_ids"], txt_ids=G["in_txt_ids"], guidance=G["in_guidance"])[0]
+    eng = _engine(tr)
+    got = _run(eng, G)
+    w = eng.w.t
+    assert eng.attn_nomax and not eng._layer_nomax(w["d1.wq"]) and eng._layer_nomax(w["d0.wq"]) and eng._layer_nomax(w["s0.wq"])
+    assert eng._qn(w["d1.wq_txt"], w["d1.wq"]) is w["d1.wq_txt"] and eng._qn(w["d0.wq"], w["d0.wq"]) is not w["d0.wq"]
+    assert relerr(got, ref) < TOL
+    monkeypatch.setenv("LX_ATTN_NOMAX", "0")
+    eng0 = _engine(tr)
+    got0 = _run(eng0, G)
+    assert not eng0.attn_nomax and relerr(got0, ref) < TOL and relerr(got, got0) < 6e-3
+    # a bias large enough to use up the room (c_factor = e^70: log2 units 101) switches every layer back
+    monkeypatch.delenv("LX_ATTN_NOMAX")
+    _run(eng, G, c_factor=2.5e30)
+    assert not eng.attn_nomax
+
+
 def test_forward_no_guidance(G):
     eng = _engine(tiny_transformer(seed=3, guidance_embeds=False))
     assert relerr(_run(eng, G, guidance=False), G["fwd_noguidance_seed3"]) < TOL
