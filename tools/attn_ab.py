@@ -14,16 +14,19 @@ import sys, hashlib, torch
 sys.path.insert(0, %r)
 from loongx_amd import ops
 big, fp8 = %r, %r
-dev = "cuda"; B, H = 1, 24; lens = (512, 4096, 4096) if big else (512, 1024, 1024); D = H * 128
+dev = "cuda"; B, H = 1, 24; lens = (512, 4096, 4096) if big else (512, 1024, 1024)
+import os
+if os.environ.get("AB_SHAPE"):        # AB_SHAPE=BxHxL: one segment (e.g. 16x64x2048: the shape the programming guide quotes attention rates on)
+    B, H, L0 = (int(v) for v in os.environ["AB_SHAPE"].split("x")); lens = (L0,)
+D = H * 128
 M = B * sum(lens)
 g = torch.Generator(device=dev).manual_seed(0)
 buf = torch.randn(M, 3 * D, device=dev, generator=g).to(torch.bfloat16)
-row0 = [0, B * lens[0], B * (lens[0] + lens[1])]; vt0 = [0, lens[0], lens[0] + lens[1]]
-import os
+row0 = [B * sum(lens[:i]) for i in range(len(lens))]; vt0 = [sum(lens[:i]) for i in range(len(lens))]
 flags = int(os.environ.get("AB_FLAGS", "0"))          # AB_NORM=1: RMS-normalised q / k (what the engine feeds); AB_FLAGS=3: + the bounded-score kernel
 one = torch.ones(128, device=dev) if (flags or os.environ.get("AB_NORM")) else None
 oneq = one * ops.Q_LOG2_FACTOR if flags else one
-segs = [(row0[i], lens[i], vt0[i], oneq, one, None, None) for i in range(3)]
+segs = [(row0[i], lens[i], vt0[i], oneq, one, None, None) for i in range(len(lens))]
 O = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
 if fp8:
     Q8 = torch.zeros(M, D, dtype=torch.uint8, device=dev); K8 = torch.zeros_like(Q8)
