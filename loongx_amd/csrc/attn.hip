@@ -378,11 +378,19 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const uint32_t v_lane_off = (uint32_t)(((wave * 8 + (lane >> 3)) * vt_ld + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) * 8)) * 2);
   // (buffer addressing: the SRSRC is rebuilt from the wave-uniform origin with scalar instructions; in the GEMM loop this form
   // measured 260 fewer stall cycles per 16 pieces than flat-global addresses)
+  uint32_t k_off0 = (uint32_t)(k_key * ldk * 2) + k_slot_off, k_off1 = (uint32_t)((k_key + 32) * ldk * 2) + k_slot_off;
+  asm volatile("" : "+v"(k_off0), "+v"(k_off1));     // (kept in registers: rematerialised they are the multiply again)
   auto piece = [&](int j, int krow, int vpos, int nclamp, int slot) {
     char* base = smem + slot * STAGE_BYTES;
     if (j < 2) {
       const lx_rsrc_t rs = lx_make_rsrc(Kbase + (size_t)krow * ldk);                                     // wave-uniform
+#ifdef LX_ATTN_KOFF_MAD
       const uint32_t off_ = (uint32_t)(min(k_key + j * 32, nclamp - 1) * ldk * 2) + k_slot_off;
+#else
+      // min(row, clamp) * ld + slot = min(row * ld + slot, clamp * ld + slot): the products are loop-invariant registers / one scalar
+      // multiply, so a piece costs v_add + v_min instead of v_min + v_mad_u64_u32 (hipcc's only 32 x 32 + 32 form, not full rate)
+      const uint32_t off_ = min(j ? k_off1 : k_off0, (uint32_t)((nclamp - 1) * ldk * 2) + k_slot_off);
+#endif
       lx_buf_to_lds(rs, (lptr_t)(base + (j * NW + wave) * 1024), off_, 0);
     } else {
       const int jj = j - 2;
@@ -1060,6 +1068,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
   const int k_lslot = (lane & 7) ^ ((k_key >> 1) & 7);
   const int v_drow = wave * 16 + (lane >> 2);
   const int v_lslot = (lane & 3) ^ ((v_drow >> 2) & 3);
+#ifdef LX_ATTN_FP8_FLAT_DMA      /* A/B: flat-global addresses, 64-bit per-lane address arithmetic per piece */
   auto stage_k = [&](const Tile& T, int slot) {      // rows past the tile's last valid key are clamped (loaded, masked later)
     const uint8_t* src = Kbase + (size_t)(T.krow + min(k_key, T.nclamp - 1)) * ldk + k_lslot * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + slot * STAGE8_BYTES + wave * 1024), 16, 0, 0);
@@ -1068,6 +1077,21 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     const uint8_t* src = Vbase + (size_t)v_drow * vt_ld + T.vpos + v_lslot * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + slot * STAGE8_BYTES + K8_BYTES + wave * 1024), 16, 0, 0);
   };
+#else
+  // buffer addressing as in lx_attn_pipe_kernel: wave-uniform tile origin in the SRSRC (scalar instructions), per-lane 32-bit offsets
+  // that are loop-invariant registers; the row clamp is min(row * ld + slot, clamp * ld + slot): v_add + v_min per K piece, nothing per V^T piece
+  uint32_t k_off8 = (uint32_t)(k_key * ldk + k_lslot * 16), v_off8 = (uint32_t)(v_drow * vt_ld + v_lslot * 16);
+  asm volatile("" : "+v"(k_off8), "+v"(v_off8));
+  auto stage_k = [&](const Tile& T, int slot) {      // rows past the tile's last valid key are clamped (loaded, masked later)
+    const lx_rsrc_t rs = lx_make_rsrc(Kbase + (size_t)T.krow * ldk);
+    const uint32_t off_ = min(k_off8, (uint32_t)((T.nclamp - 1) * ldk) + (uint32_t)(k_lslot * 16));
+    lx_buf_to_lds(rs, (lptr_t)(smem + slot * STAGE8_BYTES + wave * 1024), off_, 0);
+  };
+  auto stage_v = [&](const Tile& T, int slot) {
+    const lx_rsrc_t rs = lx_make_rsrc(Vbase + T.vpos);
+    lx_buf_to_lds(rs, (lptr_t)(smem + slot * STAGE8_BYTES + K8_BYTES + wave * 1024), v_off8, 0);
+  };
+#endif
   const int ksw = (l31 >> 1) & 7, vsw = (l31 >> 2) & 3;
   auto frag = [&](const char* p0, int slot_a, int sw) {
     const u32x4 lo = *(const u32x4*)(p0 + ((slot_a ^ sw) * 16)), hi = *(const u32x4*)(p0 + (((slot_a + 1) ^ sw) * 16));
