@@ -9,10 +9,12 @@ lens = (512, 1024, 1024); Dm = H * 128
 buf = _qkv_buffer(B, lens, H, seed=3)
 row0, vt0, vt_len = _segments(B, lens)
 VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=dev)
-ops.qkv_prep_segs(buf, 2 * Dm, 0, Dm, [(row0[i], lens[i], vt0[i], None, None, None, None) for i in range(3)], B, H, VT)
+flags = int(os.environ.get("DET_FLAGS", "0"))          # 3 = the bounded-score kernel (needs RMS-normalised q / k: unit norm weights here)
+one = torch.ones(128, device=dev) if flags else None
+ops.qkv_prep_segs(buf, 2 * Dm, 0, Dm, [(row0[i], lens[i], vt0[i], one * ops.Q_LOG2_FACTOR if flags else None, one, None, None) for i in range(3)], B, H, VT)
 O = torch.empty(buf.shape[0], Dm, dtype=torch.bfloat16, device=dev)
 def attn():
-    ops.attn_fwd(buf, buf, VT, O, q_col=2 * Dm, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
+    ops.attn_fwd(buf, buf, VT, O, q_col=2 * Dm, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=flags)
     return O
 ref = attn().clone()
 bad = 0
