@@ -1098,14 +1098,23 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
   };
   // fragment of gap g: 0-1 = K(t+1) key block 1 (d half g), 2-3 = K(t+1) key block 0 (d half g-2), 4-7 = V^T(t) d block g-4
+#ifdef LX8_ELIM_DSR            /* timing experiments only (WRONG numbers), as LX_ATTN_ELIM_* of the bf16 kernel: tools/run_r03ac.sh */
+  i32x8 fr_stale = {1, 2, 3, 4, 5, 6, 7, 8};
+  auto frag_of = [&](int g, const char* kbuf, const char* vbuf) { asm volatile("" : "+v"(fr_stale) : "v"(kbuf), "v"(vbuf)); return fr_stale; };
+#else
   auto frag_of = [&](int g, const char* kbuf, const char* vbuf) {
     if (g < 4) return frag(kbuf + ((g < 2 ? 32 : 0) + l31) * 128, (g & 1) * 4 + lhi * 2, ksw);
     return frag(vbuf + ((g - 4) * 32 + l31) * 64, lhi * 2, vsw);
   };
+#endif
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 s0, s1a, s1b;              // scores: key block 0 (in place), key block 1 of the current / next tile (swap roles)
   f32x16 offv = zero16;             // POW2: bias - running max in all 16 slots = the accumulator the score MFMAs start from
+#ifdef LX8_ELIM_SOFT
+  int pfw[8] = {0x38302c34, 0x2c383430, 0x34383c30, 0x30343828, 0x38302c34, 0x2c383430, 0x34383c30, 0x30343828};   // (non-zero operands: zeros would run at a higher clock)
+#else
   int pfw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   float off = 0.f, alpha = 1.f, mx[4], t_new = 0.f;
   bool resc = false;                 // wave-uniform: O must be multiplied by alpha before the next P.V
   auto qk = [&](const i32x8& a, const i32x8& q, const f32x16& c) {
@@ -1119,6 +1128,16 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
   // the gap's MFMA takes its fragment through one in front of it and hands its result through one behind it -- that is what keeps
   // {reads, slice, MFMA} in this order.
   // exp2 / packing of eight scores of tile t: chunk c -> key block c>>1 (SCk), register quads 2*(c&1), 2*(c&1)+1
+#ifdef LX8_ELIM_EXP
+#define LX8_EXP2(x) (x)
+#else
+#define LX8_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#ifdef LX8_ELIM_CVT        /* two f32 -> one v_perm-free integer op instead of v_cvt_pk_fp8_f32 */
+#define LX8_CVT(a, b, old, hi) ((int)(__float_as_uint(a) ^ (__float_as_uint(b) >> 3)) + (old))
+#else
+#define LX8_CVT(a, b, old, hi) __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, hi)
+#endif
 #define LX8_SOFT(c, SCk)                                                                                               \
   {                                                                                                                    \
     if constexpr (!POW2) { asm volatile("" : "+v"(off)); }                                                             \
@@ -1127,11 +1146,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
       const int rq_ = ((c) & 1) * 2 + q_;                                                                              \
       float pv_[4];                                                                                                    \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                               \
-        if constexpr (POW2) { float x_ = SCk[rq_ * 4 + e_]; asm volatile("" : "+v"(x_)); pv_[e_] = __builtin_amdgcn_exp2f(x_); } \
+        if constexpr (POW2) { float x_ = SCk[rq_ * 4 + e_]; asm volatile("" : "+v"(x_)); pv_[e_] = LX8_EXP2(x_); } \
         else pv_[e_] = __builtin_amdgcn_exp2f(fmaf(SCk[rq_ * 4 + e_], c2, off));                                       \
       }                                                                                                                \
-      int w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[0], pv_[1], pfw[kb_ * 4 + rq_], false);   /* (old value: both halves are overwritten; a literal 0 costs a v_mov) */ \
-      w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[2], pv_[3], w_, true);                                                  \
+      int w_ = LX8_CVT(pv_[0], pv_[1], pfw[kb_ * 4 + rq_], false);   /* (old value: both halves are overwritten; a literal 0 costs a v_mov) */ \
+      w_ = LX8_CVT(pv_[2], pv_[3], w_, true);                                                                          \
       pfw[kb_ * 4 + rq_] = w_;                                                                                         \
       asm volatile("" : "+v"(pfw[kb_ * 4 + rq_]));                                                                     \
     }                                                                                                                  \
@@ -1203,14 +1222,30 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     oacc[((g) - 4) & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fr[(g) & 1], pf_, oacc[((g) - 4) & 3], 0, 0, 0, 0, 0, 0); \
     asm volatile("" : "+v"(oacc[((g) - 4) & 3]));                                                                      \
   }
+#ifdef LX8_ELIM_SOFT
+#define LX8_SOFT_MAYBE(c, SCk) { asm volatile("" : "+v"(SCk)); }      /* (the scores stay live: the score MFMAs are not dead code) */
+#else
+#define LX8_SOFT_MAYBE(c, SCk) LX8_SOFT(c, SCk)
+#endif
+#ifdef LX8_ELIM_MAX
+#define LX8_MAX_MAYBE(c, SN0, SN1) { asm volatile("" : "+v"(SN0), "+v"(SN1)); }
+#else
+#define LX8_MAX_MAYBE(c, SN0, SN1) LX8_MAX(c, SN0, SN1)
+#endif
+#ifdef LX8_ELIM_DMA
+#define LX8_STAGE_MAYBE(g, PAR)
+#else
+#define LX8_STAGE_MAYBE(g, PAR)                                                                                        \
+  if ((g) == 1) stage_k(t2, PAR);                                                                                      \
+  if ((g) == 5) stage_v(t1, (PAR) ^ 1);
+#endif
   // one gap: reads of the NEXT gap's fragment, the vector slice, this gap's MFMA.  S0 = key block 0 (tile t, then t+1 in place),
   // S1C / S1N = key block 1 of tile t / t+1
 #define LX8_GAP(g, S0, S1C, S1N, PAR)                                                                                  \
   if ((g) < 7) fr[((g) + 1) & 1] = frag_of((g) + 1, kbuf, vbuf);                                                       \
   LX8_FENCE();                                                                                                         \
-  if ((g) < 2) { LX8_SOFT((g) & 1, S0) } else if ((g) < 4) { LX8_SOFT(2 + ((g) & 1), S1C) } else { LX8_MAX(((g) - 4) & 3, S0, S1N) } \
-  if ((g) == 1) stage_k(t2, PAR);                                                                                      \
-  if ((g) == 5) stage_v(t1, (PAR) ^ 1);                                                                                \
+  if ((g) < 2) { LX8_SOFT_MAYBE((g) & 1, S0) } else if ((g) < 4) { LX8_SOFT_MAYBE(2 + ((g) & 1), S1C) } else { LX8_MAX_MAYBE(((g) - 4) & 3, S0, S1N) } \
+  LX8_STAGE_MAYBE(g, PAR)                                                                                              \
   LX8_FENCE();                                                                                                         \
   LX8_MM(g, S0, S1N)                                                                                                   \
   LX8_FENCE();
