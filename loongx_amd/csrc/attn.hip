@@ -611,6 +611,13 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #endif
 #define LX_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LX_MCHUNK_MAYBE(g, SC) if constexpr (MODE == 0) { LX_MCHUNK(g, SC) }
+#ifdef LX_ATTN_WAIT_AHEAD   /* A/B: gap g waits for the fragment of gap g + 1 as well, so that every MFMA consumes a fragment that landed a gap ago */
+#define LX_WAIT_GAP(g)                                                                                                 \
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ring[(g) % LOOK]), "+v"(ring[((g) + 1) % LOOK]) : "n"((30 - (g)) < (LOOK - 2) ? ((30 - (g)) < 0 ? 0 : (30 - (g))) : (LOOK - 2)) : "memory"); \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define LX_WAIT_GAP(g) LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);
+#endif
 #ifdef LX_ATTN_ELIM_SOFT
 #define LX_HALVES(g, SC)
 #else
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   if ((g) == LX_ATTN_PG3) piece(3, 0, t1.vpos, 0, vs_slot);
 #endif
 #define LX_GAP(g, SC, SN)                                                                                              \
-  LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);                                       \
+  LX_WAIT_GAP(g)                                                                                                       \
   LX_MM(g, SC, SN, false);                                                                                             \
   LX_RD((g) + LOOK, 32, false);                                                                                        \
   LX_MCHUNK_MAYBE(g, SC)                                                                                               \
@@ -736,6 +743,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_PRIO_AT
 #undef LX_MCHUNK
 #undef LX_MCHUNK_MAYBE
+#undef LX_WAIT_GAP
 #undef LX_HALVES
 #undef LX_PIECES
 #undef LX_ITER_BARRIER
