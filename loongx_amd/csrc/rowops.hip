@@ -2,6 +2,7 @@
 // RMSNorm+RoPE(+V^T image), LoRA down-projection, skinny (M<=16) linears, timestep embedding, Euler step.
 // All loads/stores are 8-16 B per lane and coalesced; reductions are wave64 shuffles (no LDS, no atomics).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -458,11 +459,24 @@ __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms ter
   const uint16_t* xp = X + (size_t)min(m0 + l15, M - 1) * ldx + kq * 8;
   const uint16_t* ap = A + (size_t)min(l15, R - 1) * K + kq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = kbeg + wave * 32; k < kend; k += 8 * 32) {
-    const bf16x8 af = *(const bf16x8*)(ap + k);
-    const bf16x8 xf = *(const bf16x8*)(xp + k);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, acc, 0, 0, 0);
-  }
+  // A wave's K steps are 256 apart (12 of them at K = 3072). Written as {load, load, wait, MFMA} per step the loop pays the memory
+  // latency once per step (7.5 us per launch, 133 launches per forward: the whole kernel was that chain); here the loads of up to eight
+  // steps are in flight together and the MFMAs follow in the same ascending-k order (bit-identical sums).
+  int k = kbeg + wave * 32;
+  auto chunk = [&](auto n_) {
+    constexpr int NS = decltype(n_)::value;
+    bf16x8 af[NS], xf[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) { af[u] = *(const bf16x8*)(ap + k + u * 256); xf[u] = *(const bf16x8*)(xp + k + u * 256); }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], xf[u], acc, 0, 0, 0);
+    k += NS * 256;
+  };
+  while (k + 7 * 256 < kend) chunk(std::integral_constant<int, 8>{});
+  if (k + 3 * 256 < kend) chunk(std::integral_constant<int, 4>{});
+  if (k + 256 < kend) chunk(std::integral_constant<int, 2>{});
+  if (k + 256 < kend) chunk(std::integral_constant<int, 2>{});      // (at most 3 steps were left after the 4-chunk)
+  if (k < kend) chunk(std::integral_constant<int, 1>{});
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
