@@ -1139,6 +1139,232 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lx_gemm4_kernel: the same 256 x 256 x 64 tile with ONE wave per SIMD -- 256 threads, 2 x 2 waves of 128 x 128, the 256 accumulator
+// registers of a wave in AGPRs, v_mfma_f32_16x16x32_bf16 (a weight fragment is held for eight MFMAs), ALL fragments of a K tile in
+// registers (2 k-steps x (8 + 8) x 4 VGPRs), one ds_read_b128 or one LDS-DMA piece per MFMA gap, two barriers per K tile: the reads
+// of a stage are finished (registers) before its refill is issued, so two stages of 64 KiB suffice. This is the shape of the vendor
+// library's fastest kernel on this part; measured against the 8-wave loop above in tools/ubench/loop4w_rate:
+// 1.39 vs 1.58 us per K tile (the fragment bytes read from LDS per MFMA cycle are 2/3, the wave count per SIMD half). Same LDS image,
+// swizzle, pre-tiled weights and tile map as gemm_tile. Epilogues so far: bias / GELU / bf16 or fp32 store / gated residual (no LoRA,
+// no LX_EPI_QKV: those launches stay on the kernels above).
+constexpr int G4_THREADS = 256;
+constexpr int G4_STAGE = 256 * BK * 2 + BN * BK * 2;      // A tile + W tile of one K tile: 64 KiB
+constexpr int G4_LDS = 2 * G4_STAGE;
+constexpr int G4_PLD = 132;                                // fp32 row stride of the epilogue patch (128 + 4 pad)
+static_assert(G4_LDS <= 160 * 1024 && 4 * 16 * G4_PLD * 4 <= G4_LDS, "LDS budget / epilogue patch");
+
+__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) char smem[G4_LDS];
+  constexpr int BM = 256, A_BYTES = BM * BK * 2;
+  const int pid = blockIdx.x;
+  const int total = args.tile_start[MAX_SUB];
+  int lid;
+  {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, inx = pid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  }
+  const int g = tile_group(args, lid);
+  const lx_gemm_desc P = args.p[g];
+  int tm, tn;
+  tile_coords<BM>(P, lid - args.tile_start[g], tm, tn);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = P.M, N = P.N, K = P.K;
+  const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
+  const int nkt = K / BK;
+
+  // ---- staging: this wave moves pieces j * 4 + wave (j = 0..7; 1 KiB = 8 rows of 128 B each) of both operand tiles ----
+  uint32_t aoff[8], woff[8];
+  {
+    const int rsub = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = (j * 4 + wave) * 8 + rsub;
+      const int lslot = pslot ^ ((row >> 1) & 7);
+      aoff[j] = (uint32_t)((min(m0 + row, M - 1) - m0) * P.lda + lslot * 8) * 2u;
+      woff[j] = w_tiled ? (uint32_t)((j * 4 + wave) * 512 + lane * 8) * 2u : (uint32_t)((min(n0 + row, N - 1) - n0) * P.ldw + lslot * 8) * 2u;
+    }
+  }
+  const __bf16* a_org = (const __bf16*)P.A + (size_t)m0 * P.lda;
+  const __bf16* w_org = w_tiled ? (const __bf16*)P.W + ((size_t)tn * nkt) * (BN * BK) : (const __bf16*)P.W + (size_t)n0 * P.ldw;
+  const lx_rsrc_t rs_a = lx_make_rsrc(a_org), rs_w = lx_make_rsrc(w_org);
+  const int w_kstride_b = (w_tiled ? BN * BK : BK) * 2;
+  auto piece = [&](int p_, int kt, int stage) {       // p_ 0..7: A pieces, 8..15: W pieces of K tile kt
+    if (p_ < 8) lx_buf_to_lds(rs_a, (lptr_t)(smem + stage * G4_STAGE + (p_ * 4 + wave) * 1024), aoff[p_], kt * (BK * 2));
+    else lx_buf_to_lds(rs_w, (lptr_t)(smem + stage * G4_STAGE + A_BYTES + ((p_ - 8) * 4 + wave) * 1024), woff[p_ - 8], kt * w_kstride_b);
+  };
+  // ---- fragments: 16 rows x 32 k = 16 B per lane (row l15, k chunk lq); row blocks are 2 KiB apart and share the swizzle term ----
+  int a_ad[2], w_ad[2];
+  {
+    const int ar = wm * 128 + l15, wr = wn * 128 + l15;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_ad[ks] = ar * 128 + (((ks * 4 + lq) ^ ((ar >> 1) & 7)) * 16);
+      w_ad[ks] = A_BYTES + wr * 128 + (((ks * 4 + lq) ^ ((wr >> 1) & 7)) * 16);
+    }
+  }
+  f32x4 acc[8][8];                                    // [m block i][n block j]: m = i*16 + l15, n = j*16 + 4*lq + r
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[2][8], wf[2][8];                          // [k-step][block]
+  auto rd = [&](int stage, int ks, int idx) {         // idx 0..7: W block, 8..15: A block idx - 8
+    const char* base = smem + stage * G4_STAGE;
+    if (idx < 8) wf[ks][idx] = *(const bf16x8*)(base + w_ad[ks] + idx * 2048);
+    else af[ks][idx - 8] = *(const bf16x8*)(base + a_ad[ks] + (idx - 8) * 2048);
+  };
+  auto mm = [&](int ks, int n_) {                      // MFMA n_ (0..63) of a k-step: W block n_ >> 3 (held for 8 MFMAs) x A block n_ & 7
+    const int j = n_ >> 3, i = n_ & 7;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(wf[ks][j]), "v"(af[ks][i]));
+  };
+#define G4_SB() __builtin_amdgcn_sched_barrier(0)
+  // prologue: K tiles 0 and 1 staged; tile 0 landed; its k-step-0 fragments read
+#pragma unroll
+  for (int p_ = 0; p_ < 16; ++p_) piece(p_, 0, 0);
+#pragma unroll
+  for (int p_ = 0; p_ < 16; ++p_) piece(p_, min(1, nkt - 1), 1);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  G4_SB();
+#pragma unroll
+  for (int x = 0; x < 16; ++x) rd(0, 0, x);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // One K tile (stage c; its k-step-0 fragments are in registers):
+  //   k-step 0: 64 MFMAs; the 16 reads of k-step 1 behind the first 16; then every read of this stage is issued: wait, barrier, and the
+  //             refill of this stage with K tile kt + 2 starts -- A pieces one per six MFMAs
+  //   k-step 1: 64 MFMAs; W pieces one per five; vmcnt(16) = K tile kt + 1 (issued an iteration ago) has landed, barrier, and its
+  //             k-step-0 reads behind the last MFMAs.
+  // Branch-free tail: past the last K tile the final tile is staged again (identical bytes over a stage nobody reads any more).
+  int c = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int n = c ^ 1;
+    const int kt2 = min(kt + 2, nkt - 1);
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      if (m == 16) {
+        G4_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        G4_SB();
+      }
+      mm(0, m); G4_SB();
+      if (m < 16) { rd(c, 1, m); G4_SB(); }
+      if (m >= 16 && (m - 16) % 6 == 0) { piece((m - 16) / 6, kt2, c); G4_SB(); }
+    }
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      if (m == 43) {
+        G4_SB();
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        G4_SB();
+      }
+      mm(1, m); G4_SB();
+      if (m < 40 && m % 5 == 0) { piece(8 + m / 5, kt2, c); G4_SB(); }
+      if (m >= 43 && m < 59) { rd(n, 0, m - 43); G4_SB(); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    c = n;
+  }
+#undef G4_SB
+  // the inline-asm MFMAs are opaque to the hazard recogniser (MFMA write -> v_accvgpr_read: 18 wait states); every LDS-DMA piece
+  // has landed and every wave is done with the operand stages before the patch below reuses them
+  asm volatile("s_nop 15\n s_nop 7\n s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
+  const int epi = P.epilogue & 0xff;
+  const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
+  const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+  float* patch = (float*)smem + wave * (16 * G4_PLD);
+  const bool bf16_out = epi == LX_EPI_STORE_BF16;
+  const int c8 = (lane & 15) * 8, c4 = (lane & 31) * 4;
+  const int ncol = nw0 + (bf16_out ? c8 : c4);
+  const bool col_ok = ncol < N;
+  f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+  if (P.bias && col_ok) {
+    bias0 = *(const f32x4*)(P.bias + ncol);
+    if (bf16_out) bias1 = *(const f32x4*)(P.bias + ncol + 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias0), "+v"(bias1)::"memory");
+  const bool gelu0 = do_gelu && ncol >= P.gelu_col_start;
+  const int m_base = args.m_base[g];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int mb = mw0 + i * 16;
+    if (mb >= M) continue;                             // (wave-uniform; `continue`, not `break`: the loop must unroll, acc[i] is a register index)
+    f32x4 res[8], gat[8];
+    if (epi == LX_EPI_RESID_F32) {                     // residual / gate rows of the block, requested before the patch is written
+      const int rpb = P.rows_per_batch;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int m = mb + t * 2 + (lane >> 5);
+        if (m < M && col_ok) {
+          res[t] = *(const f32x4*)((const float*)P.C + (size_t)m * P.ldc + ncol);
+          if (P.gate) gat[t] = *(const f32x4*)(P.gate + (size_t)((m_base + m) / rpb) * P.gate_ld + ncol);
+        }
+      }
+    }
+    // the block's eight accumulators stay in AGPRs up to here (left to itself hipcc moves all 256 to VGPRs at once and spills them)
+    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(f32x4*)(patch + l15 * G4_PLD + j * 16 + 4 * lq) = acc[i][j];
+    __builtin_amdgcn_wave_barrier();
+    if (bf16_out) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 4 + (lane >> 4), m = mb + row;
+        f32x4 v0 = *(const f32x4*)(patch + row * G4_PLD + c8);
+        f32x4 v1 = *(const f32x4*)(patch + row * G4_PLD + c8 + 4);
+        if (m < M && col_ok) {
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; }
+          if (gelu0) { v0 = gelu_tanh4(v0); v1 = gelu_tanh4(v1); }
+          u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+          *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
+        }
+      }
+    } else {
+      if (epi == LX_EPI_RESID_F32) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(res[t]), "+v"(gat[t]));
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 2 + (lane >> 5), m = mb + row;
+        f32x4 v = *(const f32x4*)(patch + row * G4_PLD + c4);
+        if (m < M && col_ok) {
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) v[c_] += bias0[c_];
+          if (gelu0) v = gelu_tanh4(v);
+          if (epi == LX_EPI_RESID_F32) {
+            f32x4 o = res[t];
+            if (P.gate) {
+#pragma unroll
+              for (int c_ = 0; c_ < 4; ++c_) o[c_] = __builtin_fmaf(gat[t][c_], v[c_], o[c_]);
+            } else {
+#pragma unroll
+              for (int c_ = 0; c_ < 4; ++c_) o[c_] += v[c_];
+            }
+            v = o;
+          }
+          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
+}
+
 }  // namespace
 
 // ---- launch planning ---------------------------------------------------------------------------------------------
@@ -1148,9 +1374,10 @@ __global__ __launch_bounds__(NTHREADS) void lx_gemm_pair_kernel(const GemmArgs a
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4; };
 static GemmEnv read_gemm_env() {
-  return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1)};
+  return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
+                 env_int("LX_GEMM4", 1)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1322,6 +1549,24 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   const int NCU = device_cus() > 0 ? device_cus() : 256;   // one workgroup per CU: a launch runs in rounds of NCU tiles
   const GemmEnv& env = gemm_env();
   const int forced = env.bm;      // 256 | 128 | 0 = plan
+  // lx_gemm4_kernel (one wave per SIMD, 256-row tiles only): the launches whose epilogue it has and whose tile count fills whole rounds.
+  // LX_GEMM4 = 0 never | 1 (default) where the last round is at least 3/4 full or there are >= 8 rounds | 2 whenever the epilogue allows (tests).
+  if (env.g4 && forced == 0 && !split && !qkv) {
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && problems[i].lora_t == nullptr && (problems[i].epilogue & 0xff) <= LX_EPI_RESID_F32 && problems[i].K / BK >= 2;
+    const long rounds = (t256 + NCU - 1) / NCU;
+    const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
+    if (ok && fills) {
+      GemmArgs all;
+      all.n = 0;
+      all.tile_start[0] = 0;
+      for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+      for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
+      hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all);
+      LX_LAUNCH_CHECK("lx_gemm_bf16");
+      return LX_OK;
+    }
+  }
   // Two workgroups per 256-row tile (lx_gemm_pair_kernel) when there are at most 128 such tiles: needs one K for the whole
   // group, a 256-CU device and the scratch slots. LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144:
   // the swap costs ~6 us, the better loop saves 0.12 us per K tile) | 2 whenever possible (tests).
