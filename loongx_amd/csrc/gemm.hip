@@ -1225,6 +1225,25 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(wf[ks][j]), "v"(af[ks][i]));
   };
 #define G4_SB() __builtin_amdgcn_sched_barrier(0)
+  // ---- LoRA up-projection (block.py via peft: y += (x A^T) B^T on the adapter's rows): acc starts from t . up^T, as one extra 32-deep
+  // MFMA k-step. Lane (row l15, chunk lq) carries ranks 2 lq and 2 lq + 1; each rank fills four k-slots with the bf16 hi / lo cross
+  // terms [u_hi, u_hi, u_lo, u_lo] x [t_hi, t_lo, t_hi, t_lo]: fp32-class (2^-16), as lora_apply above does for the 8-wave kernels.
+  // The loads go out BEFORE the operand DMA (vmcnt is one in-order queue: the wait that covers K tile 0 then covers them too).
+  const bool has_lora = P.lora_t != nullptr;           // (the planner admits rank <= 8, even, 8-byte aligned rows here)
+  u32x2 lu[8], lt[8][4];
+  if (has_lora) {
+    const int R = P.lora_r, nsplit = P.lora_nsplit;
+    const int toff = R * min(n0 / max(P.lora_mod_cols, 1), P.lora_toff_max);
+    const int rk = min(2 * lq, R - 2);                 // (ranks past R: loaded from a valid address, zeroed below)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lu[j] = *(const u32x2*)(P.lora_up + (size_t)min(n0 + wn * 128 + j * 16 + l15, N - 1) * R + rk);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float* tp = P.lora_t + (size_t)min(m0 + wm * 128 + i * 16 + l15, M - 1) * P.lora_ldt + toff + rk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lt[i][q] = *(const u32x2*)(tp + (size_t)min(q, nsplit - 1) * P.lora_split_stride);
+    }
+  }
   // prologue: K tiles 0 and 1 staged; tile 0 landed; its k-step-0 fragments read
 #pragma unroll
   for (int p_ = 0; p_ < 16; ++p_) piece(p_, 0, 0);
@@ -1235,6 +1254,43 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   G4_SB();
 #pragma unroll
   for (int x = 0; x < 16; ++x) rd(0, 0, x);
+  if (has_lora) {
+    const int R = P.lora_r, nsplit = P.lora_nsplit;
+    const bool live = 2 * lq < R;                      // this lane's two ranks exist
+    auto frag_u = [&](u32x2 v) {
+      const float a = live ? __uint_as_float(v[0]) : 0.f, b = live ? __uint_as_float(v[1]) : 0.f;
+      const uint16_t ah = f32_to_bf16(a), bh = f32_to_bf16(b);
+      const uint16_t al = f32_to_bf16(a - bf16_to_f32(ah)), bl = f32_to_bf16(b - bf16_to_f32(bh));
+      const u32x4 w = {(uint32_t)ah * 0x10001u, (uint32_t)al * 0x10001u, (uint32_t)bh * 0x10001u, (uint32_t)bl * 0x10001u};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    auto frag_t = [&](float a, float b) {
+      a = live ? a : 0.f; b = live ? b : 0.f;
+      const uint16_t ah = f32_to_bf16(a), bh = f32_to_bf16(b);
+      const uint32_t pa = (uint32_t)ah | ((uint32_t)f32_to_bf16(a - bf16_to_f32(ah)) << 16);
+      const uint32_t pb = (uint32_t)bh | ((uint32_t)f32_to_bf16(b - bf16_to_f32(bh)) << 16);
+      const u32x4 w = {pa, pa, pb, pb};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    bf16x8 uf[8], tf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) uf[j] = frag_u(lu[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                      // slabs added in slab order, as lora_sum does
+      float a = __uint_as_float(lt[i][0][0]), b = __uint_as_float(lt[i][0][1]);
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (q < nsplit) { a += __uint_as_float(lt[i][q][0]); b += __uint_as_float(lt[i][q][1]); }
+      tf[i] = frag_t(a, b);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(uf[j]), "v"(tf[i]));
+    // hipcc reconciles the accumulators' AGPR assignment of this branch with the other path's through v_accvgpr_read / _mov right
+    // here, and does not know the asm statements above are MFMAs: cover MFMA write -> accvgpr read by hand (seen: the last block lost its term)
+    asm volatile("s_nop 15\n s_nop 7" ::: "memory");
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // One K tile (stage c; its k-step-0 fragments are in registers):
   //   k-step 0: 64 MFMAs; the 16 reads of k-step 1 behind the first 16; then every read of this stage is issued: wait, barrier, and the
@@ -1553,7 +1609,13 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   // LX_GEMM4 = 0 never | 1 (default) where the last round is at least 3/4 full or there are >= 8 rounds | 2 whenever the epilogue allows (tests).
   if (env.g4 && forced == 0 && !split && !qkv) {
     bool ok = true;
-    for (int i = 0; i < n; ++i) ok = ok && problems[i].lora_t == nullptr && (problems[i].epilogue & 0xff) <= LX_EPI_RESID_F32 && problems[i].K / BK >= 2;
+    for (int i = 0; i < n; ++i) {
+      const lx_gemm_desc& p = problems[i];
+      ok = ok && (p.epilogue & 0xff) <= LX_EPI_RESID_F32 && p.K / BK >= 2;
+      if (p.lora_t)        // the kernel's LoRA step: two ranks per 8-byte load, one 32-deep MFMA k-step, up to four K-split slabs
+        ok = ok && p.lora_r <= 8 && p.lora_r % 2 == 0 && p.lora_nsplit >= 1 && p.lora_nsplit <= 4 && p.lora_ldt % 2 == 0 && p.lora_split_stride % 2 == 0 &&
+             ((((uintptr_t)p.lora_t) | ((uintptr_t)p.lora_up)) & 7) == 0;
+    }
     const long rounds = (t256 + NCU - 1) / NCU;
     const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
     if (ok && fills) {
