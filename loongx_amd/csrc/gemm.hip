@@ -1352,10 +1352,22 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias0), "+v"(bias1)::"memory");
   const bool gelu0 = do_gelu && ncol >= P.gelu_col_start;
   const int m_base = args.m_base[g];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  // LX_EPI_QKV tiles (block.py:60-99: attn.norm_q / norm_k + apply_rotary_emb, and the attention kernel's V^T image): a wave's 128
+  // columns are exactly one head, so the sum of squares of a row is a 16-lane reduction of the row-access layout (no LDS exchange)
+  const bool qkv_tile = (P.epilogue & LX_EPI_QKV) != 0 && n0 < 3 * P.qkv_d;
+  const int qkind = qkv_tile ? n0 / P.qkv_d : -1;      // 0: k, 1: v, 2: q (tile-uniform)
+  f32x4 nw0v = {1.f, 1.f, 1.f, 1.f}, nw1v = {1.f, 1.f, 1.f, 1.f};
+  if (qkv_tile && qkind != 1) {
+    const float* nwp = (qkind == 2 ? P.qkv_norm_q : P.qkv_norm_k) + c8;
+    nw0v = *(const f32x4*)nwp; nw1v = *(const f32x4*)(nwp + 4);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nw0v), "+v"(nw1v)::"memory");
+  }
+  // one 16-row block; a generic lambda over an integral constant, not a loop: acc[i] must be a compile-time register index (a loop that
+  // hipcc declines to unroll sends all 256 accumulators to scratch)
+  auto block = [&](auto ic_) {
+    constexpr int i = decltype(ic_)::value;
     const int mb = mw0 + i * 16;
-    if (mb >= M) continue;                             // (wave-uniform; `continue`, not `break`: the loop must unroll, acc[i] is a register index)
+    if (mb >= M) return;                               // (wave-uniform)
     f32x4 res[8], gat[8];
     if (epi == LX_EPI_RESID_F32) {                     // residual / gate rows of the block, requested before the patch is written
       const int rpb = P.rows_per_batch;
@@ -1373,6 +1385,60 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
     for (int j = 0; j < 8; ++j) *(f32x4*)(patch + l15 * G4_PLD + j * 16 + 4 * lq) = acc[i][j];
     __builtin_amdgcn_wave_barrier();
+    if (qkv_tile) {
+      const int D = P.qkv_d, L = P.rows_per_batch, H = D >> 7;
+      const int gm = m_base + mb, b = gm / L, p0 = gm - b * L;           // (M and L are multiples of 32: a 16-row block is whole, in one batch)
+      const int h = (nw0 - qkind * D) >> 7;
+      if (qkind == 1) {
+        // v: 16 keys x 128 head dims -> V^T rows; lane = (d, group of 8 keys), the 16-key interleave of the attention kernel's image
+        const int gk = lane & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int d = t * 32 + (lane >> 1);
+          const float bd = P.bias ? P.bias[nw0 + d] : 0.f;
+          float e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = patch[qkv_vt_interleave(gk * 8 + k) * G4_PLD + d] + bd;
+          u32x4 o = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+          *(u32x4*)((uint16_t*)P.qkv_vt + ((size_t)(b * H + h) * 128 + d) * P.qkv_vt_ld + P.qkv_vt_pos0 + p0 + gk * 8) = o;
+        }
+      } else {
+        uint16_t* const out = (qkind == 0 && P.qkv_k) ? (uint16_t*)P.qkv_k : (uint16_t*)P.C;
+        const int out_ld = (qkind == 0 && P.qkv_k) ? P.qkv_k_ld : P.ldc;
+        f32x4 cs[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                  // the block's RoPE rows: (cos, sin) pairs of this lane's 8 columns
+          const float* rp = P.qkv_rope + (size_t)(p0 + t * 4 + (lane >> 4)) * 128 + c8;
+          cs[t][0] = *(const f32x4*)rp; cs[t][1] = *(const f32x4*)(rp + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = t * 4 + (lane >> 4), m = mb + row;
+          f32x4 v0 = *(const f32x4*)(patch + row * G4_PLD + c8);
+          f32x4 v1 = *(const f32x4*)(patch + row * G4_PLD + c8 + 4);
+          float ss = 0.f;
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; ss = __builtin_fmaf(v0[c_], v0[c_], ss); ss = __builtin_fmaf(v1[c_], v1[c_], ss); }
+          ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+          const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+          float x[8], y[8];
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) { x[c_] = v0[c_] * r * nw0v[c_]; x[4 + c_] = v1[c_] * r * nw1v[c_]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                // pairs (2q, 2q+1): out = x*cos + rot*sin, rot = (-x_odd, x_even)
+            const float co = q < 2 ? cs[t][0][2 * q] : cs[t][1][2 * q - 4], si = q < 2 ? cs[t][0][2 * q + 1] : cs[t][1][2 * q - 3];
+            y[2 * q] = x[2 * q] * co - x[2 * q + 1] * si;
+            y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
+          }
+          if (m < M) {
+            u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+            *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
     if (bf16_out) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -1417,7 +1483,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       }
     }
     __builtin_amdgcn_wave_barrier();
-  }
+  };
+  block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
+  block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{}); block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
 #endif
 }
 
@@ -1607,11 +1675,11 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   const int forced = env.bm;      // 256 | 128 | 0 = plan
   // lx_gemm4_kernel (one wave per SIMD, 256-row tiles only): the launches whose epilogue it has and whose tile count fills whole rounds.
   // LX_GEMM4 = 0 never | 1 (default) where the last round is at least 3/4 full or there are >= 8 rounds | 2 whenever the epilogue allows (tests).
-  if (env.g4 && forced == 0 && !split && !qkv) {
+  if (env.g4 && forced == 0 && !split) {
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const lx_gemm_desc& p = problems[i];
-      ok = ok && (p.epilogue & 0xff) <= LX_EPI_RESID_F32 && p.K / BK >= 2;
+      ok = ok && (p.epilogue & 0xff) <= LX_EPI_RESID_F32 && p.K / BK >= 2 && !((p.epilogue & LX_EPI_QKV) && p.qkv_q8);   // (e4m3 q/k/v images: the 8-wave kernels)
       if (p.lora_t)        // the kernel's LoRA step: two ranks per 8-byte load, one 32-deep MFMA k-step, up to four K-split slabs
         ok = ok && p.lora_r <= 8 && p.lora_r % 2 == 0 && p.lora_nsplit >= 1 && p.lora_nsplit <= 4 && p.lora_ldt % 2 == 0 && p.lora_split_stride % 2 == 0 &&
              ((((uintptr_t)p.lora_t) | ((uintptr_t)p.lora_up)) & 7) == 0;
