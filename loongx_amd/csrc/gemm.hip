@@ -1155,18 +1155,32 @@ constexpr int G4_LDS = 2 * G4_STAGE;
 constexpr int G4_PLD = 132;                                // fp32 row stride of the epilogue patch (128 + 4 pad)
 static_assert(G4_LDS <= 160 * 1024 && 4 * 16 * G4_PLD * 4 <= G4_LDS, "LDS budget / epilogue patch");
 
-__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args) {
+// Split tail (sk_parts > 1; a launch with ONE K for all its problems): the tiles of the last, partial round are cut into sk_parts K
+// ranges, one workgroup each (grid = full-round tiles + sk_parts x tail tiles), so that the tail costs 1 / sk_parts of a round. The
+// workgroups of a tail tile sit next to each other in the grid, i.e. run at the same time: parts 1.. park their 256 accumulator
+// registers in their slot of the caller's workspace and raise a flag, part 0 (which also holds the LoRA term) adds them and runs the
+// epilogue. The owner's spin is bounded and sets the workspace's error word (lx_gemm_workspace_status), as the pair kernel's does.
+constexpr int SK_SLOT_FLOATS = G4_THREADS * 256;        // 256 accumulator registers x 256 lanes = 256 KiB
+constexpr int SK_MAX_WG = 256;
+
+__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args, const int sk_full, const int sk_parts, float* __restrict__ sk_slots,
+                                                              int* __restrict__ sk_flags, int* __restrict__ sk_err) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) char smem[G4_LDS];
   constexpr int BM = 256, A_BYTES = BM * BK * 2;
   const int pid = blockIdx.x;
   const int total = args.tile_start[MAX_SUB];
-  int lid;
-  {
-    const int q = total >> 3, r = total & 7;
+  int lid, part = 0;
+  if (pid < sk_full) {                                 // a whole tile: the XCD-aware map over the full-round tiles
+    const int q = sk_full >> 3, r = sk_full & 7;
     const int xcd = pid & 7, inx = pid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  } else {                                             // one K range of a tail tile
+    const int r = pid - sk_full;
+    lid = sk_full + r / sk_parts;
+    part = r - (r / sk_parts) * sk_parts;
   }
+  (void)total;
   const int g = tile_group(args, lid);
   const lx_gemm_desc P = args.p[g];
   int tm, tn;
@@ -1177,7 +1191,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = P.M, N = P.N, K = P.K;
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
-  const int nkt = K / BK;
+  const int nkt = K / BK;                              // K tiles of the whole tile; this workgroup's share: [kt_begin, kt_end)
+  const bool split_tile = pid >= sk_full && sk_parts > 1;
+  const int kt_begin = split_tile ? (nkt * part) / sk_parts : 0;
+  const int kt_end = split_tile ? (nkt * (part + 1)) / sk_parts : nkt;
 
   // ---- staging: this wave moves pieces j * 4 + wave (j = 0..7; 1 KiB = 8 rows of 128 B each) of both operand tiles ----
   uint32_t aoff[8], woff[8];
@@ -1229,7 +1246,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // MFMA k-step. Lane (row l15, chunk lq) carries ranks 2 lq and 2 lq + 1; each rank fills four k-slots with the bf16 hi / lo cross
   // terms [u_hi, u_hi, u_lo, u_lo] x [t_hi, t_lo, t_hi, t_lo]: fp32-class (2^-16), as lora_apply above does for the 8-wave kernels.
   // The loads go out BEFORE the operand DMA (vmcnt is one in-order queue: the wait that covers K tile 0 then covers them too).
-  const bool has_lora = P.lora_t != nullptr;           // (the planner admits rank <= 8, even, 8-byte aligned rows here)
+  const bool has_lora = P.lora_t != nullptr && kt_begin == 0;     // (the planner admits rank <= 8, even, 8-byte aligned rows; once per tile: with its first K tiles)
   u32x2 lu[8], lt[8][4];
   if (has_lora) {
     const int R = P.lora_r, nsplit = P.lora_nsplit;
@@ -1246,9 +1263,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   }
   // prologue: K tiles 0 and 1 staged; tile 0 landed; its k-step-0 fragments read
 #pragma unroll
-  for (int p_ = 0; p_ < 16; ++p_) piece(p_, 0, 0);
+  for (int p_ = 0; p_ < 16; ++p_) piece(p_, kt_begin, 0);
 #pragma unroll
-  for (int p_ = 0; p_ < 16; ++p_) piece(p_, min(1, nkt - 1), 1);
+  for (int p_ = 0; p_ < 16; ++p_) piece(p_, min(kt_begin + 1, kt_end - 1), 1);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   G4_SB();
@@ -1286,9 +1303,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(uf[j]), "v"(tf[i]));
-    // hipcc reconciles the accumulators' AGPR assignment of this branch with the other path's through v_accvgpr_read / _mov right
-    // here, and does not know the asm statements above are MFMAs: cover MFMA write -> accvgpr read by hand (seen: the last block lost its term)
+      for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j], tf[i], acc[i][j], 0, 0, 0);
+    // (the builtin, not the inline-asm form of the main loop: hipcc moves accumulators between AGPRs around this branch, and only
+    //  knows the MFMA -> accvgpr-read wait states of instructions it can see -- with asm statements here the last blocks lost their term)
     asm volatile("s_nop 15\n s_nop 7" ::: "memory");
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1299,9 +1316,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   //             k-step-0 reads behind the last MFMAs.
   // Branch-free tail: past the last K tile the final tile is staged again (identical bytes over a stage nobody reads any more).
   int c = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int n = c ^ 1;
-    const int kt2 = min(kt + 2, nkt - 1);
+    const int kt2 = min(kt + 2, kt_end - 1);
 #pragma unroll
     for (int m = 0; m < 64; ++m) {
       if (m == 16) {
@@ -1334,6 +1351,63 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // has landed and every wave is done with the operand stages before the patch below reuses them
   asm volatile("s_nop 15\n s_nop 7\n s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+
+  // ---- split tail: hand-over of the partial sums ----------------------------------------------------------------------------
+  if (split_tile) {
+    if (part > 0) {
+      // park the accumulators (register r of thread tid at [r][tid]: 16 B per lane and instruction, sc1 = visible at agent scope),
+      // raise the flag, done
+      const lx_rsrc_t rs = lx_make_rsrc(sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS);
+      auto park = [&](auto ic_) {
+        constexpr int i = decltype(ic_)::value;
+        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 v = acc[i][j];
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs, tid * 16,
+                                                 (i * 8 + j) * (G4_THREADS * 16), PAIR_AUX_SC1);
+        }
+      };
+      park(std::integral_constant<int, 0>{}); park(std::integral_constant<int, 1>{}); park(std::integral_constant<int, 2>{}); park(std::integral_constant<int, 3>{});
+      park(std::integral_constant<int, 4>{}); park(std::integral_constant<int, 5>{}); park(std::integral_constant<int, 6>{}); park(std::integral_constant<int, 7>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    for (int pp = 1; pp < sk_parts; ++pp) {            // the owner: wait (bounded) for each partner, add its sums, clear its flag
+      const int ps = pid - sk_full + pp;
+      if (tid == 0) {
+        int spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(sk_flags + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 20)) { ok = false; break; }
+        }
+        if (ok) __hip_atomic_store(sk_flags + ps, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
+      }
+      __syncthreads();
+      const lx_rsrc_t rs = lx_make_rsrc(sk_slots + (size_t)ps * SK_SLOT_FLOATS);
+      auto fetch = [&](auto ic_) {
+        constexpr int i = decltype(ic_)::value;
+        u32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (i * 8 + j) * (G4_THREADS * 16), PAIR_AUX_SC1);
+        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f32x4 a = acc[i][j];
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) a[c_] += __uint_as_float(v[j][c_]);
+          acc[i][j] = a;
+        }
+        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+      };
+      fetch(std::integral_constant<int, 0>{}); fetch(std::integral_constant<int, 1>{}); fetch(std::integral_constant<int, 2>{}); fetch(std::integral_constant<int, 3>{});
+      fetch(std::integral_constant<int, 4>{}); fetch(std::integral_constant<int, 5>{}); fetch(std::integral_constant<int, 6>{}); fetch(std::integral_constant<int, 7>{});
+    }
+  }
 
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
   const int epi = P.epilogue & 0xff;
@@ -1498,10 +1572,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 0)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1512,6 +1586,9 @@ extern "C" void lx_gemm_reload_env(void) { g_gemm_env = read_gemm_env(); }
 // whoever owns a stream owns its workspace, so launches on different streams never share slots or flags.
 namespace {
 constexpr size_t PAIR_WS_BYTES = (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float) + (PAIR_MAX_WG + 64) * sizeof(int);
+// behind it, the split-tail area of lx_gemm4_kernel: [SK_MAX_WG slots of 256 KiB | SK_MAX_WG flags] (the error word is the pair area's)
+constexpr size_t SK_WS_OFF = (PAIR_WS_BYTES + 255) & ~(size_t)255;
+constexpr size_t SK_WS_BYTES = SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float) + (SK_MAX_WG + 64) * sizeof(int);
 
 int device_cus() {
   static int n = -1;
@@ -1561,7 +1638,7 @@ static void plan_add(GemmArgs& a, const lx_gemm_desc& p, int m_base, int bm) {
   for (int i = a.n + 1; i <= MAX_SUB; ++i) a.tile_start[i] = a.tile_start[a.n];
 }
 
-extern "C" size_t lx_gemm_workspace_bytes(void) { return PAIR_WS_BYTES; }
+extern "C" size_t lx_gemm_workspace_bytes(void) { return SK_WS_BYTES; }
 
 extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   LX_CHECK_ARG(workspace, "lx_gemm_workspace_status: NULL workspace");
@@ -1575,6 +1652,7 @@ extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   if (v == 0) return LX_OK;
   // a timed-out pair leaves flags behind: reset all of them with the error word so the workspace is usable again
   (void)hipMemsetAsync((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
+  (void)hipMemsetAsync((char*)workspace + SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float), 0, (SK_MAX_WG + 64) * sizeof(int), s);
   (void)hipStreamSynchronize(s);
   lx_set_error("lx_gemm_bf16_ws: a split-K pair workgroup timed out waiting for its partner (CUs held by other work?); the results "
                "of that launch are invalid. Re-run with the workspace omitted (lx_gemm_bf16) or LX_GEMM_PAIR=0");
@@ -1675,7 +1753,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
   const int forced = env.bm;      // 256 | 128 | 0 = plan
   // lx_gemm4_kernel (one wave per SIMD, 256-row tiles only): the launches whose epilogue it has and whose tile count fills whole rounds.
   // LX_GEMM4 = 0 never | 1 (default) where the last round is at least 3/4 full or there are >= 8 rounds | 2 whenever the epilogue allows (tests).
-  if (env.g4 && forced == 0 && !split) {
+  if (env.g4 && forced == 0 && !split && (workspace || env.g4 == 2)) {     // (no workspace = the batch-size-invariant plans only)
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const lx_gemm_desc& p = problems[i];
@@ -1686,13 +1764,31 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     }
     const long rounds = (t256 + NCU - 1) / NCU;
     const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
-    if (ok && fills) {
+    // split tail (LX_GEMM4_SK = 0 default: measured slower than the 8-wave kernels' half-height tail on the step's shapes | 1 on): at least one full round, fewer than 8 rounds, a last round less than 3/4 full, one K
+    // for the whole launch, the caller's workspace: its tiles are cut into as many K ranges (<= 4, >= 8 K tiles each) as fit one round
+    bool uniform_k4 = true;
+    for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
+    const long tail = t256 % NCU, full = t256 - tail;
+    int parts = 1;
+    if (env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && full > 0 && rounds < 8 && tail > 0) {
+      parts = (int)(NCU / tail);
+      if (parts > 4) parts = 4;
+      while (parts > 1 && (problems[0].K / BK) / parts < 8) --parts;
+      if (tail * parts > SK_MAX_WG) parts = 1;
+    }
+    if (ok && (fills || parts > 1)) {
       GemmArgs all;
       all.n = 0;
       all.tile_start[0] = 0;
       for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
       for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
-      hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all);
+      if (parts > 1) {
+        float* slots = (float*)((char*)workspace + SK_WS_OFF);
+        int* flags = (int*)((char*)workspace + SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float));
+        int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
+        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + tail * parts)), dim3(G4_THREADS), 0, s, all, (int)full, parts, slots, flags, err);
+      } else
+        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
       LX_LAUNCH_CHECK("lx_gemm_bf16");
       return LX_OK;
     }

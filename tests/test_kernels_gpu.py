@@ -29,7 +29,7 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-PLANS = [256, 128, "pair"]
+PLANS = [256, 128, "pair", "g4"]
 
 
 _WS = []
@@ -50,7 +50,7 @@ def _restore_gemm_env():
     yield
     if torch.cuda.is_available():
         from loongx_amd import _lib
-        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR"):
+        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR", "LX_GEMM4", "LX_GEMM4_SK"):
             os.environ.pop(k, None)
         _lib.lib.lx_gemm_reload_env()
 
@@ -62,6 +62,9 @@ def _plan(monkeypatch, bm):
     if bm == "pair":
         monkeypatch.delenv("LX_GEMM_BM", raising=False)
         monkeypatch.setenv("LX_GEMM_PAIR", "2")
+    elif bm == "g4":                      # lx_gemm4_kernel (one wave per SIMD) wherever its epilogues allow, whatever the tile count
+        monkeypatch.delenv("LX_GEMM_BM", raising=False)
+        monkeypatch.setenv("LX_GEMM4", "2")
     else:
         monkeypatch.setenv("LX_GEMM_BM", str(bm))
     _lib.lib.lx_gemm_reload_env()
@@ -181,6 +184,47 @@ def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     ops.gemm([ops.gemm_desc(A, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_F32)], ws)
     assert torch.equal(C1, C2)
     assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("sk", [0, 1])
+def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
+    """lx_gemm4_kernel (4 waves x 128x128, AGPR accumulators) on a two-problem launch with every epilogue ingredient it has: gated fp32
+    residual + bias + LoRA (rank 4, two K-split slabs) on one problem, bf16 store + GELU on the other; 280 tiles = one full round and a
+    24-tile tail. sk = 1: the tail's tiles are cut into four K ranges that meet through the workspace (LX_GEMM4_SK=1). Against fp32
+    references, bit-identical from run to run, and (sk = 0) the planner's default choice for this shape equals the forced one."""
+    monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    monkeypatch.setenv("LX_GEMM4", "2")
+    monkeypatch.setenv("LX_GEMM4_SK", str(sk))
+    ops.lib.lx_gemm_reload_env()
+    ws = _ws()
+    M1, M2, N, K, r = 768, 352, 256 * 56, 2048, 4          # 3 x 56 + 2 x 56 = 280 tiles (the second problem's last tile row is ragged)
+    A1 = rnd(M1, K, seed=1, dtype=torch.bfloat16); A2 = rnd(M2, K, seed=2, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=3, scale=0.03, dtype=torch.bfloat16)
+    Wt = ops.tile_weight(W.clone())
+    bias = rnd(N, seed=4, scale=0.1)
+    gate = rnd(3, N, seed=5)
+    X0 = rnd(M1, N, seed=6)
+    Ad = rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16); Bu = rnd(N, r, seed=8, scale=0.1)
+    Tl = torch.zeros(2, M1, 16, dtype=torch.float32, device=DEV)
+    ops.lora_down(A1, Ad, Tl[0, :, :r], n_split=2, split_stride=Tl.stride(0))
+
+    def run():
+        X = X0.clone()
+        C2 = torch.zeros(M2, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm([ops.gemm_desc(A1, Wt, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=256, lora_t=Tl[0, :, :r], lora_up=Bu,
+                                lora_nsplit=2, lora_split_stride=Tl.stride(0)),
+                  ops.gemm_desc(A2, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU)], ws)
+        return X, C2
+    X, C2 = run()
+    t = A1.float() @ Ad.float().T
+    y = A1.float() @ W.float().T + t @ Bu.T + bias
+    ref1 = X0 + gate.repeat_interleave(256, 0)[:M1] * y
+    ref2 = torch.nn.functional.gelu(A2.float() @ W.float().T + bias, approximate="tanh")
+    assert relerr(X.cpu(), ref1.cpu()) < 2e-5
+    assert relerr(C2.float().cpu(), ref2.cpu()) < 4e-3
+    Xb, C2b = run()
+    assert torch.equal(X, Xb) and torch.equal(C2, C2b)
+    ops.gemm_workspace_status(ws)
 
 
 def test_gemm_pair_kernel_long_k(ops, monkeypatch):

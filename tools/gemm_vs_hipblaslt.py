@@ -27,7 +27,8 @@ for M, N, K, name in SHAPES:
     C2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     d = ops.gemm_desc(A, Wt, C)
     WrT = Wr.t()
-    lx = lambda: ops.gemm([d])
+    ws = ops.gemm_workspace(dev) if os.environ.get("GV_WS", "1") != "0" else None      # (the engine's default plans pass the workspace)
+    lx = lambda: ops.gemm([d], workspace=ws)
     vendor = lambda: torch.matmul(A, WrT, out=C2)
     best = {"lx": 1e9, "vendor": 1e9}
     for _ in range(3):

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03ap; mkdir -p $O
+LX_GEMM4=0 python bench.py --config 2 --no-secondary --no-cpu-baseline --no-parity --steps 2 --warmup 1 > $O/bench2_g4off.json 2>> $O/err.txt
+python bench.py --config 2 --no-secondary --no-cpu-baseline --steps 2 --warmup 1 > $O/bench2_g4on.json 2>> $O/err.txt
+LX_GEMM4=0 python bench.py --no-secondary --no-cpu-baseline --no-parity > $O/bench_g4off.json 2>> $O/err.txt
+python bench.py --no-secondary --no-cpu-baseline --no-parity > $O/bench_g4on.json 2>> $O/err.txt
+LX_GEMM4=0 python bench.py --hw 64 --batch 4 --no-secondary --no-cpu-baseline --no-parity --steps 2 --warmup 1 > $O/bench1024_g4off.json 2>> $O/err.txt
+python bench.py --hw 64 --batch 4 --no-secondary --no-cpu-baseline --no-parity --steps 2 --warmup 1 > $O/bench1024_g4on.json 2>> $O/err.txt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r03ap/bench*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("kernel","")[:40], (d.get("parity") or {}).get("noise_pred_relerr_mean"))
+PY
+tail -3 $O/err.txt
