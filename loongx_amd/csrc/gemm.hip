@@ -1153,34 +1153,31 @@ constexpr int G4_THREADS = 256;
 constexpr int G4_STAGE = 256 * BK * 2 + BN * BK * 2;      // A tile + W tile of one K tile: 64 KiB
 constexpr int G4_LDS = 2 * G4_STAGE;
 constexpr int G4_PLD = 132;                                // fp32 row stride of the epilogue patch (128 + 4 pad)
-static_assert(G4_LDS <= 160 * 1024 && 4 * 16 * G4_PLD * 4 <= G4_LDS, "LDS budget / epilogue patch");
+static_assert(G4_LDS <= 160 * 1024 && 4 * 2 * 16 * G4_PLD * 4 <= G4_LDS, "LDS budget / epilogue patches");
 
-// Split tail (sk_parts > 1; a launch with ONE K for all its problems): the tiles of the last, partial round are cut into sk_parts K
-// ranges, one workgroup each (grid = full-round tiles + sk_parts x tail tiles), so that the tail costs 1 / sk_parts of a round. The
-// workgroups of a tail tile sit next to each other in the grid, i.e. run at the same time: parts 1.. park their 256 accumulator
-// registers in their slot of the caller's workspace and raise a flag, part 0 (which also holds the LoRA term) adds them and runs the
-// epilogue. The owner's spin is bounded and sets the workspace's error word (lx_gemm_workspace_status), as the pair kernel's does.
-constexpr int SK_SLOT_FLOATS = G4_THREADS * 256;        // 256 accumulator registers x 256 lanes = 256 KiB
-constexpr int SK_MAX_WG = 256;
+// (A split-tail form -- the tiles of a partial last round cut into K ranges, one workgroup each, meeting through the workspace -- was
+// built and measured in round 3: correct, but its park / fetch code made hipcc spill accumulators on EVERY tile's path (132 VGPRs, 52
+// scratch operations behind the main loop), and at K = 3072 it lost to the 8-wave kernels' half-height tail anyway; removed again.)
+#ifdef LX_G4_PROBE     /* phase stamps (s_memtime, 100 MHz) of lx_gemm4_kernel per workgroup: tools/g4_probe.py */
+__device__ unsigned long long lx_g4_probe_buf[8192 * 8];
+#define G4_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 8192) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lx_g4_probe_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define G4_STAMP(k)
+#endif
 
-__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args, const int sk_full, const int sk_parts, float* __restrict__ sk_slots,
-                                                              int* __restrict__ sk_flags, int* __restrict__ sk_err) {
+__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) char smem[G4_LDS];
   constexpr int BM = 256, A_BYTES = BM * BK * 2;
   const int pid = blockIdx.x;
+  G4_STAMP(0)
   const int total = args.tile_start[MAX_SUB];
-  int lid, part = 0;
-  if (pid < sk_full) {                                 // a whole tile: the XCD-aware map over the full-round tiles
-    const int q = sk_full >> 3, r = sk_full & 7;
+  int lid;
+  {
+    const int q = total >> 3, r = total & 7;
     const int xcd = pid & 7, inx = pid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
-  } else {                                             // one K range of a tail tile
-    const int r = pid - sk_full;
-    lid = sk_full + r / sk_parts;
-    part = r - (r / sk_parts) * sk_parts;
   }
-  (void)total;
   const int g = tile_group(args, lid);
   const lx_gemm_desc P = args.p[g];
   int tm, tn;
@@ -1191,10 +1188,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = P.M, N = P.N, K = P.K;
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
-  const int nkt = K / BK;                              // K tiles of the whole tile; this workgroup's share: [kt_begin, kt_end)
-  const bool split_tile = pid >= sk_full && sk_parts > 1;
-  const int kt_begin = split_tile ? (nkt * part) / sk_parts : 0;
-  const int kt_end = split_tile ? (nkt * (part + 1)) / sk_parts : nkt;
+  const int nkt = K / BK;
+  constexpr int kt_begin = 0;
+  const int kt_end = nkt;
 
   // ---- staging: this wave moves pieces j * 4 + wave (j = 0..7; 1 KiB = 8 rows of 128 B each) of both operand tiles ----
   uint32_t aoff[8], woff[8];
@@ -1246,7 +1242,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // MFMA k-step. Lane (row l15, chunk lq) carries ranks 2 lq and 2 lq + 1; each rank fills four k-slots with the bf16 hi / lo cross
   // terms [u_hi, u_hi, u_lo, u_lo] x [t_hi, t_lo, t_hi, t_lo]: fp32-class (2^-16), as lora_apply above does for the 8-wave kernels.
   // The loads go out BEFORE the operand DMA (vmcnt is one in-order queue: the wait that covers K tile 0 then covers them too).
-  const bool has_lora = P.lora_t != nullptr && kt_begin == 0;     // (the planner admits rank <= 8, even, 8-byte aligned rows; once per tile: with its first K tiles)
+  const bool has_lora = P.lora_t != nullptr;           // (the planner admits rank <= 8, even, 8-byte aligned rows here)
   u32x2 lu[8], lt[8][4];
   if (has_lora) {
     const int R = P.lora_r, nsplit = P.lora_nsplit;
@@ -1269,6 +1265,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   G4_SB();
+  G4_STAMP(1)
 #pragma unroll
   for (int x = 0; x < 16; ++x) rd(0, 0, x);
   if (has_lora) {
@@ -1315,6 +1312,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   //   k-step 1: 64 MFMAs; W pieces one per five; vmcnt(16) = K tile kt + 1 (issued an iteration ago) has landed, barrier, and its
   //             k-step-0 reads behind the last MFMAs.
   // Branch-free tail: past the last K tile the final tile is staged again (identical bytes over a stage nobody reads any more).
+  G4_STAMP(2)
   int c = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int n = c ^ 1;
@@ -1349,71 +1347,16 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #undef G4_SB
   // the inline-asm MFMAs are opaque to the hazard recogniser (MFMA write -> v_accvgpr_read: 18 wait states); every LDS-DMA piece
   // has landed and every wave is done with the operand stages before the patch below reuses them
+  G4_STAMP(3)
   asm volatile("s_nop 15\n s_nop 7\n s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
-  // ---- split tail: hand-over of the partial sums ----------------------------------------------------------------------------
-  if (split_tile) {
-    if (part > 0) {
-      // park the accumulators (register r of thread tid at [r][tid]: 16 B per lane and instruction, sc1 = visible at agent scope),
-      // raise the flag, done
-      const lx_rsrc_t rs = lx_make_rsrc(sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS);
-      auto park = [&](auto ic_) {
-        constexpr int i = decltype(ic_)::value;
-        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4 v = acc[i][j];
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs, tid * 16,
-                                                 (i * 8 + j) * (G4_THREADS * 16), PAIR_AUX_SC1);
-        }
-      };
-      park(std::integral_constant<int, 0>{}); park(std::integral_constant<int, 1>{}); park(std::integral_constant<int, 2>{}); park(std::integral_constant<int, 3>{});
-      park(std::integral_constant<int, 4>{}); park(std::integral_constant<int, 5>{}); park(std::integral_constant<int, 6>{}); park(std::integral_constant<int, 7>{});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    for (int pp = 1; pp < sk_parts; ++pp) {            // the owner: wait (bounded) for each partner, add its sums, clear its flag
-      const int ps = pid - sk_full + pp;
-      if (tid == 0) {
-        int spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(sk_flags + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 20)) { ok = false; break; }
-        }
-        if (ok) __hip_atomic_store(sk_flags + ps, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
-      }
-      __syncthreads();
-      const lx_rsrc_t rs = lx_make_rsrc(sk_slots + (size_t)ps * SK_SLOT_FLOATS);
-      auto fetch = [&](auto ic_) {
-        constexpr int i = decltype(ic_)::value;
-        u32x4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (i * 8 + j) * (G4_THREADS * 16), PAIR_AUX_SC1);
-        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f32x4 a = acc[i][j];
-#pragma unroll
-          for (int c_ = 0; c_ < 4; ++c_) a[c_] += __uint_as_float(v[j][c_]);
-          acc[i][j] = a;
-        }
-        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
-      };
-      fetch(std::integral_constant<int, 0>{}); fetch(std::integral_constant<int, 1>{}); fetch(std::integral_constant<int, 2>{}); fetch(std::integral_constant<int, 3>{});
-      fetch(std::integral_constant<int, 4>{}); fetch(std::integral_constant<int, 5>{}); fetch(std::integral_constant<int, 6>{}); fetch(std::integral_constant<int, 7>{});
-    }
-  }
+  G4_STAMP(4)
 
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
   const int epi = P.epilogue & 0xff;
   const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
   const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
-  float* patch = (float*)smem + wave * (16 * G4_PLD);
+  float* patch = (float*)smem + wave * (2 * 16 * G4_PLD);          // two 16-row patches per wave
   const bool bf16_out = epi == LX_EPI_STORE_BF16;
   const int c8 = (lane & 15) * 8, c4 = (lane & 31) * 4;
   const int ncol = nw0 + (bf16_out ? c8 : c4);
@@ -1436,14 +1379,26 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     nw0v = *(const f32x4*)nwp; nw1v = *(const f32x4*)(nwp + 4);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(nw0v), "+v"(nw1v)::"memory");
   }
-  // one 16-row block; a generic lambda over an integral constant, not a loop: acc[i] must be a compile-time register index (a loop that
-  // hipcc declines to unroll sends all 256 accumulators to scratch)
+  // One 16-row block at a time through TWO patches: with one wave per SIMD nothing else covers the LDS round trips, so block i + 1 is
+  // written (accumulators -> patch (i + 1) & 1) right behind the reads of block i, under their latency and block i's arithmetic and
+  // stores (a strictly serial write -> wait -> read -> wait -> store chain per block measured 12 us per tile: tools/g4_probe.py).
+  // Generic lambdas over an integral constant, not loops: acc[i] must be a compile-time register index (a loop that hipcc declines to
+  // unroll sends all 256 accumulators to scratch).
+  auto put = [&](auto ic_) {
+    constexpr int i = decltype(ic_)::value;
+    float* pt = patch + (i & 1) * (16 * G4_PLD);
+    // the block's eight accumulators stay in AGPRs up to here (left to itself hipcc moves all 256 to VGPRs at once and spills them)
+    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(f32x4*)(pt + l15 * G4_PLD + j * 16 + 4 * lq) = acc[i][j];
+  };
   auto block = [&](auto ic_) {
     constexpr int i = decltype(ic_)::value;
     const int mb = mw0 + i * 16;
-    if (mb >= M) return;                               // (wave-uniform)
+    if (mb >= M) return;                               // (wave-uniform; the blocks behind it are out of range as well)
+    const float* pt = patch + (i & 1) * (16 * G4_PLD);
     f32x4 res[8], gat[8];
-    if (epi == LX_EPI_RESID_F32) {                     // residual / gate rows of the block, requested before the patch is written
+    if (epi == LX_EPI_RESID_F32 && !qkv_tile) {        // residual / gate rows of the block, requested first
       const int rpb = P.rows_per_batch;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -1454,11 +1409,11 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         }
       }
     }
-    // the block's eight accumulators stay in AGPRs up to here (left to itself hipcc moves all 256 to VGPRs at once and spills them)
-    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *(f32x4*)(patch + l15 * G4_PLD + j * 16 + 4 * lq) = acc[i][j];
     __builtin_amdgcn_wave_barrier();
+    // block i + 1 goes into the other patch HERE, at one place per block and outside every epilogue branch: with the accumulator reads
+    // inside the (tile-uniform) branches hipcc has to reconcile 256 AGPR assignments at every join, through VGPRs and scratch
+    if constexpr (i < 7) { if (mb + 16 < M) put(std::integral_constant<int, i + 1>{}); }
+    __builtin_amdgcn_sched_barrier(0);
     if (qkv_tile) {
       const int D = P.qkv_d, L = P.rows_per_batch, H = D >> 7;
       const int gm = m_base + mb, b = gm / L, p0 = gm - b * L;           // (M and L are multiples of 32: a 16-row block is whole, in one batch)
@@ -1466,20 +1421,23 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       if (qkind == 1) {
         // v: 16 keys x 128 head dims -> V^T rows; lane = (d, group of 8 keys), the 16-key interleave of the attention kernel's image
         const int gk = lane & 1;
+        float e[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[t][k] = pt[qkv_vt_interleave(gk * 8 + k) * G4_PLD + t * 32 + (lane >> 1)];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int d = t * 32 + (lane >> 1);
           const float bd = P.bias ? P.bias[nw0 + d] : 0.f;
-          float e[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) e[k] = patch[qkv_vt_interleave(gk * 8 + k) * G4_PLD + d] + bd;
-          u32x4 o = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+          u32x4 o = {pack_bf16x2(e[t][0] + bd, e[t][1] + bd), pack_bf16x2(e[t][2] + bd, e[t][3] + bd), pack_bf16x2(e[t][4] + bd, e[t][5] + bd),
+                     pack_bf16x2(e[t][6] + bd, e[t][7] + bd)};
           *(u32x4*)((uint16_t*)P.qkv_vt + ((size_t)(b * H + h) * 128 + d) * P.qkv_vt_ld + P.qkv_vt_pos0 + p0 + gk * 8) = o;
         }
       } else {
         uint16_t* const out = (qkind == 0 && P.qkv_k) ? (uint16_t*)P.qkv_k : (uint16_t*)P.C;
         const int out_ld = (qkind == 0 && P.qkv_k) ? P.qkv_k_ld : P.ldc;
-        f32x4 cs[4][2];
+        f32x4 cs[4][2], pv[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {                  // the block's RoPE rows: (cos, sin) pairs of this lane's 8 columns
           const float* rp = P.qkv_rope + (size_t)(p0 + t * 4 + (lane >> 4)) * 128 + c8;
@@ -1487,9 +1445,13 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+          const int row = t * 4 + (lane >> 4);
+          pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
           const int row = t * 4 + (lane >> 4), m = mb + row;
-          f32x4 v0 = *(const f32x4*)(patch + row * G4_PLD + c8);
-          f32x4 v1 = *(const f32x4*)(patch + row * G4_PLD + c8 + 4);
+          f32x4 v0 = pv[t][0], v1 = pv[t][1];
           float ss = 0.f;
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; ss = __builtin_fmaf(v0[c_], v0[c_], ss); ss = __builtin_fmaf(v1[c_], v1[c_], ss); }
@@ -1510,15 +1472,19 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
       return;
     }
     if (bf16_out) {
+      f32x4 pv[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 4 + (lane >> 4);
+        pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = t * 4 + (lane >> 4), m = mb + row;
-        f32x4 v0 = *(const f32x4*)(patch + row * G4_PLD + c8);
-        f32x4 v1 = *(const f32x4*)(patch + row * G4_PLD + c8 + 4);
+        f32x4 v0 = pv[t][0], v1 = pv[t][1];
         if (m < M && col_ok) {
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; }
@@ -1528,6 +1494,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         }
       }
     } else {
+      f32x4 pv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pv[t] = *(const f32x4*)(pt + (t * 2 + (lane >> 5)) * G4_PLD + c4);
       if (epi == LX_EPI_RESID_F32) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1536,7 +1505,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int row = t * 2 + (lane >> 5), m = mb + row;
-        f32x4 v = *(const f32x4*)(patch + row * G4_PLD + c4);
+        f32x4 v = pv[t];
         if (m < M && col_ok) {
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) v[c_] += bias0[c_];
@@ -1556,10 +1525,12 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
   };
+  if (mw0 < M) put(std::integral_constant<int, 0>{});
   block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
   block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{}); block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G4_STAMP(5)
 #endif
 }
 
@@ -1572,10 +1543,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 0)};
+                 env_int("LX_GEMM4", 1)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1586,9 +1557,6 @@ extern "C" void lx_gemm_reload_env(void) { g_gemm_env = read_gemm_env(); }
 // whoever owns a stream owns its workspace, so launches on different streams never share slots or flags.
 namespace {
 constexpr size_t PAIR_WS_BYTES = (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float) + (PAIR_MAX_WG + 64) * sizeof(int);
-// behind it, the split-tail area of lx_gemm4_kernel: [SK_MAX_WG slots of 256 KiB | SK_MAX_WG flags] (the error word is the pair area's)
-constexpr size_t SK_WS_OFF = (PAIR_WS_BYTES + 255) & ~(size_t)255;
-constexpr size_t SK_WS_BYTES = SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float) + (SK_MAX_WG + 64) * sizeof(int);
 
 int device_cus() {
   static int n = -1;
@@ -1638,7 +1606,12 @@ static void plan_add(GemmArgs& a, const lx_gemm_desc& p, int m_base, int bm) {
   for (int i = a.n + 1; i <= MAX_SUB; ++i) a.tile_start[i] = a.tile_start[a.n];
 }
 
-extern "C" size_t lx_gemm_workspace_bytes(void) { return SK_WS_BYTES; }
+extern "C" size_t lx_gemm_workspace_bytes(void) { return PAIR_WS_BYTES; }
+#ifdef LX_G4_PROBE
+extern "C" int lx_g4_probe_read(unsigned long long* host, size_t n_u64) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(lx_g4_probe_buf), n_u64 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   LX_CHECK_ARG(workspace, "lx_gemm_workspace_status: NULL workspace");
@@ -1652,7 +1625,6 @@ extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   if (v == 0) return LX_OK;
   // a timed-out pair leaves flags behind: reset all of them with the error word so the workspace is usable again
   (void)hipMemsetAsync((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
-  (void)hipMemsetAsync((char*)workspace + SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float), 0, (SK_MAX_WG + 64) * sizeof(int), s);
   (void)hipStreamSynchronize(s);
   lx_set_error("lx_gemm_bf16_ws: a split-K pair workgroup timed out waiting for its partner (CUs held by other work?); the results "
                "of that launch are invalid. Re-run with the workspace omitted (lx_gemm_bf16) or LX_GEMM_PAIR=0");
@@ -1764,31 +1736,13 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     }
     const long rounds = (t256 + NCU - 1) / NCU;
     const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
-    // split tail (LX_GEMM4_SK = 0 default: measured slower than the 8-wave kernels' half-height tail on the step's shapes | 1 on): at least one full round, fewer than 8 rounds, a last round less than 3/4 full, one K
-    // for the whole launch, the caller's workspace: its tiles are cut into as many K ranges (<= 4, >= 8 K tiles each) as fit one round
-    bool uniform_k4 = true;
-    for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
-    const long tail = t256 % NCU, full = t256 - tail;
-    int parts = 1;
-    if (env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && full > 0 && rounds < 8 && tail > 0) {
-      parts = (int)(NCU / tail);
-      if (parts > 4) parts = 4;
-      while (parts > 1 && (problems[0].K / BK) / parts < 8) --parts;
-      if (tail * parts > SK_MAX_WG) parts = 1;
-    }
-    if (ok && (fills || parts > 1)) {
+    if (ok && fills) {
       GemmArgs all;
       all.n = 0;
       all.tile_start[0] = 0;
       for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
       for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
-      if (parts > 1) {
-        float* slots = (float*)((char*)workspace + SK_WS_OFF);
-        int* flags = (int*)((char*)workspace + SK_WS_OFF + (size_t)SK_MAX_WG * SK_SLOT_FLOATS * sizeof(float));
-        int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
-        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + tail * parts)), dim3(G4_THREADS), 0, s, all, (int)full, parts, slots, flags, err);
-      } else
-        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
+      hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all);
       LX_LAUNCH_CHECK("lx_gemm_bf16");
       return LX_OK;
     }
