@@ -298,7 +298,7 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
         traffic, traffic_src = _gemm_traffic_mb()
         gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
                  "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
-                 "lx_gemm_kernel (bf16 32x32x16 MFMA, fused epilogues)")
+                 "lx_gemm_* (bf16 MFMA, fused epilogues; launch-weighted over the 8-wave 32x32x16 kernels and lx_gemm4_kernel, the one-wave-per-SIMD 16x16x32 form)")
         if gemm_fp8 or precise or B != 1 or hw != 32:
             traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels at the headline shape
         res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 301 /* 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
+#define LX_VERSION 302 /* 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
                           * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {

@@ -1165,32 +1165,48 @@ __device__ unsigned long long lx_g4_probe_buf[8192 * 8];
 #define G4_STAMP(k)
 #endif
 
-__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args) {
+// Split form (sk_parts == 2): the tiles at positions >= sk_full of the tile order -- a partial last round, or every tile of a launch
+// with at most 128 of them -- are computed by TWO workgroups, half of K each, next to each other in the grid. The second one runs the
+// plain fp32-store epilogue into its 256 x 256 slot of the caller's workspace and raises a flag; the first one (which also holds the
+// LoRA term) waits (bounded: the workspace's error word reports a time-out, as the pair kernel's does), and its epilogue adds the
+// parked sums row by row where it reads its own from the patch -- the accumulators themselves are never touched outside the main loop
+// and the one place per block that writes them to the patch (anything else makes hipcc shuffle and spill them).
+constexpr int SK_SLOT_FLOATS = 256 * 256;
+
+__global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args, const int sk_full, const int sk_parts, float* __restrict__ sk_slots,
+                                                              int* __restrict__ sk_flags, int* __restrict__ sk_err) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) char smem[G4_LDS];
   constexpr int BM = 256, A_BYTES = BM * BK * 2;
   const int pid = blockIdx.x;
   G4_STAMP(0)
   const int total = args.tile_start[MAX_SUB];
-  int lid;
-  {
-    const int q = total >> 3, r = total & 7;
+  int lid, part = 0;
+  if (pid < sk_full) {                                 // a whole tile: the XCD-aware map over the whole-tile part of the order
+    const int q = sk_full >> 3, r = sk_full & 7;
     const int xcd = pid & 7, inx = pid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
+  } else {                                             // one half of K of a split tile
+    const int r = pid - sk_full;
+    lid = sk_full + (r >> 1);
+    part = r & 1;
   }
+  (void)total;
+  const bool split_tile = pid >= sk_full && sk_parts == 2;
   const int g = tile_group(args, lid);
-  const lx_gemm_desc P = args.p[g];
+  lx_gemm_desc P = args.p[g];
   int tm, tn;
   tile_coords<BM>(P, lid - args.tile_start[g], tm, tn);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int M = P.M, N = P.N, K = P.K;
+  int m0 = tm * BM, n0 = tn * BN;
+  int M = P.M, N = P.N;
+  const int K = P.K;
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
-  const int nkt = K / BK;
-  constexpr int kt_begin = 0;
-  const int kt_end = nkt;
+  const int nkt = K / BK;                              // K tiles of the tile; this workgroup's share: [kt_begin, kt_end)
+  const int kt_begin = split_tile && part ? nkt >> 1 : 0;
+  const int kt_end = split_tile && !part ? nkt >> 1 : nkt;
 
   // ---- staging: this wave moves pieces j * 4 + wave (j = 0..7; 1 KiB = 8 rows of 128 B each) of both operand tiles ----
   uint32_t aoff[8], woff[8];
@@ -1242,7 +1258,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // MFMA k-step. Lane (row l15, chunk lq) carries ranks 2 lq and 2 lq + 1; each rank fills four k-slots with the bf16 hi / lo cross
   // terms [u_hi, u_hi, u_lo, u_lo] x [t_hi, t_lo, t_hi, t_lo]: fp32-class (2^-16), as lora_apply above does for the 8-wave kernels.
   // The loads go out BEFORE the operand DMA (vmcnt is one in-order queue: the wait that covers K tile 0 then covers them too).
-  const bool has_lora = P.lora_t != nullptr;           // (the planner admits rank <= 8, even, 8-byte aligned rows here)
+  const bool has_lora = P.lora_t != nullptr && kt_begin == 0;     // (the planner admits rank <= 8, even, 8-byte aligned rows; once per tile: with its first K tiles)
   u32x2 lu[8], lt[8][4];
   if (has_lora) {
     const int R = P.lora_r, nsplit = P.lora_nsplit;
@@ -1352,6 +1368,30 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   __syncthreads();
   G4_STAMP(4)
 
+  // ---- split tiles: the second half parks through the plain fp32-store epilogue, the first half waits for it ----
+  const bool parked = split_tile && part == 1;
+  const float* partner = nullptr;                      // the other half's sums (tile-local [256][256] fp32), added in the epilogue
+  const int lm0 = wm * 128, ln0 = wn * 128;            // this wave's tile-local origin
+  if (parked) {
+    P.C = sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS;
+    P.ldc = 256; P.epilogue = LX_EPI_STORE_F32; P.bias = nullptr;
+    m0 = 0; n0 = 0; M = 256; N = 256;
+  } else if (split_tile) {
+    if (tid == 0) {
+      int spins = 0;
+      bool ok = true;
+      while (__hip_atomic_load(sk_flags + (pid - sk_full + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) { ok = false; break; }
+      }
+      if (ok) __hip_atomic_store(sk_flags + (pid - sk_full + 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold stale lines of the slot (an earlier launch's sums)
+    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;
+  }
+
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
   const int epi = P.epilogue & 0xff;
   const bool do_gelu = (P.epilogue & LX_EPI_GELU) != 0;
@@ -1425,7 +1465,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) e[t][k] = pt[qkv_vt_interleave(gk * 8 + k) * G4_PLD + t * 32 + (lane >> 1)];
+          for (int k = 0; k < 8; ++k) {
+            const int rk = qkv_vt_interleave(gk * 8 + k), dk = t * 32 + (lane >> 1);
+            e[t][k] = pt[rk * G4_PLD + dk] + (partner ? partner[(size_t)(lm0 + i * 16 + rk) * 256 + ln0 + dk] : 0.f);
+          }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int d = t * 32 + (lane >> 1);
@@ -1447,6 +1490,15 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         for (int t = 0; t < 4; ++t) {
           const int row = t * 4 + (lane >> 4);
           pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
+        }
+        if (partner) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float* pp = partner + (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
+            const f32x4 a = *(const f32x4*)pp, b2 = *(const f32x4*)(pp + 4);
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) { pv[t][0][c_] += a[c_]; pv[t][1][c_] += b2[c_]; }
+          }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1481,6 +1533,15 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         const int row = t * 4 + (lane >> 4);
         pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
       }
+      if (partner) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float* pp = partner + (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
+          const f32x4 a = *(const f32x4*)pp, b2 = *(const f32x4*)(pp + 4);
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) { pv[t][0][c_] += a[c_]; pv[t][1][c_] += b2[c_]; }
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = t * 4 + (lane >> 4), m = mb + row;
@@ -1497,6 +1558,14 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       f32x4 pv[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) pv[t] = *(const f32x4*)(pt + (t * 2 + (lane >> 5)) * G4_PLD + c4);
+      if (partner) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const f32x4 a = *(const f32x4*)(partner + (size_t)(lm0 + i * 16 + t * 2 + (lane >> 5)) * 256 + ln0 + c4);
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) pv[t][c_] += a[c_];
+        }
+      }
       if (epi == LX_EPI_RESID_F32) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1529,6 +1598,15 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   if (mw0 < M) put(std::integral_constant<int, 0>{});
   block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
   block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{}); block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
+  if (parked) {                                        // publish: stores done, L2 written back at agent scope, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G4_STAMP(5)
 #endif
@@ -1543,10 +1621,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 0)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1557,6 +1635,9 @@ extern "C" void lx_gemm_reload_env(void) { g_gemm_env = read_gemm_env(); }
 // whoever owns a stream owns its workspace, so launches on different streams never share slots or flags.
 namespace {
 constexpr size_t PAIR_WS_BYTES = (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float) + (PAIR_MAX_WG + 64) * sizeof(int);
+// behind it, the split-tile area of lx_gemm4_kernel: [256 slots of 256 KiB | 256 flags] (the error word is the pair area's)
+constexpr size_t SK_WS_OFF = (PAIR_WS_BYTES + 255) & ~(size_t)255;
+constexpr size_t SK_WS_BYTES = SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float) + (256 + 64) * sizeof(int);
 
 int device_cus() {
   static int n = -1;
@@ -1606,7 +1687,7 @@ static void plan_add(GemmArgs& a, const lx_gemm_desc& p, int m_base, int bm) {
   for (int i = a.n + 1; i <= MAX_SUB; ++i) a.tile_start[i] = a.tile_start[a.n];
 }
 
-extern "C" size_t lx_gemm_workspace_bytes(void) { return PAIR_WS_BYTES; }
+extern "C" size_t lx_gemm_workspace_bytes(void) { return SK_WS_BYTES; }
 #ifdef LX_G4_PROBE
 extern "C" int lx_g4_probe_read(unsigned long long* host, size_t n_u64) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(lx_g4_probe_buf), n_u64 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
@@ -1625,6 +1706,7 @@ extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   if (v == 0) return LX_OK;
   // a timed-out pair leaves flags behind: reset all of them with the error word so the workspace is usable again
   (void)hipMemsetAsync((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
+  (void)hipMemsetAsync((char*)workspace + SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float), 0, (256 + 64) * sizeof(int), s);
   (void)hipStreamSynchronize(s);
   lx_set_error("lx_gemm_bf16_ws: a split-K pair workgroup timed out waiting for its partner (CUs held by other work?); the results "
                "of that launch are invalid. Re-run with the workspace omitted (lx_gemm_bf16) or LX_GEMM_PAIR=0");
@@ -1736,13 +1818,30 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     }
     const long rounds = (t256 + NCU - 1) / NCU;
     const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
-    if (ok && fills) {
+    // split form (LX_GEMM4_SK = 0 default | 1 on; measured on the step's shapes in round 3: fused projection 284 vs 277 us for the 8-wave
+    // mixed plan, q/k/v 140 vs 126, ff2 159 vs 157 and proj_out 190 vs 193 for the pair kernel, 1.003 vs 1.020 images/s end to end -- the
+    // release / acquire round trip and the owner's exposed partner loads cost what the shorter tail saves): the tiles of a partial last round, or all tiles of a launch with <= 128 of them and
+    // a long K, by two workgroups each (half of K), meeting through the caller's workspace. One K for the whole launch, >= 16 K tiles.
+    bool uniform_k4 = true;
+    for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
+    const long tail = t256 % NCU, full = t256 - tail;
+    const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && problems[0].K / BK >= 16 &&
+                           tail > 0 && tail * 2 <= 256 && rounds < 8;
+    const bool split_all = can_split && full == 0 && problems[0].K / BK >= env.pair_min_kt;      // (the pair kernel's shapes)
+    const bool split_tail = can_split && full > 0;
+    if (ok && (fills || split_all || split_tail)) {
       GemmArgs all;
       all.n = 0;
       all.tile_start[0] = 0;
       for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
       for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
-      hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all);
+      if (split_all || split_tail) {
+        float* slots = (float*)((char*)workspace + SK_WS_OFF);
+        int* flags = (int*)((char*)workspace + SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float));
+        int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
+        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, 2, slots, flags, err);
+      } else
+        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
       LX_LAUNCH_CHECK("lx_gemm_bf16");
       return LX_OK;
     }

@@ -50,7 +50,7 @@ def _restore_gemm_env():
     yield
     if torch.cuda.is_available():
         from loongx_amd import _lib
-        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR", "LX_GEMM4"):
+        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR", "LX_GEMM4", "LX_GEMM4_SK"):
             os.environ.pop(k, None)
         _lib.lib.lx_gemm_reload_env()
 
@@ -186,12 +186,15 @@ def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
 
-def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch):
+@pytest.mark.parametrize("sk", [0, 1])
+def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
     """lx_gemm4_kernel (4 waves x 128x128, AGPR accumulators) on a two-problem launch with every plain-epilogue ingredient it has: gated
     fp32 residual + bias + LoRA (rank 4, two K-split slabs) on one problem, bf16 store + GELU on the other (its last tile row ragged);
-    against fp32 references, bit-identical from run to run."""
+    280 tiles = one full round + a 24-tile tail. sk = 1 (LX_GEMM4_SK): the tail's tiles by two workgroups each, half of K, meeting
+    through the workspace. Against fp32 references, bit-identical from run to run."""
     monkeypatch.delenv("LX_GEMM_BM", raising=False)
     monkeypatch.setenv("LX_GEMM4", "2")
+    monkeypatch.setenv("LX_GEMM4_SK", str(sk))
     ops.lib.lx_gemm_reload_env()
     ws = _ws()
     M1, M2, N, K, r = 768, 352, 256 * 56, 2048, 4          # 3 x 56 + 2 x 56 = 280 tiles (the second problem's last tile row is ragged)
