@@ -141,6 +141,11 @@ void lx_gemm_reload_env(void);
  *   (the library keeps no scratch of its own, so launches on different streams never share slots or flags).
  *   NULL / 0 => exactly lx_gemm_bf16.
  * LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144) | 2 whenever possible (tests).
+ * Passing a workspace also selects the plans that depend on the launch's tile count: lx_gemm4_kernel (the 256x256x64 tile with one
+ * wave per SIMD, AGPR accumulators) for launches whose tiles fill whole rounds (LX_GEMM4 = 0 never | 1 default | 2 whenever its
+ * epilogues allow; LX_GEMM4_SK = 1: its split form, which does exchange through the workspace). Without one the plans do not depend
+ * on the batch size: a data-parallel shard reproduces the single-GPU batch bit for bit.
+ * Layout (for callers that poll asynchronously): the error word is the int 64 ints before the end of the workspace.
  * The pair plan needs both workgroups of a tile resident at once (<= 256 workgroups on a 256-CU device, checked); if other work
  * holds CUs for longer than the bounded wait (~1 s), the waiting workgroup raises the workspace's error word and finishes with
  * an invalid tile instead of hanging or trapping: lx_gemm_workspace_status() (synchronises `stream`) then returns

@@ -1635,9 +1635,12 @@ extern "C" void lx_gemm_reload_env(void) { g_gemm_env = read_gemm_env(); }
 // whoever owns a stream owns its workspace, so launches on different streams never share slots or flags.
 namespace {
 constexpr size_t PAIR_WS_BYTES = (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float) + (PAIR_MAX_WG + 64) * sizeof(int);
-// behind it, the split-tile area of lx_gemm4_kernel: [256 slots of 256 KiB | 256 flags] (the error word is the pair area's)
-constexpr size_t SK_WS_OFF = (PAIR_WS_BYTES + 255) & ~(size_t)255;
-constexpr size_t SK_WS_BYTES = SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float) + (256 + 64) * sizeof(int);
+// IN FRONT of it, the split-tile area of lx_gemm4_kernel: [256 slots of 256 KiB | 256 flags + pad]; the pair area stays LAST, so the one
+// error word both kernels raise is still the int at (end - 64 ints): callers that poll it asynchronously read that position
+constexpr size_t SK_AREA_BYTES = (((size_t)256 * SK_SLOT_FLOATS * sizeof(float) + (256 + 64) * sizeof(int)) + 255) & ~(size_t)255;
+constexpr size_t PAIR_OFF = SK_AREA_BYTES;               // byte offset of the pair area
+constexpr size_t SK_WS_BYTES = PAIR_OFF + PAIR_WS_BYTES;
+static_assert(PAIR_WS_BYTES % 4 == 0, "the error word is an aligned int");
 
 int device_cus() {
   static int n = -1;
@@ -1696,7 +1699,7 @@ extern "C" int lx_g4_probe_read(unsigned long long* host, size_t n_u64) {
 
 extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   LX_CHECK_ARG(workspace, "lx_gemm_workspace_status: NULL workspace");
-  int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
+  int* err = (int*)((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
   int v = 0;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(&v, err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
@@ -1705,8 +1708,8 @@ extern "C" int lx_gemm_workspace_status(void* workspace, void* stream) {
   }
   if (v == 0) return LX_OK;
   // a timed-out pair leaves flags behind: reset all of them with the error word so the workspace is usable again
-  (void)hipMemsetAsync((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
-  (void)hipMemsetAsync((char*)workspace + SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float), 0, (256 + 64) * sizeof(int), s);
+  (void)hipMemsetAsync((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float), 0, (PAIR_MAX_WG + 64) * sizeof(int), s);
+  (void)hipMemsetAsync((char*)workspace + (size_t)256 * SK_SLOT_FLOATS * sizeof(float), 0, (256 + 64) * sizeof(int), s);
   (void)hipStreamSynchronize(s);
   lx_set_error("lx_gemm_bf16_ws: a split-K pair workgroup timed out waiting for its partner (CUs held by other work?); the results "
                "of that launch are invalid. Re-run with the workspace omitted (lx_gemm_bf16) or LX_GEMM_PAIR=0");
@@ -1836,9 +1839,9 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
       for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
       for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, 256);
       if (split_all || split_tail) {
-        float* slots = (float*)((char*)workspace + SK_WS_OFF);
-        int* flags = (int*)((char*)workspace + SK_WS_OFF + (size_t)256 * SK_SLOT_FLOATS * sizeof(float));
-        int* err = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
+        float* slots = (float*)workspace;
+        int* flags = (int*)((char*)workspace + (size_t)256 * SK_SLOT_FLOATS * sizeof(float));
+        int* err = (int*)((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
         hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, 2, slots, flags, err);
       } else
         hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
@@ -1856,11 +1859,11 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const int per_xcd = (int)(t256 / 8 + (t256 % 8 ? 1 : 0));
     const bool fits = per_xcd * 16 <= PAIR_MAX_WG && kmax / BK >= 2;
     const bool pays = pair_mode == 2 || kmax / BK >= env.pair_min_kt;
-    if (workspace) LX_CHECK_ARG(ws_bytes >= PAIR_WS_BYTES && ((uintptr_t)workspace & 255) == 0, "lx_gemm_bf16_ws: workspace needs %zu bytes, 256-byte aligned", PAIR_WS_BYTES);
+    if (workspace) LX_CHECK_ARG(ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0, "lx_gemm_bf16_ws: workspace needs %zu bytes (lx_gemm_workspace_bytes()), 256-byte aligned", SK_WS_BYTES);
     if (workspace && pair_mode && forced == 0 && uniform_k && fits && pays && !qkv && NCU == PAIR_MAX_WG) {
       {
-        float* slots = (float*)workspace;
-        int* flags = (int*)((char*)workspace + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float));
+        float* slots = (float*)((char*)workspace + PAIR_OFF);
+        int* flags = (int*)((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float));
         GemmArgs all;
         all.n = 0;
         all.tile_start[0] = 0;

@@ -174,14 +174,18 @@ class DiTEngine:
             self.cond_ready = False
             self.sched = None
 
-    def gemm_ws(self) -> Optional[torch.Tensor]:
+    def gemm_ws(self, side: bool = False) -> Optional[torch.Tensor]:
+        """The caller-owned GEMM workspace of lx_gemm_bf16_ws (the default launch plans: split-K pairs, lx_gemm4_kernel). One per stream:
+        side=True is the second stream's (the MLP-up half of the single blocks' projection, LX_OVERLAP) -- its launches have too many
+        tiles for any plan that exchanges through the workspace, but passing one is what selects the default plans."""
         if not self.pair_plan:
             return None
         if self._gemm_ws is None:
             if torch.cuda.is_current_stream_capturing():
                 return None                      # never allocate inside a capture; the eager warm-up pass allocates it
             self._gemm_ws = ops.gemm_workspace(self.device)
-        return self._gemm_ws
+            self._gemm_ws_side = ops.gemm_workspace(self.device)
+        return self._gemm_ws_side if side else self._gemm_ws
 
     def check_status(self, sync: bool = True) -> None:
         """Raises LxError if a split-K pair workgroup timed out (the results of that step are invalid); the pair plan is then
@@ -193,6 +197,8 @@ class DiTEngine:
         if sync:
             try:
                 ops.gemm_workspace_status(self._gemm_ws)
+                if getattr(self, "_gemm_ws_side", None) is not None:
+                    ops.gemm_workspace_status(self._gemm_ws_side)
             except Exception:
                 self.pair_plan, self.graphs, self._err_event = False, {}, None
                 raise
@@ -557,7 +563,7 @@ class DiTEngine:
                     kw.update(lora_t=self.TL[row0:row0 + a.shape[0], lora_t_col0:], lora_up=lo.up[c0:c0 + W.shape[0]], lora_mod_cols=lora_mod_cols,
                               lora_toff_max=lora_toff_max, lora_nsplit=nsplit, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, W, c, **kw))
-        ops.gemm(probs, self.gemm_ws() if ws else None)
+        ops.gemm(probs, self.gemm_ws(side=not ws))
 
     def _rope_pairs(self, check: bool) -> None:
         """(cos, sin) per rotary pair, [L, 128], for LX_EPI_QKV, and the decision whether the projections of this configuration
