@@ -227,6 +227,21 @@ def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
     ops.gemm_workspace_status(ws)
 
 
+def test_gemm_workspace_error_word_position(ops):
+    """The engine polls the workspace's error word asynchronously (FluxEngine.check_status(sync=False)) at a FIXED position: the int 64
+    ints before the end (include/lx.h). Raising it by hand must be what lx_gemm_workspace_status reports -- and resets."""
+    from loongx_amd._lib import LxError
+    ws = ops.gemm_workspace(DEV)
+    n = ws.numel()
+    assert n == ops.lib.lx_gemm_workspace_bytes() and not bool(ws.any())
+    ops.gemm_workspace_status(ws)                                         # clean
+    ws[n - 64 * 4: n - 63 * 4].view(torch.int32)[0] = 1
+    with pytest.raises(LxError):
+        ops.gemm_workspace_status(ws)
+    ops.gemm_workspace_status(ws)                                         # reported once, then reset
+    assert not bool(ws[n - 64 * 4:].any())
+
+
 def test_gemm_pair_kernel_long_k(ops, monkeypatch):
     """Two workgroups per tile on the single-block proj_out shape (120 tiles, K = 15360, gated fp32 residual + LoRA): against the
     128-row-tile kernel on the same inputs, bit-identical from run to run, and again after HIP-graph capture + replays (each
