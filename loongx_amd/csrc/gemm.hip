@@ -1371,6 +1371,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // ---- split tiles: the second half parks through the plain fp32-store epilogue, the first half waits for it ----
   const bool parked = split_tile && part == 1;
   const float* partner = nullptr;                      // the other half's sums (tile-local [256][256] fp32), added in the epilogue
+  auto pld4 = [&](size_t off_floats) {                 // 16 B of the partner's slot, agent scope (sc1: not from this CU's L1 / a stale L2 line)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lx_make_rsrc(partner), (int)(off_floats * 4), 0, PAIR_AUX_SC1);
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  };
   const int lm0 = wm * 128, ln0 = wn * 128;            // this wave's tile-local origin
   if (parked) {
     P.C = sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS;
@@ -1388,8 +1392,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold stale lines of the slot (an earlier launch's sums)
-    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;
+    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;      // read with sc1 loads (written with sc1 stores): no fences
   }
 
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
@@ -1454,6 +1457,27 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     // inside the (tile-uniform) branches hipcc has to reconcile 256 AGPR assignments at every join, through VGPRs and scratch
     if constexpr (i < 7) { if (mb + 16 < M) put(std::integral_constant<int, i + 1>{}); }
     __builtin_amdgcn_sched_barrier(0);
+    if (partner) {
+      // split owner: the other half's sums of this block are added INTO the patch, row layout (two 16-B sc1 loads per lane and four-row
+      // pass), before any epilogue path reads it -- one place for all paths (the V^T path reads the patch by columns: per-element
+      // partner loads there cost 256 four-byte loads per lane and tile, the q/k/v launch went from 136 to 203 us)
+      f32x4 pa[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const size_t po = (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
+        pa[t][0] = pld4(po); pa[t][1] = pld4(po + 4);
+      }
+      float* pw = patch + (i & 1) * (16 * G4_PLD);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float* q_ = pw + (t * 4 + (lane >> 4)) * G4_PLD + c8;
+        f32x4 v0 = *(const f32x4*)q_, v1 = *(const f32x4*)(q_ + 4);
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += pa[t][0][c_]; v1[c_] += pa[t][1][c_]; }
+        *(f32x4*)q_ = v0; *(f32x4*)(q_ + 4) = v1;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (qkv_tile) {
       const int D = P.qkv_d, L = P.rows_per_batch, H = D >> 7;
       const int gm = m_base + mb, b = gm / L, p0 = gm - b * L;           // (M and L are multiples of 32: a 16-row block is whole, in one batch)
@@ -1467,7 +1491,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const int rk = qkv_vt_interleave(gk * 8 + k), dk = t * 32 + (lane >> 1);
-            e[t][k] = pt[rk * G4_PLD + dk] + (partner ? partner[(size_t)(lm0 + i * 16 + rk) * 256 + ln0 + dk] : 0.f);
+            e[t][k] = pt[rk * G4_PLD + dk];
           }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1490,15 +1514,6 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         for (int t = 0; t < 4; ++t) {
           const int row = t * 4 + (lane >> 4);
           pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
-        }
-        if (partner) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float* pp = partner + (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
-            const f32x4 a = *(const f32x4*)pp, b2 = *(const f32x4*)(pp + 4);
-#pragma unroll
-            for (int c_ = 0; c_ < 4; ++c_) { pv[t][0][c_] += a[c_]; pv[t][1][c_] += b2[c_]; }
-          }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1533,15 +1548,6 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         const int row = t * 4 + (lane >> 4);
         pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
       }
-      if (partner) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float* pp = partner + (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
-          const f32x4 a = *(const f32x4*)pp, b2 = *(const f32x4*)(pp + 4);
-#pragma unroll
-          for (int c_ = 0; c_ < 4; ++c_) { pv[t][0][c_] += a[c_]; pv[t][1][c_] += b2[c_]; }
-        }
-      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = t * 4 + (lane >> 4), m = mb + row;
@@ -1558,14 +1564,6 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       f32x4 pv[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) pv[t] = *(const f32x4*)(pt + (t * 2 + (lane >> 5)) * G4_PLD + c4);
-      if (partner) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const f32x4 a = *(const f32x4*)(partner + (size_t)(lm0 + i * 16 + t * 2 + (lane >> 5)) * 256 + ln0 + c4);
-#pragma unroll
-          for (int c_ = 0; c_ < 4; ++c_) pv[t][c_] += a[c_];
-        }
-      }
       if (epi == LX_EPI_RESID_F32) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1590,7 +1588,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
             }
             v = o;
           }
-          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
+          if (parked)      // agent-scope write-through: the owner reads it with sc1 loads, no cache maintenance on either side
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                   lx_make_rsrc(P.C), (int)(((size_t)m * 256 + ncol) * 4), 0, PAIR_AUX_SC1);
+          else *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
         }
       }
     }
@@ -1598,14 +1599,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   if (mw0 < M) put(std::integral_constant<int, 0>{});
   block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
   block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{}); block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
-  if (parked) {                                        // publish: stores done, L2 written back at agent scope, then the flag
+  if (parked) {                                        // publish: every wave's sc1 stores acknowledged, then the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G4_STAMP(5)
@@ -1624,7 +1621,7 @@ static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64
 struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 0)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1821,9 +1818,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     }
     const long rounds = (t256 + NCU - 1) / NCU;
     const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
-    // split form (LX_GEMM4_SK = 0 default | 1 on; measured on the step's shapes in round 3: fused projection 284 vs 277 us for the 8-wave
-    // mixed plan, q/k/v 140 vs 126, ff2 159 vs 157 and proj_out 190 vs 193 for the pair kernel, 1.003 vs 1.020 images/s end to end -- the
-    // release / acquire round trip and the owner's exposed partner loads cost what the shorter tail saves): the tiles of a partial last round, or all tiles of a launch with <= 128 of them and
+    // split form (LX_GEMM4_SK = 1 default | 0 off): the tiles of a partial last round, or all tiles of a launch with <= 128 of them and
     // a long K, by two workgroups each (half of K), meeting through the caller's workspace. One K for the whole launch, >= 16 K tiles.
     bool uniform_k4 = true;
     for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
@@ -1831,7 +1826,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && problems[0].K / BK >= 16 &&
                            tail > 0 && tail * 2 <= 256 && rounds < 8;
     const bool split_all = can_split && full == 0 && problems[0].K / BK >= env.pair_min_kt;      // (the pair kernel's shapes)
-    const bool split_tail = can_split && full > 0;
+    const bool split_tail = can_split && full > 0 && tail * 3 <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
     if (ok && (fills || split_all || split_tail)) {
       GemmArgs all;
       all.n = 0;

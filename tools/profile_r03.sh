@@ -2,7 +2,7 @@
 # the default bench line (headline + secondary legs), rocprofv3 kernel stats + PMC passes of the headline workload, kernel stats of
 # the precise and fp8-attention modes, the CS3/DGF batch; leaves only text / json summaries under gpurun_out/prof_<tag>
 set -x
-TAG=${1:-r03zz}
+TAG=${1:-r03fin}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
