@@ -13,10 +13,10 @@ def per_dispatch(path, counter):
     c = sqlite3.connect(path)
     tot, n, by = 0.0, 0, {}
     for name, v in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
-        if "lx_gemm_" not in name:
+        if "lx_gemm" not in name:              # lx_gemm_kernel<..>, lx_gemm_mixed / _pair / _split / _fp8 kernels, lx_gemm4_kernel
             continue
         tot += v; n += 1
-        k = re.search(r"lx_gemm_\w+(<[^>]*>)?", name).group(0)
+        k = re.search(r"lx_gemm\w+(<[^>]*>)?", name).group(0)
         a = by.setdefault(k, [0.0, 0]); a[0] += v; a[1] += 1
     return tot, n, {k: round(v[0] / v[1], 1) for k, v in by.items()}
 
