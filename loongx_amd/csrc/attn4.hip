@@ -1,0 +1,540 @@
+// attn4.hip -- lx_attn4_kernel: the joint attention of attn.hip (same contract, same K / V^T images, same bounded-score softmax) with
+// ONE wave per SIMD. Replaces F.scaled_dot_product_attention + the mask / c_factor bias of attn_forward (src/flux/block.py:101-135)
+// wherever the caller passes LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED (the engine's default for bf16 attention).
+//
+// Why another shape: in the 8-wave kernel every wave reads the whole 32-KiB K / V^T tile from LDS for its 32 query
+// rows -- one 1-KiB fragment per MFMA, 16-28 % of the launch by elimination -- and the two waves of a SIMD add their issue streams. Here
+// a workgroup is 4 waves x 64 query rows (two 32-row blocks per wave): every K / V^T fragment feeds TWO MFMAs, half the waves issue
+// LDS-DMA, and a wave owns its SIMD's 512 registers: O^T (2 x 4 x 16) and the Q fragments (2 x 8 x 4) live in AGPRs; ONE score set
+// (2 x 2 x 16), the P words (2 x 4 x 4) and a four-deep fragment ring in the architectural VGPRs. The matrix instructions and the
+// softmax are inline asm in a fixed order (one fragment "slot" = wait, MFMA, vector fillers, MFMA, the ds_read for four slots ahead,
+// fillers); hipcc allocates registers and emits the scalar code, the LDS-DMA pieces and the epilogue. The loop body is NOT expanded:
+// with one copy of the body every value has one live range around the loop and hipcc's allocator has nothing to split (a first version
+// with two score sets and a body expanded six times for immediate ring offsets spilled 962 registers; pinning its operands to physical
+// registers turned the accumulators into VGPR-class values and spilled 1481).
+//
+// One frame T of the loop = 32 slots = 64 MFMAs = a modulo schedule over three tiles (the 64 keys of a tile are two 32-key blocks
+// kb = 0 / 1 whose scores live in separate registers, and four 16-key slices s = 0..3 for P.V; slices 0, 1 belong to kb 0):
+//   slots  0-1   P.V slice 2 of tile T-1, d blocks 2, 3        vector stream (160 instructions per frame, in order):
+//   slots  2-5   P.V slice 3 of tile T-1                          softmax slices 0, 1, 2, 3 of tile T = per lane 16 exp2, 16 row-sum adds and
+//   slots  6-13  scores of tile T, key block 1                    8 cvt_pk each; slices 0, 1 read the kb-0 scores (complete since slot 29 of the
+//   slots 14-17  P.V slice 0 of tile T                            previous frame, overwritten from slot 22 on), slices 2, 3 the kb-1 scores
+//   slots 18-21  P.V slice 1 of tile T                            (complete at slot 13, overwritten from slot 6 of the next frame)
+//   slots 22-29  scores of tile T+1, key block 0
+//   slots 30-31  P.V slice 2 of tile T, d blocks 0, 1
+// K and V^T tiles sit in two three-deep rings (96 KiB): in frame T the kb-1 half of K(T), K(T+1), V^T(T-1) and V^T(T) are read, K(T+2)
+// is staged behind the frame's barrier (slot 8; four 1-KiB LDS-DMA pieces per wave) and V^T(T+1) in slots 24-27; both are waited for at
+// slot 8 of the NEXT frame, so staging latency is never exposed. Ring positions are run-time: the eight K and four V^T fragment
+// addresses move by one position per frame (twelve v_add).
+//
+// Hazards the assembler does not see (inline asm is opaque to hipcc's hazard recogniser; gfx940-class rules):
+//   MFMA result -> VALU read (11 wait states for an 8-pass MFMA): kb-0 scores are complete at slot 29 and first read in slot 0 of the next
+//     frame, kb-1 scores complete at slot 13 and first read in slot 16 (static_asserts below): two slots = at least 14 instructions.
+//   v_exp_f32 result -> the next VALU (trans forwarding, 1 wait state): the stream is [exp e(u), exp o(u), add e(u-1), add o(u-1),
+//     cvt(u-1)]: nothing reads an exp2 result in the instruction after it.
+//   MFMA result in AGPRs -> v_accvgpr_read (epilogue): s_nop 15 + s_nop 7 behind the loop.
+#include "attn_common.h"
+
+namespace {
+
+constexpr int A4_KV = 16384;                 // one K tile [64 keys][128 d] or one V^T tile [128 d][64 keys], bf16
+constexpr int A4_VB = 3 * A4_KV;             // the V^T ring starts behind the K ring
+constexpr int A4_LDS = 6 * A4_KV;            // 96 KiB
+static_assert(A4_LDS <= 160 * 1024, "LDS budget");
+
+// ---- the frame's schedule (compile-time tables) ----
+// slot -> matrix work: kind 0 = score fragment (ks = f, key block kb), kind 1 = P.V fragment f = s * 4 + db
+constexpr int a4_kind(int i) { return (i >= 6 && i < 14) || (i >= 22 && i < 30) ? 0 : 1; }
+constexpr int a4_kb(int i) { return i < 14 ? 1 : 0; }                                       // score slots: key block
+constexpr int a4_ks(int i) { return (i < 14 ? i - 6 : i - 22) & 7; }                        // score slots: 16-wide d step
+constexpr int a4_pvf(int i) { return (i < 6 ? 10 + i : i < 22 ? i - 14 : i - 22) & 15; }    // P.V slots: 0-1 -> 10, 11; 2-5 -> 12..15; 14-21 -> 0..7; 30-31 -> 8, 9
+// Row sums. LX_A4_LSUM 1 (default): on the matrix pipe -- behind the last P.V MFMA of a slice one more MFMA per query block multiplies the
+// slice's P^T fragment by an all-ones A fragment: every accumulator register of a lane then holds sum_k P[q, k] of the ROUNDED
+// probabilities (the values P.V sees), summed over both half-waves' keys: 8 MFMAs per frame instead of 64 v_add_f32. The frame is bound by
+// instruction ISSUE (a v_add ~6 cycles, an exp2 ~11, a ds_read_b128 ~16, an LDS-DMA piece ~60 against 32 per MFMA), not by the matrix
+// pipe (64 of ~110 cycles per slot busy): the eight MFMAs are the cheaper way. 0: v_add_f32 per probability (A/B).
+#ifndef LX_A4_LSUM
+#define LX_A4_LSUM 0
+#endif
+constexpr int A4_SL = LX_A4_LSUM ? 24 : 40;      // vector instructions per 16-key slice (both query blocks)
+// vector instructions per slot. LX_A4_SCHED 0: the same number in every slot; 1 (default): none in the eight slots that carry an LDS-DMA piece
+#ifndef LX_A4_SCHED
+#define LX_A4_SCHED 1
+#endif
+constexpr int a4_nslot(int i) {
+#if LX_A4_SCHED == 0
+  return A4_SL / 8;
+#elif LX_A4_LSUM
+  return (i >= 8 && i < 12) || (i >= 24 && i < 28) ? 0 : 4;
+#else
+  constexpr int n[32] = {7, 7, 6, 7, 7, 6, 7, 6, 0, 0, 0, 0, 7, 7, 7, 6, 7, 7, 6, 7, 7, 6, 7, 6, 0, 0, 0, 0, 7, 7, 7, 6};
+  return n[i];
+#endif
+}
+constexpr int a4_ngap(int g) { return (g & 1) ? a4_nslot(g >> 1) / 2 : (a4_nslot(g >> 1) + 1) / 2; }   // gap 2i: behind the slot's first MFMA
+constexpr int a4_pos(int g) { int p = 0; for (int k = 0; k < g; ++k) p += a4_ngap(k); return p; }      // stream position at the start of gap g (0..64)
+static_assert(a4_pos(64) == 4 * A4_SL, "four slices of vector instructions per frame");
+static_assert(a4_pos(28) >= A4_SL && a4_pos(36) >= 2 * A4_SL && a4_pos(60) >= 3 * A4_SL, "a slice's P words are complete before its P.V slots (14, 18, 30)");
+static_assert(a4_pos(32) <= 2 * A4_SL, "slices 2, 3 read the kb-1 scores: not before slot 16 (complete at slot 13 + 11 wait states)");
+static_assert(a4_pos(44) >= 2 * A4_SL, "slices 0, 1 read the kb-0 scores: done before slot 22 overwrites them");
+static_assert(a4_pos(12) <= 3 * A4_SL && a4_pos(4) <= 2 * A4_SL, "P words of slices 2 / 3 are rewritten only after the previous tile's P.V slots 0-1 / 2-5");
+// The softmax of one 16-key slice is a stream of vector instructions over 8 pair units u = pair * 2 + query block:
+//   LSUM 0:  exp2 e(0), o(0) | for u = 1..7: exp2 e(u), exp2 o(u), add e(u-1), add o(u-1), cvt_pk(u-1) | add e(7), add o(7), cvt_pk(7)    (40)
+//   LSUM 1:  exp2 e(0), o(0) | for u = 1..7: exp2 e(u), exp2 o(u), cvt_pk(u-1)                          | cvt_pk(7)                        (24)
+// kind: 0 exp2, 1 add, 2 cvt_pk
+#if LX_A4_LSUM
+constexpr int a4_op_kind(int n) { return n < 2 ? 0 : n == 23 ? 2 : ((n - 2) % 3 < 2 ? 0 : 2); }
+constexpr int a4_op_unit(int n) { return n < 2 ? 0 : n == 23 ? 7 : ((n - 2) % 3 < 2 ? (n - 2) / 3 + 1 : (n - 2) / 3); }
+constexpr int a4_op_half(int n) { return n < 2 ? n : n == 23 ? 0 : ((n - 2) % 3 < 2 ? (n - 2) % 3 : 0); }
+#else
+constexpr int a4_op_kind(int n) { return n < 2 ? 0 : n >= 37 ? (n == 39 ? 2 : 1) : ((n - 2) % 5 < 2 ? 0 : (n - 2) % 5 < 4 ? 1 : 2); }
+constexpr int a4_op_unit(int n) { return n < 2 ? 0 : n >= 37 ? 7 : ((n - 2) % 5 < 2 ? (n - 2) / 5 + 1 : (n - 2) / 5); }
+constexpr int a4_op_half(int n) { return n < 2 ? n : n >= 37 ? (n - 37) & 1 : ((n - 2) % 5 < 2 ? (n - 2) % 5 : ((n - 2) % 5 - 2) & 1); }
+#endif
+// Fragment ring: LX_A4_LOOK reads in flight (4 or 8: it has to divide 32); LX_A4_WAIT2: one s_waitcnt per TWO slots (even slots wait for their own
+// fragment and the next one)
+#ifndef LX_A4_LOOK
+#define LX_A4_LOOK 4
+#endif
+#ifndef LX_A4_WAIT2
+#define LX_A4_WAIT2 0
+#endif
+constexpr int A4_LOOK = LX_A4_LOOK;
+static_assert(A4_LOOK == 4 || A4_LOOK == 8, "ring depth");
+// lgkmcnt for position i of a fragment sequence of n_seq reads (-1: no wait here): min(LOOK, n_seq - i) reads are outstanding in front of it
+constexpr int a4_wait(int i, int n_seq) {
+  const int out = n_seq - i < A4_LOOK ? n_seq - i : A4_LOOK;
+  if (LX_A4_WAIT2) return (i & 1) ? -1 : (out - 2 < 0 ? 0 : out - 2);
+  return out - 1;
+}
+// LDS-DMA pieces: K(T+2) pieces 0-3 behind slots 8-11 (right behind the barrier), V^T(T+1) pieces 0-3 behind slots 24-27
+constexpr int a4_kpiece(int i) { return i >= 8 && i < 12 ? i - 8 : -1; }
+constexpr int a4_vpiece(int i) { return i >= 24 && i < 28 ? i - 24 : -1; }
+
+template <int MODE>   // 1: p = exp2(s)   2: p = exp2(s + bias): the bias of the (query, key) segment pair is the srcC of the first score MFMA
+__global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int QBLK = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[A4_LDS];
+  const lx_attn_desc& D = args.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int BH = D.B * D.H;
+  const int bh = blockIdx.x % BH;
+  const int qt = blockIdx.x / BH;
+  const int b = bh / D.H, h = bh % D.H;
+  int sq = 0;
+#pragma unroll
+  for (int s = 1; s < 3; ++s)
+    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
+  // descriptor fields -> scalars, once (a kernarg array indexed with the running segment inside the loop is a dependent s_load)
+  const int n_seg = D.n_seg;
+  const int len0 = D.seg_len[0], len1 = D.seg_len[1], len2 = D.seg_len[2];
+  const int row00 = D.seg_row0[0], row01 = D.seg_row0[1], row02 = D.seg_row0[2];
+  const int vt00 = D.seg_vt0[0], vt01 = D.seg_vt0[1], vt02 = D.seg_vt0[2];
+  const float bia0 = D.bias[sq][0], bia1 = D.bias[sq][1], bia2 = D.bias[sq][2];
+  auto pick = [](int s, auto x0, auto x1, auto x2) { return s == 0 ? x0 : (s == 1 ? x1 : x2); };
+  auto seg_len = [&](int s) { return pick(s, len0, len1, len2); };
+  const int q_len = seg_len(sq);
+  const int q_seg_row0 = pick(sq, row00, row01, row02);
+  const int q0_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 64 + l31;       // query block qb: + 32 * qb
+
+  // ---- Q fragments (AGPRs): lane (q = l31, half = lhi) of block qb holds d = ks*16 + lhi*8 .. +8 ----
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const size_t q_row = (size_t)q_seg_row0 + (size_t)b * q_len + min(q0_in_seg + 32 * qb, q_len - 1);
+    const __bf16* qp = (const __bf16*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  f32x16 oacc[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // LSUM 0: per lane, its own 32 probabilities per tile [query block][even / odd value]
+#if LX_A4_LSUM
+  f32x16 lacc[2];                                   // LSUM 1: every register = the row's sum (AGPRs)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
+  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
+  asm volatile("" : "+v"(ones_frag));
+#endif
+
+  // ---- staging: piece j (0..3) of this wave = 1 KiB = K rows (j*4 + wave)*4 .. +4 (256 B each) / V^T rows (j*4 + wave)*8 .. +8 (128 B) ----
+  const int ldk = D.ldk, vt_ld = D.vt_ld;
+  const lx_rsrc_t rs_k = lx_make_rsrc((const __bf16*)D.K + D.k_col + h * DH);
+  const lx_rsrc_t rs_v = lx_make_rsrc((const __bf16*)D.VT + (size_t)bh * DH * vt_ld);
+  uint32_t k_off[4], v_off[4];
+  uint32_t k_slot_off;
+  {
+    const int key0 = wave * 4 + (lane >> 4);                   // + 16 j
+    k_slot_off = (uint32_t)((((lane & 15) ^ (key0 & 15)) * 8) * 2);
+    const int drow0 = wave * 8 + (lane >> 3);                  // + 32 j: (drow >> 1) & 7 does not depend on j
+    const uint32_t v_slot_off = (uint32_t)((((lane & 7) ^ ((drow0 >> 1) & 7)) * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k_off[j] = (uint32_t)((key0 + 16 * j) * ldk * 2) + k_slot_off;
+      v_off[j] = (uint32_t)((drow0 + 32 * j) * vt_ld * 2) + v_slot_off;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(k_off[j]), "+v"(v_off[j]));   // (kept in registers: rematerialised they are the multiplies again)
+  // K rows are clamped to the tile's last valid key (ragged segment tails; a tile that does not exist is staged from row 0 of the
+  // previous one and never used): min(row, clamp) * ld + slot = min(row * ld + slot, clamp * ld + slot). ring_off: byte offset of the
+  // ring position (0, 16384, 32768)
+  const int piece_lds = wave * 1024;
+  auto kpiece = [&](int j, int ring_off, int krow, int nclamp) {
+    const uint32_t off_ = min(k_off[j], (uint32_t)((nclamp - 1) * ldk * 2) + k_slot_off);
+    lx_buf_to_lds(rs_k, (lptr_t)(smem + ring_off + piece_lds + j * 4096), off_, krow * ldk * 2);
+  };
+  auto vpiece = [&](int j, int ring_off, int vpos) {
+    lx_buf_to_lds(rs_v, (lptr_t)(smem + A4_VB + ring_off + piece_lds + j * 4096), v_off[j], vpos * 2);
+  };
+
+  // ---- wave-uniform KV-tile descriptors, handed down a three-deep FIFO: tile T (mask), T+1 (bias of its scores, V^T staging), T+2 (K staging).
+  // The key segments this query segment attends to are packed into up to three "runs" once; the generator's common step is three scalar
+  // adds and a min, a run switch is a rare branch. ----
+  struct Tile { int krow, vpos, nvalid, nclamp; float bl; };   // first key row, first V^T column, keys in the tile (0 = none), staging clamp (>= 1), bias * log2 e
+  int rk0 = 0, rk1 = 0, rk2 = 0, rv0 = 0, rv1 = 0, rv2 = 0, rl0 = 0, rl1 = 0, rl2 = 0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
+  int n_runs = 0;
+#pragma unroll
+  for (int sg = 0; sg < 3; ++sg) {
+    const float bi = pick(sg, bia0, bia1, bia2);
+    if (sg < n_seg && bi > -1e37f) {
+      const int ln = seg_len(sg), kr = pick(sg, row00, row01, row02) + b * ln, vp = pick(sg, vt00, vt01, vt02);
+      const float bl = bi * 1.4426950408889634f;
+      if (n_runs == 0) { rk0 = kr; rv0 = vp; rl0 = ln; rb0 = bl; }
+      else if (n_runs == 1) { rk1 = kr; rv1 = vp; rl1 = ln; rb1 = bl; }
+      else { rk2 = kr; rv2 = vp; rl2 = ln; rb2 = bl; }
+      ++n_runs;
+    }
+  }
+  int g_run = -1, g_left = 0;
+  Tile g_cur = {0, 0, 0, 1, 0.f};
+  auto gen_next = [&]() {
+    if (__builtin_expect(g_left > 0, 1)) {
+      g_cur.krow += KVBLK; g_cur.vpos += KVBLK;
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      ++g_run;
+      if (g_run >= n_runs) { g_run = n_runs; g_cur.nvalid = 0; g_cur.nclamp = 1; g_left = 0; return; }   // krow / vpos stay on the last real tile
+      g_left = pick(g_run, rl0, rl1, rl2);
+      g_cur.krow = pick(g_run, rk0, rk1, rk2);
+      g_cur.vpos = pick(g_run, rv0, rv1, rv2);
+      g_cur.bl = pick(g_run, rb0, rb1, rb2);
+    }
+    g_cur.nvalid = min(g_left, KVBLK);
+    g_cur.nclamp = g_cur.nvalid;
+    g_left -= g_cur.nvalid;
+  };
+  gen_next(); Tile T0 = g_cur;
+  gen_next(); Tile T1 = g_cur;
+  gen_next(); Tile T2 = g_cur;
+
+  // ---- fragment addresses: K 16-B slot ((2ks + lhi) ^ (key & 15)), V^T slot ((2s + lhi) ^ ((d >> 1) & 7)); key block / d block are immediates,
+  // the ring position is part of the register: kaddr points at ring position 0 (K(0)), vaddr at position 2 (the stand-in for "V^T(-1)") ----
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  uint32_t kaddr[8], vaddr[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds0 + l31 * 256 + (((2 * ks + lhi) ^ (l31 & 15)) * 16);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) vaddr[s] = lds0 + A4_VB + 2 * A4_KV + l31 * 128 + (((2 * s + lhi) ^ ((l31 >> 1) & 7)) * 16);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(kaddr[ks]));
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(vaddr[s]));
+
+  bf16x8 ring[A4_LOOK];
+  u32x4 pw[2][4];              // [query block][slice]: the slice's P^T fragment (8 bf16 per lane)
+  f32x16 sc[2][2];             // [query block][key block]
+  float pv[2][2];              // exp2 results in flight: [unit parity][even / odd value]
+  f32x16 offv;                 // MODE 2: bias * log2 e of the tile whose scores are computed next, in all 16 registers
+  float off_cur = T0.bl;
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offv[r] = off_cur;
+  }
+  // "tile -1": P = 0 against a copy of V^T(0) (finite values: 0 x finite = 0; LDS garbage could hold NaN patterns)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { pw[qb][2] = u32x4{0, 0, 0, 0}; pw[qb][3] = u32x4{0, 0, 0, 0}; }
+#ifdef LX_A4_ELIM_VALU
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { pw[qb][0] = u32x4{1, 1, 1, 1}; pw[qb][1] = u32x4{1, 1, 1, 1}; pv[qb][0] = pv[qb][1] = 0.f; }
+#endif
+
+#define A4_SB() __builtin_amdgcn_sched_barrier(0)
+  // LX_A4_ELIM_*: timing experiments only (WRONG numbers): what one class of instructions costs the stream -- DSR the fragment reads, DMA the
+  // LDS-DMA pieces, VALU the softmax stream, BAR the frame barrier, ADDR the twelve ring-position adds (tools/run_a4_elim.sh)
+#ifdef LX_A4_RING_AGPR       /* the fragment ring in AGPRs (MFMA A operands may be AGPRs; ds_read can target them) */
+#define A4_RC "a"
+#else
+#define A4_RC "v"
+#endif
+#ifdef LX_A4_ELIM_DSR
+#define A4_DSR(dst, addr, offs) asm volatile("" : "+" A4_RC(dst) : "v"(addr)); A4_SB()
+#elif defined(LX_A4_ELIM_DSR_HALF)
+#define A4_DSR(dst, addr, offs) if constexpr (((offs) / 4096) & 1) asm volatile("" : "+" A4_RC(dst) : "v"(addr)); else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" A4_RC(dst) : "v"(addr), "n"(offs)); A4_SB()
+#else
+#define A4_DSR(dst, addr, offs) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" A4_RC(dst) : "v"(addr), "n"(offs)); A4_SB()
+#endif
+#define A4_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); A4_SB()
+  // the fragment read for slot j (j >= 32: slots 0-3 of the next frame, P.V fragments)
+#define A4_RD(j)                                                                                                       \
+  {                                                                                                                    \
+    constexpr int j_ = (j) & 31;                                                                                       \
+    if constexpr (a4_kind(j_) == 0) { A4_DSR(ring[j_ % A4_LOOK], kaddr[a4_ks(j_)], a4_kb(j_) * 8192); }                \
+    else { A4_DSR(ring[j_ % A4_LOOK], vaddr[a4_pvf(j_) >> 2], (a4_pvf(j_) & 3) * 4096); }                              \
+  }
+  // an MFMA statement, with the wait for its fragment in front of it in the SAME statement when WN >= 0 (an asm that DEFINES the ring
+  // register right in front of the asm that reads it makes hipcc put an s_nop between them: "assume inline asm has dst forwarding hazard")
+#ifdef LX_A4_ELIM_WAIT
+#define A4_WN(WN) -1
+#else
+#define A4_WN(WN) (WN)
+#endif
+#define A4_ASMW(WN, TEXT, OUT, ...)                                                                                    \
+  if constexpr (A4_WN(WN) >= 0) asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" TEXT : OUT : __VA_ARGS__, [w] "n"((WN) < 0 ? 0 : (WN)) : "memory"); \
+  else asm volatile(TEXT : OUT : __VA_ARGS__ : "memory")
+#define A4_MMQ(ks, kb, qb, R, WN)                                                                                      \
+  {                                                                                                                    \
+    if constexpr ((ks) == 0) {                                                                                         \
+      if constexpr (MODE == 2) { A4_ASMW(WN, "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3", "=&v"(sc[qb][kb]), A4_RC(ring[R]), "a"(qf[qb][0]), "v"(offv)); } \
+      else { A4_ASMW(WN, "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0", "=&v"(sc[qb][kb]), A4_RC(ring[R]), "a"(qf[qb][0])); } \
+    } else { A4_ASMW(WN, "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0", "+v"(sc[qb][kb]), A4_RC(ring[R]), "a"(qf[qb][ks])); } \
+    A4_SB();                                                                                                           \
+  }
+#define A4_MMP(f, qb, R, WN)                                                                                           \
+  {                                                                                                                    \
+    A4_ASMW(WN, "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0", "+a"(oacc[qb][(f) & 3]), A4_RC(ring[R]), "v"(pw[qb][(f) >> 2])); \
+    A4_SB();                                                                                                           \
+  }
+#define A4_MM(i, qb, WN)                                                                                               \
+  if constexpr (a4_kind(i) == 0) { A4_MMQ(a4_ks(i), a4_kb(i), qb, (i) % A4_LOOK, WN) } else { A4_MMP(a4_pvf(i), qb, (i) % A4_LOOK, WN) }
+  // vector stream position n (0..159): slice s = n / 40; value j = 2 * pair + half of query block qb is score register 8 * (s & 1) + j of sc[qb][s >> 1]
+#ifdef LX_A4_ELIM_EXP
+#define A4_EXP_OP "v_mov_b32"
+#else
+#define A4_EXP_OP "v_exp_f32"
+#endif
+#ifdef LX_A4_ELIM_ADD
+#define A4_ADD_OP(l, p) asm volatile("" : "+v"(l) : "v"(p));
+#else
+#define A4_ADD_OP(l, p) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l) : "v"(p));
+#endif
+#ifdef LX_A4_ELIM_CVT
+#define A4_CVT_OP(dst, e, o) asm volatile("" : "+v"(dst) : "v"(e), "v"(o))
+#else
+#define A4_CVT_OP(dst, e, o) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dst) : "v"(e), "v"(o))
+#endif
+#define A4_OP(n)                                                                                                       \
+  {                                                                                                                    \
+    constexpr int s_ = (n) / A4_SL, m_ = (n) % A4_SL, u_ = a4_op_unit(m_), hf_ = a4_op_half(m_), qb_ = u_ & 1, pr_ = u_ >> 1; \
+    if constexpr (a4_op_kind(m_) == 0) asm volatile(A4_EXP_OP " %0, %1" : "=v"(pv[u_ & 1][hf_]) : "v"(sc[qb_][s_ >> 1][8 * (s_ & 1) + 2 * pr_ + hf_])); \
+    else if constexpr (a4_op_kind(m_) == 1) { A4_ADD_OP(lsum[qb_][hf_], pv[u_ & 1][hf_]) }                             \
+    else A4_CVT_OP(pw[qb_][s_][pr_], pv[u_ & 1][0], pv[u_ & 1][1]);                                                    \
+  }
+#define A4_OPK(g, k) if constexpr ((k) < a4_ngap(g)) A4_OP((a4_pos(g) + (k)) % (4 * A4_SL))
+#ifdef LX_A4_ELIM_VALU
+#define A4_VALU(g)
+#else
+#define A4_VALU(g) { A4_OPK(g, 0) A4_OPK(g, 1) A4_OPK(g, 2) A4_OPK(g, 3) } A4_SB();
+#endif
+  // One slot. DRAIN: the matrix work of slots 0-5 only (the last tile's P.V slices 2b, 3 behind the loop)
+#ifdef LX_A4_ELIM_BAR
+#define A4_FRAME_BARRIER()
+#else
+#define A4_FRAME_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef LX_A4_ELIM_DMA
+#define A4_KPIECE(j, pos, krow, nclamp)
+#define A4_VPIECE(j, pos, vpos)
+#else
+#define A4_KPIECE(j, pos, krow, nclamp) kpiece(j, pos, krow, nclamp)
+#define A4_VPIECE(j, pos, vpos) vpiece(j, pos, vpos)
+#endif
+#ifdef LX_A4_ELIM_ADDR
+#define A4_ADDR_STEP(reg, d)
+#else
+#define A4_ADDR_STEP(reg, d) reg += d; asm volatile("" : "+v"(reg))
+#endif
+#define A4_SLOT(i, DRAIN)                                                                                              \
+  if constexpr (!(DRAIN)) {                                                                                            \
+    if constexpr ((i) == 8) {       /* pieces of the previous frame landed (this wave, then every wave); every wave is done with K(T-1), V^T(T-2) */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); A4_SB();                                                        \
+      A4_FRAME_BARRIER(); A4_SB();                                                                                     \
+    }                                                                                                                  \
+    if constexpr ((i) == 16) {      /* ragged last tile of a segment, key block 1 (complete since slot 13): keys past the end get p = exp2(-1e30) = 0 */ \
+      if (T0.nvalid < KVBLK) {                                                                                         \
+        A4_SB();                                                                                                       \
+        int lh4_ = 4 * lhi;                                                                                            \
+        LX_PIN_IN_BRANCH(lh4_);                                                                                        \
+        _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) _Pragma("unroll") for (int r = 0; r < 16; ++r)                \
+          if (lh4_ + 32 + 8 * (r >> 2) + (r & 3) >= T0.nvalid) sc[qb][1][r] = -1e30f;                                  \
+      }                                                                                                                \
+      A4_SB();                                                                                                         \
+    }                                                                                                                  \
+    if constexpr ((i) == 20 && MODE == 2) {      /* slot 22 starts the scores of tile T+1 from ITS bias */              \
+      if (T1.bl != off_cur) {                                                                                          \
+        A4_SB();                                                                                                       \
+        off_cur = T1.bl;                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) offv[r] = off_cur;                                              \
+        asm volatile("" : "+v"(offv));                                                                                 \
+      }                                                                                                                \
+      A4_SB();                                                                                                         \
+    }                                                                                                                  \
+  }                                                                                                                    \
+  A4_MM(i, 0, (DRAIN) ? a4_wait(i, A4_LOOK == 4 ? 6 : 8) : a4_wait((i) & 1, 64))     /* (steady state: LOOK reads outstanding at every slot; a4_wait(0 / 1, .) by parity) */ \
+  if constexpr (!(DRAIN)) { A4_VALU(2 * (i)) }                                                                         \
+  A4_MM(i, 1, -1)                                                                                                      \
+  if constexpr (!(DRAIN) || (i) + A4_LOOK < 6) { A4_RD((i) + A4_LOOK) }                                                \
+  if constexpr (LX_A4_LSUM && a4_kind(i) == 1 && (a4_pvf(i) & 3) == 3) {      /* the slice's row sums */                \
+    A4_LSUM_MM(a4_pvf(i) >> 2, 0) A4_LSUM_MM(a4_pvf(i) >> 2, 1)                                                        \
+  }                                                                                                                    \
+  if constexpr (!(DRAIN)) {                                                                                            \
+    A4_VALU(2 * (i) + 1)                                                                                               \
+    if constexpr ((i) >= 2 && (i) < 6) { A4_ADDR_STEP(vaddr[((i) - 2) & 3], dv); A4_SB(); }     /* V^T reads move on to ring position T (the reads of slots <= 5 are issued by slot 1) */ \
+    if constexpr ((i) >= 10 && (i) < 18) { A4_ADDR_STEP(kaddr[((i) - 10) & 7], dk); A4_SB(); } /* K reads move on to position T+1 (the kb-1 reads of K(T) are issued by slot 9) */ \
+    if constexpr (a4_kpiece(i) >= 0) { A4_KPIECE(a4_kpiece(i) & 3, pos_prev, T2.krow, T2.nclamp); A4_SB(); }              \
+    if constexpr (a4_vpiece(i) >= 0) { A4_VPIECE(a4_vpiece(i) & 3, pos_next, T1.vpos); A4_SB(); }                         \
+    if constexpr ((i) == 27) { T0 = T1; T1 = T2; A4_SB(); }     /* (nothing reads T1 / T2 behind the V^T pieces: the scalar bookkeeping sits under queued MFMAs) */ \
+    if constexpr ((i) == 28) { gen_next(); T2 = g_cur; A4_SB(); }                                                      \
+  }
+#if LX_A4_LSUM
+#define A4_LSUM_MM(sl, qb) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones_frag), "v"(pw[qb][sl])); A4_SB();
+#else
+#define A4_LSUM_MM(sl, qb)
+#endif
+#define A4_SLOT4(i, DRAIN) A4_SLOT(i, DRAIN) A4_SLOT((i) + 1, DRAIN) A4_SLOT((i) + 2, DRAIN) A4_SLOT((i) + 3, DRAIN)
+
+  // ---- prologue: K(0) -> position 0, V^T(0) -> positions 2 (as "V^T(-1)") and 0, K(1) -> position 1; kb-0 scores of tile 0 ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kpiece(j, 0, T0.krow, T0.nclamp);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vpiece(j, 2 * A4_KV, T0.vpos);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vpiece(j, 0, T0.vpos);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kpiece(j, A4_KV, T1.krow, T1.nclamp);
+  A4_SB();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // Q and K(0)
+  A4_SB();
+  __builtin_amdgcn_s_barrier();
+  A4_SB();
+  // (the Q fragments pass through an empty asm so that their loads are complete -- hipcc's own waits -- before the asm MFMAs read them)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[qb][ks]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  A4_SB();
+#define A4_PRD(ks) A4_DSR(ring[(ks) % A4_LOOK], kaddr[ks], 0)
+#define A4_PG(ks)                                                                                                      \
+  A4_MMQ(ks, 0, 0, (ks) % A4_LOOK, a4_wait(ks, 8)) A4_MMQ(ks, 0, 1, (ks) % A4_LOOK, -1)                                \
+  if constexpr ((ks) + A4_LOOK < 8) { A4_PRD(((ks) + A4_LOOK) & 7); }
+  A4_PRD(0); A4_PRD(1); A4_PRD(2); A4_PRD(3);
+  if constexpr (A4_LOOK == 8) { A4_PRD(4); A4_PRD(5); A4_PRD(6); A4_PRD(7); }
+  A4_PG(0) A4_PG(1) A4_PG(2) A4_PG(3) A4_PG(4) A4_PG(5) A4_PG(6) A4_PG(7)
+#undef A4_PG
+#undef A4_PRD
+  A4_SB();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V^T(0) twice and K(1), this wave ...
+  A4_SB();
+  __builtin_amdgcn_s_barrier();                          // ... and every wave
+  A4_SB();
+  asm volatile("s_nop 7" ::: "memory");                  // (the kb-0 scores of tile 0 -> their first vector read: 11 wait states, with room)
+  A4_SB();
+  A4_RD(32) A4_RD(33) A4_RD(34) A4_RD(35)                // the ring: the first slots of frame 0 (0-5: "tile -1", P = 0)
+  if constexpr (A4_LOOK == 8) { A4_RD(36) A4_RD(37) A4_RD(38) A4_RD(39) }
+  int pos_cur = 0;                                       // byte offset of ring position T % 3
+  while (true) {
+    const int pos_next = pos_cur == 2 * A4_KV ? 0 : pos_cur + A4_KV;      // position of T+1: V^T(T+1) is staged there, the K reads move there
+    const int pos_prev = pos_cur == 0 ? 2 * A4_KV : pos_cur - A4_KV;      // position of T-1 = T+2: K(T+2) is staged there, the V^T reads come from there
+    const int dk = pos_next - pos_cur, dv = pos_cur - pos_prev;
+    if (T0.nvalid < KVBLK) {        // ragged last tile of a segment, key block 0 (complete since slot 29 of the previous frame)
+      A4_SB();
+      int lh4_ = 4 * lhi;
+      LX_PIN_IN_BRANCH(lh4_);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (lh4_ + 8 * (r >> 2) + (r & 3) >= T0.nvalid) sc[qb][0][r] = -1e30f;
+    }
+    A4_SB();
+    A4_SLOT4(0, false) A4_SLOT4(4, false) A4_SLOT4(8, false) A4_SLOT4(12, false)
+    A4_SLOT4(16, false) A4_SLOT4(20, false) A4_SLOT4(24, false) A4_SLOT4(28, false)
+    pos_cur = pos_next;
+    A4_SB();
+    if (T0.nvalid == 0) break;
+  }
+  // ---- drain: P.V slice 2 (d blocks 2, 3) and slice 3 of the last tile ----
+  {
+    const int dv = 0, dk = 0, pos_prev = 0, pos_next = 0;
+    (void)dv; (void)dk; (void)pos_prev; (void)pos_next;
+    A4_SLOT4(0, true) A4_SLOT(4, true) A4_SLOT(5, true)
+  }
+#undef A4_SLOT4
+#undef A4_LSUM_MM
+#undef A4_FRAME_BARRIER
+#undef A4_KPIECE
+#undef A4_VPIECE
+#undef A4_ADDR_STEP
+#undef A4_SLOT
+#undef A4_VALU
+#undef A4_OPK
+#undef A4_OP
+#undef A4_EXP_OP
+#undef A4_ADD_OP
+#undef A4_CVT_OP
+#undef A4_MM
+#undef A4_ASMW
+#undef A4_MMP
+#undef A4_MMQ
+#undef A4_RD
+#undef A4_WAITR
+#undef A4_DSR
+  // MFMA results in AGPRs -> v_accvgpr_read: 18 wait states by hand; every LDS-DMA piece of this wave has landed before the wave ends
+  asm volatile("s_nop 15\n s_nop 7\n s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  A4_SB();
+#undef A4_SB
+
+  // ---- epilogue: O[q, d] = O^T / l ----
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#if LX_A4_LSUM
+    const float l_tot = lacc[qb][0];      // (the MFMA summed over both half-waves' keys)
+#else
+    const float l_lane = lsum[qb][0] + lsum[qb][1];
+    const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
+#endif
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int q_in_seg = q0_in_seg + 32 * qb;
+    const size_t q_row = (size_t)q_seg_row0 + (size_t)b * q_len + min(q_in_seg, q_len - 1);
+    // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+    if (q_in_seg < q_len) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc[qb], inv, lhi, args.wide_store != 0);
+  }
+#endif
+}
+
+}  // namespace
+
+// mode 1: no bias on any attended pair; 2: biases. The caller (lx_attn_fwd) has validated the descriptor and decided that the
+// bounded-score contract holds and that every byte offset fits 31 bits.
+int lx_attn4_launch(const void* attn_args, int grid, int mode, void* stream) {
+  const AttnArgs& a = *(const AttnArgs*)attn_args;
+  if (mode == 2) hipLaunchKernelGGL((lx_attn4_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((lx_attn4_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return 0;
+}

@@ -1,0 +1,69 @@
+// attn_common.h -- what the attention translation units (attn.hip: the 8-wave kernels; attn4.hip: the one-wave-per-SIMD kernel) share:
+// the launch argument block, the K / V^T tile geometry and the row-per-lane epilogue store.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// A value defined behind an empty asm INSIDE a rarely taken branch cannot be hoisted out of the loop around it. Without it hipcc's
+// LICM turned the 32 key constants of the ragged-tile masks into registers held (or spilled) across the whole tile loop: 30 VGPRs of
+// lx_attn_pipe_kernel (254 -> 224) and 33 spilled registers of lx_attn_fp8_pipe_kernel<true, true> (-> 0).
+#ifdef LX_ATTN_NO_LICM_FIX
+#define LX_PIN_IN_BRANCH(x)
+#else
+#define LX_PIN_IN_BRANCH(x) asm volatile("" : "+v"(x))
+#endif
+
+constexpr int DH = 128;
+constexpr int KVBLK = 64;
+constexpr int K_BYTES = KVBLK * DH * 2;   // 16 KiB
+constexpr int V_BYTES = DH * KVBLK * 2;   // 16 KiB
+constexpr int STAGE_BYTES = K_BYTES + V_BYTES;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct AttnArgs {
+  lx_attn_desc d;
+  int qt_start[4];   // prefix of (32*NW)-row query tiles per segment
+  int wide_store;    // O rows and columns are 16-byte aligned: the epilogue stores 16 B per lane (lx_store_o)
+  int prio_young;    // LX_ATTN_PRIO=1: one static s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration; guide T5 static form)
+};
+
+// Epilogue store of one query row per lane pair: O[q, d] = O^T / l; lane (q = lane & 31, half = lane >> 5) holds
+// d = db*32 + 8*rq + 4*half + (0..3), i.e. 8 bytes of bf16 per (db, rq), and the two halves of a row hold ADJACENT 8-byte groups.
+// wide: for each pair of groups (rq, rq+1) one v_permlane32_swap per dword hands the lower half-wave the upper half's group rq and
+// the upper half-wave the lower half's group rq+1: every lane then owns 16 contiguous bytes -> 8 dwordx4 stores per lane instead of
+// 16 dwordx2, same bytes, same addresses (the store tail of a row-per-lane epilogue is store-ISSUE bound: guide T21).
+__device__ __forceinline__ void lx_store_o(uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi, bool wide) {
+  if (wide) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq += 2) {
+        const uint32_t a0 = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        const uint32_t a1 = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        const uint32_t b0 = pack_bf16x2(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv);
+        const uint32_t b1 = pack_bf16x2(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        *(u32x4*)(row + db * 32 + 8 * (rq + lhi)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+  } else {
+    uint16_t* op = row + 4 * lhi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 o;
+        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
+        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        *(u32x2*)(op + db * 32 + rq * 8) = o;
+      }
+  }
+}
+
+}  // namespace
+
+// attn4.hip: launches lx_attn4_kernel (one wave per SIMD; bounded-score contract only) on a validated AttnArgs block (256-row query tiles)
+int lx_attn4_launch(const void* attn_args, int grid, int mode, void* stream);

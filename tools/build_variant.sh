@@ -7,10 +7,10 @@ NAME=$1; SRC=$2; shift 2
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../loongx_amd/csrc" && pwd)"
 OUT="$HERE/../lib"; OBJ="$OUT/obj"
 [[ -f "$OBJ/api.o" ]] || bash "$HERE/build.sh"
-EXTRA=""; [[ "$SRC" == "attn" ]] && EXTRA="-fno-honor-nans"
+EXTRA=""; [[ "$SRC" == "attn" || "$SRC" == "attn4" ]] && EXTRA="-fno-honor-nans"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $EXTRA "$@" -c "$HERE/$SRC.hip" -o "$OBJ/${SRC}_$NAME.o"
 OBJS=""
-for s in api gemm attn rowops precise fp8 vae cs3 dgf; do
+for s in api gemm attn attn4 rowops precise fp8 vae cs3 dgf; do
   if [[ "$s" == "$SRC" ]]; then OBJS="$OBJS $OBJ/${SRC}_$NAME.o"; else OBJS="$OBJS $OBJ/$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblx_amd_$NAME.so" $OBJS
