@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 302 /* 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
+#define LX_VERSION 303 /* 0.3.3: + lx_attn_last_kernel (which attention kernel lx_attn_fwd launched: the one-wave-per-SIMD lx_attn4_kernel serves multi-round bounded-score launches); no layout change. 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
                           * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {
@@ -254,8 +254,17 @@ typedef struct lx_attn_desc {
  * 100: a normalised head vector has length <= sqrt(128) * max|w|, RoPE is a rotation. Softmax is shift-invariant and exp2 of such an
  * argument neither overflows nor leaves fp32's normal range over 2^16 keys, so the kernel keeps NO running maximum: no row max, no
  * rescale, no per-score multiply-add -- p = exp2(q.k [+ bias]). Results differ from the max-tracking form by rounding only. */
-enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2 };
+/* LX_ATTN_INVARIANT: the choice of kernel must not depend on the batch size of the launch (the planner otherwise picks between two kernels
+ * whose row sums are accumulated in different orders -- equal to rounding, not bit for bit): what a data-parallel shard needs to reproduce
+ * the single-GPU batch exactly (the engine sets it together with its batch-size-invariant GEMM plans, LX_PAIR_PLAN=0). */
+enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4 };
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
+/* Which kernel the calling thread's last successful lx_attn_fwd launched (a planner decision, exposed for benchmarks and tests):
+ * LX_ATTN_KERNEL_8WAVE: the 8-wave kernels of attn.hip (two waves per SIMD, 32 query rows per wave);
+ * LX_ATTN_KERNEL_4WAVE: lx_attn4_kernel (attn4.hip: one wave per SIMD, 64 query rows per wave, persistent over query tiles) -- bounded-score
+ *   launches of at least two rounds of workgroups with at most 64 key tiles per query tile (LX_ATTN4=1 / 0 in the environment: always / never). */
+enum { LX_ATTN_KERNEL_NONE = 0, LX_ATTN_KERNEL_8WAVE = 1, LX_ATTN_KERNEL_4WAVE = 2 };
+int lx_attn_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) attention path -- BASELINE configs[4] ("fp8 MFMA attention path"); opt-in, the bf16 path above is the

@@ -48,7 +48,7 @@ class AttnDesc(C.Structure):
                 ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32), ("flags", C.c_int32)]
 
 
-LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED = 1, 2
+LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT = 1, 2, 4
 
 
 class AttnF32Desc(C.Structure):
@@ -90,6 +90,7 @@ _SIGS = {
     "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
+    "lx_attn_last_kernel": (C.c_int, []),
     "lx_qkv_prep_fp8_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _P, _I, _P, _I, _F, _F, _F, _P]),
     "lx_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnDesc), _F, _F, _P]),
     "lx_split_bf16": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),

@@ -1332,6 +1332,9 @@ static int lx_attn_wide_store(const lx_attn_desc* d) {
   return on && d->ldo % 8 == 0 && d->o_col % 8 == 0 && ((uintptr_t)d->O & 15) == 0;
 }
 
+static thread_local int lx_attn_last = LX_ATTN_KERNEL_NONE;
+extern "C" int lx_attn_last_kernel(void) { return lx_attn_last; }
+
 extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG(d && d->Q && d->K && d->VT && d->O, "lx_attn_fwd: NULL operand");
   LX_CHECK_ARG(d->n_seg >= 1 && d->n_seg <= 3, "lx_attn_fwd: n_seg=%d must be 1..3", d->n_seg);
@@ -1368,22 +1371,32 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
   hipStream_t st = (hipStream_t)stream;
-  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
                "lx_attn_fwd: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
   bool any_bias = false;                       // a finite non-zero bias on a pair that is attended to
   for (int s = 0; s < nq; ++s)
     for (int k = 0; k < d->n_seg; ++k) any_bias |= d->bias[s][k] > -1e37f && d->bias[s][k] != 0.f;
   static const bool nomax_ok = [] { const char* e = getenv("LX_ATTN_NOMAX"); return e ? atoi(e) != 0 : true; }();
-  // lx_attn4_kernel (attn4.hip: one wave per SIMD, every K / V^T fragment feeds two MFMAs) serves the bounded-score contract; its staging
-  // addresses a tile as buffer base + 32-bit byte offsets, so the K rows and one head's V^T image have to lie within 2 GiB. LX_ATTN4=0: off (A/B).
-  static const bool attn4_ok = [] { const char* e = getenv("LX_ATTN4"); return e ? atoi(e) != 0 : true; }();
-  if (piped && (d->flags & LX_ATTN_BOUNDED) && nomax_ok && attn4_ok) {
-    long long max_row = 0;
-    for (int s = 0; s < d->n_seg; ++s) max_row = std::max(max_row, (long long)d->seg_row0[s] + (long long)d->B * d->seg_len[s]);
-    const bool fits = (max_row + 64) * (long long)d->ldk * 2 < (1ll << 31) && 130ll * d->vt_ld * 2 < (1ll << 31);
-    if (fits) {
+  // lx_attn4_kernel (attn4.hip: one wave per SIMD, every K / V^T fragment feeds two MFMAs, persistent over the query tiles) serves the
+  // bounded-score contract; its staging addresses a tile as buffer base + 32-bit byte offsets, so the K column block and the V^T image
+  // have to lie within 2 GiB each. LX_ATTN4 = 0: never, 1: whenever it can, unset: where it measured faster than the 8-wave kernel on
+  // MI355X (profiles/r04_attn4_ab.txt): launches of at least two rounds of workgroups whose items are at most 64 key tiles long
+  // (B = 16, S = 2560: +1.4 %; 16 x 64 x 2048: +1.7 %) -- one round (B = 1: -2.7 % at S = 2560) and long items (S = 8704: -1.4 %) stay
+  // on the 8-wave kernel.
+  static const int attn4_mode = [] { const char* e = getenv("LX_ATTN4"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (piped && (d->flags & LX_ATTN_BOUNDED) && nomax_ok && attn4_mode != 0) {
+    long long max_row = 0, key_tiles = 0;
+    for (int s = 0; s < d->n_seg; ++s) {
+      max_row = std::max(max_row, (long long)d->seg_row0[s] + (long long)d->B * d->seg_len[s]);
+      key_tiles += (d->seg_len[s] + 63) / 64;
+    }
+    const bool fits = ((max_row + 64) * (long long)d->ldk + (long long)d->H * 128) * 2 < (1ll << 31) &&
+                      ((long long)d->B * d->H + 1) * 128 * d->vt_ld * 2 < (1ll << 31);
+    const bool wanted = attn4_mode == 1 || (!(d->flags & LX_ATTN_INVARIANT) && grid >= 2 * lx_attn4_cus() && key_tiles <= 64);
+    if (fits && wanted) {
       lx_attn4_launch(&a, grid, any_bias ? 2 : 1, stream);
       LX_LAUNCH_CHECK("lx_attn_fwd (lx_attn4_kernel)");
+      lx_attn_last = LX_ATTN_KERNEL_4WAVE;
       return LX_OK;
     }
   }
@@ -1401,6 +1414,7 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
     else hipLaunchKernelGGL((lx_attn_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
   }
   LX_LAUNCH_CHECK("lx_attn_fwd");
+  lx_attn_last = LX_ATTN_KERNEL_8WAVE;
   return LX_OK;
 }
 

@@ -112,7 +112,7 @@ constexpr int a4_kpiece(int i) { return i >= 8 && i < 12 ? i - 8 : -1; }
 constexpr int a4_vpiece(int i) { return i >= 24 && i < 28 ? i - 24 : -1; }
 
 template <int MODE>   // 1: p = exp2(s)   2: p = exp2(s + bias): the bias of the (query, key) segment pair is the srcC of the first score MFMA
-__global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
+__global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, const int n_items) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int QBLK = 256;
   __shared__ __attribute__((aligned(1024))) char smem[A4_LDS];
@@ -121,60 +121,55 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int n_cta = gridDim.x;
 
-  const int BH = D.B * D.H;
-  const int bh = blockIdx.x % BH;
-  const int qt = blockIdx.x / BH;
-  const int b = bh / D.H, h = bh % D.H;
-  int sq = 0;
-#pragma unroll
-  for (int s = 1; s < 3; ++s)
-    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
-  // descriptor fields -> scalars, once (a kernarg array indexed with the running segment inside the loop is a dependent s_load)
+  // descriptor fields -> scalars, once (a kernarg array indexed with a running index inside the loops is a dependent s_load)
+  const int BH = D.B * D.H, NH = D.H;
   const int n_seg = D.n_seg;
   const int len0 = D.seg_len[0], len1 = D.seg_len[1], len2 = D.seg_len[2];
   const int row00 = D.seg_row0[0], row01 = D.seg_row0[1], row02 = D.seg_row0[2];
   const int vt00 = D.seg_vt0[0], vt01 = D.seg_vt0[1], vt02 = D.seg_vt0[2];
-  const float bia0 = D.bias[sq][0], bia1 = D.bias[sq][1], bia2 = D.bias[sq][2];
+  const float b00 = D.bias[0][0], b01 = D.bias[0][1], b02 = D.bias[0][2], b10 = D.bias[1][0], b11 = D.bias[1][1], b12 = D.bias[1][2],
+              b20 = D.bias[2][0], b21 = D.bias[2][1], b22 = D.bias[2][2];
+  const int qs1 = args.qt_start[1], qs2 = args.qt_start[2];
   auto pick = [](int s, auto x0, auto x1, auto x2) { return s == 0 ? x0 : (s == 1 ? x1 : x2); };
   auto seg_len = [&](int s) { return pick(s, len0, len1, len2); };
-  const int q_len = seg_len(sq);
-  const int q_seg_row0 = pick(sq, row00, row01, row02);
-  const int q0_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 64 + l31;       // query block qb: + 32 * qb
+  const int ldk = D.ldk, vt_ld = D.vt_ld, ldq = D.ldq;
 
-  // ---- Q fragments (AGPRs): lane (q = l31, half = lhi) of block qb holds d = ks*16 + lhi*8 .. +8 ----
-  bf16x8 qf[2][8];
+  // ---- work items: one item = one 256-row query tile of one (batch, head). A workgroup walks items blockIdx.x, + gridDim.x, ... : the
+  // launch is PERSISTENT when there are more items than CUs. Between items only O / l / Q change hands: the K / V^T tile stream, its rings
+  // and the frame pipeline run on across the boundary (the generator below hands out the next item's tiles behind the last tile of this
+  // one), so the next item's first tiles are staged under this item's last frames and its Q is fetched under the last frame. Measured
+  // before this (profiles/r04_attn4_cycles.txt): prologue + epilogue + dispatch = 18-20 k of a workgroup's 105-125 k cycles at 32-40 tiles. ----
+  struct Item { int w, b, h, bh, sq, q_len, q_row0, q_tile0; };   // q_row0: first row of the item's query segment and batch; q_tile0: the tile's first row in it
+  auto decode = [&](int w) {
+    Item it;
+    it.w = w;
+    const int qt = w / BH;
+    it.bh = w - qt * BH;
+    it.b = it.bh / NH;
+    it.h = it.bh - it.b * NH;
+    it.sq = (n_seg > 2 && qt >= qs2) ? 2 : ((n_seg > 1 && qt >= qs1) ? 1 : 0);
+    it.q_len = seg_len(it.sq);
+    it.q_row0 = pick(it.sq, row00, row01, row02) + it.b * it.q_len;
+    it.q_tile0 = (qt - pick(it.sq, 0, qs1, qs2)) * QBLK;
+    return it;
+  };
+  // Q fragments of an item: lane (q = l31, half = lhi) of query block qb holds d = ks*16 + lhi*8 .. +8
+  auto load_q = [&](const Item& it, bf16x8 (&q)[2][8]) {
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const size_t q_row = (size_t)q_seg_row0 + (size_t)b * q_len + min(q0_in_seg + 32 * qb, q_len - 1);
-    const __bf16* qp = (const __bf16*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 8;
+    for (int qb = 0; qb < 2; ++qb) {
+      const size_t q_row = (size_t)it.q_row0 + min(it.q_tile0 + wave * 64 + l31 + 32 * qb, it.q_len - 1);
+      const __bf16* qp = (const __bf16*)D.Q + q_row * ldq + D.q_col + it.h * DH + lhi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 16);
-  }
+      for (int ks = 0; ks < 8; ++ks) q[qb][ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+  };
 
-  f32x16 oacc[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
-  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // LSUM 0: per lane, its own 32 probabilities per tile [query block][even / odd value]
-#if LX_A4_LSUM
-  f32x16 lacc[2];                                   // LSUM 1: every register = the row's sum (AGPRs)
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
-  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
-  asm volatile("" : "+v"(ones_frag));
-#endif
-
-  // ---- staging: piece j (0..3) of this wave = 1 KiB = K rows (j*4 + wave)*4 .. +4 (256 B each) / V^T rows (j*4 + wave)*8 .. +8 (128 B) ----
-  const int ldk = D.ldk, vt_ld = D.vt_ld;
-  const lx_rsrc_t rs_k = lx_make_rsrc((const __bf16*)D.K + D.k_col + h * DH);
-  const lx_rsrc_t rs_v = lx_make_rsrc((const __bf16*)D.VT + (size_t)bh * DH * vt_ld);
+  // ---- staging: piece j (0..3) of this wave = 1 KiB = K rows (j*4 + wave)*4 .. +4 (256 B each) / V^T rows (j*4 + wave)*8 .. +8 (128 B).
+  // The buffer descriptors cover the whole K column block / V^T image; the item's head and the tile's rows are the scalar offset. ----
+  const lx_rsrc_t rs_k = lx_make_rsrc((const __bf16*)D.K + D.k_col);
+  const lx_rsrc_t rs_v = lx_make_rsrc((const __bf16*)D.VT);
   uint32_t k_off[4], v_off[4];
   uint32_t k_slot_off;
   {
@@ -192,65 +187,85 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
   for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(k_off[j]), "+v"(v_off[j]));   // (kept in registers: rematerialised they are the multiplies again)
   // K rows are clamped to the tile's last valid key (ragged segment tails; a tile that does not exist is staged from row 0 of the
   // previous one and never used): min(row, clamp) * ld + slot = min(row * ld + slot, clamp * ld + slot). ring_off: byte offset of the
-  // ring position (0, 16384, 32768)
+  // ring position (0, 16384, 32768); ksoff / vsoff: byte offset of the tile's first key row (+ head) / first V^T column (+ batch, head)
   const int piece_lds = wave * 1024;
-  auto kpiece = [&](int j, int ring_off, int krow, int nclamp) {
+  auto kpiece = [&](int j, int ring_off, int ksoff, int nclamp) {
     const uint32_t off_ = min(k_off[j], (uint32_t)((nclamp - 1) * ldk * 2) + k_slot_off);
-    lx_buf_to_lds(rs_k, (lptr_t)(smem + ring_off + piece_lds + j * 4096), off_, krow * ldk * 2);
+    lx_buf_to_lds(rs_k, (lptr_t)(smem + ring_off + piece_lds + j * 4096), off_, ksoff);
   };
-  auto vpiece = [&](int j, int ring_off, int vpos) {
-    lx_buf_to_lds(rs_v, (lptr_t)(smem + A4_VB + ring_off + piece_lds + j * 4096), v_off[j], vpos * 2);
+  auto vpiece = [&](int j, int ring_off, int vsoff) {
+    lx_buf_to_lds(rs_v, (lptr_t)(smem + A4_VB + ring_off + piece_lds + j * 4096), v_off[j], vsoff);
   };
 
   // ---- wave-uniform KV-tile descriptors, handed down a three-deep FIFO: tile T (mask), T+1 (bias of its scores, V^T staging), T+2 (K staging).
-  // The key segments this query segment attends to are packed into up to three "runs" once; the generator's common step is three scalar
-  // adds and a min, a run switch is a rare branch. ----
-  struct Tile { int krow, vpos, nvalid, nclamp; float bl; };   // first key row, first V^T column, keys in the tile (0 = none), staging clamp (>= 1), bias * log2 e
-  int rk0 = 0, rk1 = 0, rk2 = 0, rv0 = 0, rv1 = 0, rv2 = 0, rl0 = 0, rl1 = 0, rl2 = 0;
-  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
-  int n_runs = 0;
-#pragma unroll
-  for (int sg = 0; sg < 3; ++sg) {
-    const float bi = pick(sg, bia0, bia1, bia2);
-    if (sg < n_seg && bi > -1e37f) {
-      const int ln = seg_len(sg), kr = pick(sg, row00, row01, row02) + b * ln, vp = pick(sg, vt00, vt01, vt02);
-      const float bl = bi * 1.4426950408889634f;
-      if (n_runs == 0) { rk0 = kr; rv0 = vp; rl0 = ln; rb0 = bl; }
-      else if (n_runs == 1) { rk1 = kr; rv1 = vp; rl1 = ln; rb1 = bl; }
-      else { rk2 = kr; rv2 = vp; rl2 = ln; rb2 = bl; }
-      ++n_runs;
-    }
-  }
+  // The key segments an item's query segment attends to are packed into up to three "runs" when the generator reaches the item; the common
+  // step is two scalar adds and a min, a run / item switch is a rare branch. ----
+  struct Tile { int ksoff, vsoff, nvalid, nclamp, w; float bl; };   // K / V^T byte offsets, keys in the tile (0 = none), staging clamp (>= 1), item, bias * log2 e
+  // Generator state is (item, run, keys left, current tile) only: a run / item switch recomputes what it needs from the item index (rare
+  // path, ~100 scalar instructions), so that the common path carries no table around the loop (loop-carried scalars that a rare branch
+  // redefines cost a dozen s_mov per frame at hipcc's block merges).
+  int gw = blockIdx.x;                       // the item whose tiles are being handed out
   int g_run = -1, g_left = 0;
-  Tile g_cur = {0, 0, 0, 1, 0.f};
+  Tile g_cur = {0, 0, 0, 1, 0, 0.f};
   auto gen_next = [&]() {
     if (__builtin_expect(g_left > 0, 1)) {
-      g_cur.krow += KVBLK; g_cur.vpos += KVBLK;
+      g_cur.ksoff += KVBLK * ldk * 2; g_cur.vsoff += KVBLK * 2;
     } else {
       __builtin_amdgcn_sched_barrier(0);
-      ++g_run;
-      if (g_run >= n_runs) { g_run = n_runs; g_cur.nvalid = 0; g_cur.nclamp = 1; g_left = 0; return; }   // krow / vpos stay on the last real tile
-      g_left = pick(g_run, rl0, rl1, rl2);
-      g_cur.krow = pick(g_run, rk0, rk1, rk2);
-      g_cur.vpos = pick(g_run, rv0, rv1, rv2);
-      g_cur.bl = pick(g_run, rb0, rb1, rb2);
+      int sq_ = 0, rl0 = 0, rl1 = 0, rl2 = 0, r = 3;
+      Item it = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto runs_of = [&](int w) {            // key segments the item's query segment attends to: length, or 0 (masked / absent)
+        it = decode(w);
+        sq_ = it.sq;
+        rl0 = pick(sq_, b00, b10, b20) > -1e37f ? len0 : 0;
+        rl1 = (n_seg > 1 && pick(sq_, b01, b11, b21) > -1e37f) ? len1 : 0;
+        rl2 = (n_seg > 2 && pick(sq_, b02, b12, b22) > -1e37f) ? len2 : 0;
+      };
+      auto next_run = [&](int p) { return (p < 0 && rl0 > 0) ? 0 : ((p < 1 && rl1 > 0) ? 1 : ((p < 2 && rl2 > 0) ? 2 : 3)); };
+      if (gw < n_items) { runs_of(gw); r = next_run(g_run); }
+      if (r == 3) {                          // this item's keys are exhausted: on to the workgroup's next item
+        gw = gw < n_items ? gw + n_cta : gw;
+        if (gw >= n_items) { gw = n_items; g_cur.nvalid = 0; g_cur.nclamp = 1; g_cur.w = n_items; g_left = 0; return; }   // offsets stay on the last real tile
+        runs_of(gw);
+        r = next_run(-1);                    // (lx_attn_fwd: every query segment attends to at least one key segment)
+      }
+      g_run = r;
+      g_left = pick(r, rl0, rl1, rl2);
+      g_cur.ksoff = (pick(r, row00, row01, row02) + it.b * g_left) * ldk * 2 + it.h * (DH * 2);
+      g_cur.vsoff = pick(r, vt00, vt01, vt02) * 2 + it.bh * DH * vt_ld * 2;
+      g_cur.bl = pick(sq_, pick(r, b00, b01, b02), pick(r, b10, b11, b12), pick(r, b20, b21, b22)) * 1.4426950408889634f;
+      g_cur.w = gw;
     }
     g_cur.nvalid = min(g_left, KVBLK);
     g_cur.nclamp = g_cur.nvalid;
     g_left -= g_cur.nvalid;
   };
+  Item C = decode(gw);                       // the item being computed
   gen_next(); Tile T0 = g_cur;
   gen_next(); Tile T1 = g_cur;
   gen_next(); Tile T2 = g_cur;
 
+  bf16x8 qf[2][8];             // Q fragments of the item (AGPRs)
+  bf16x8 qn[2][8];             // the next item's, fetched under this item's last frame
+  load_q(C, qn);
+
+  f32x16 oacc[2][4];
+  float lsum[2][2];            // LSUM 0: per lane, its own 32 probabilities per tile [query block][even / odd value]
+#if LX_A4_LSUM
+  f32x16 lacc[2];              // LSUM 1: every register = the row's sum (AGPRs)
+  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
+  asm volatile("" : "+v"(ones_frag));
+#endif
+
   // ---- fragment addresses: K 16-B slot ((2ks + lhi) ^ (key & 15)), V^T slot ((2s + lhi) ^ ((d >> 1) & 7)); key block / d block are immediates,
-  // the ring position is part of the register: kaddr points at ring position 0 (K(0)), vaddr at position 2 (the stand-in for "V^T(-1)") ----
+  // the ring position is part of the register: both start at ring position 0 ----
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
   uint32_t kaddr[8], vaddr[4];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds0 + l31 * 256 + (((2 * ks + lhi) ^ (l31 & 15)) * 16);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) vaddr[s] = lds0 + A4_VB + 2 * A4_KV + l31 * 128 + (((2 * s + lhi) ^ ((l31 >> 1) & 7)) * 16);
+  for (int s = 0; s < 4; ++s) vaddr[s] = lds0 + A4_VB + l31 * 128 + (((2 * s + lhi) ^ ((l31 >> 1) & 7)) * 16);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(kaddr[ks]));
 #pragma unroll
@@ -261,18 +276,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
   f32x16 sc[2][2];             // [query block][key block]
   float pv[2][2];              // exp2 results in flight: [unit parity][even / odd value]
   f32x16 offv;                 // MODE 2: bias * log2 e of the tile whose scores are computed next, in all 16 registers
-  float off_cur = T0.bl;
-  if constexpr (MODE == 2) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) offv[r] = off_cur;
-  }
-  // "tile -1": P = 0 against a copy of V^T(0) (finite values: 0 x finite = 0; LDS garbage could hold NaN patterns)
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) { pw[qb][2] = u32x4{0, 0, 0, 0}; pw[qb][3] = u32x4{0, 0, 0, 0}; }
-#ifdef LX_A4_ELIM_VALU
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) { pw[qb][0] = u32x4{1, 1, 1, 1}; pw[qb][1] = u32x4{1, 1, 1, 1}; pv[qb][0] = pv[qb][1] = 0.f; }
-#endif
+  float off_cur = 0.f;
 
 #define A4_SB() __builtin_amdgcn_sched_barrier(0)
   // LX_A4_ELIM_*: timing experiments only (WRONG numbers): what one class of instructions costs the stream -- DSR the fragment reads, DMA the
@@ -406,8 +410,12 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
     A4_VALU(2 * (i) + 1)                                                                                               \
     if constexpr ((i) >= 2 && (i) < 6) { A4_ADDR_STEP(vaddr[((i) - 2) & 3], dv); A4_SB(); }     /* V^T reads move on to ring position T (the reads of slots <= 5 are issued by slot 1) */ \
     if constexpr ((i) >= 10 && (i) < 18) { A4_ADDR_STEP(kaddr[((i) - 10) & 7], dk); A4_SB(); } /* K reads move on to position T+1 (the kb-1 reads of K(T) are issued by slot 9) */ \
-    if constexpr (a4_kpiece(i) >= 0) { A4_KPIECE(a4_kpiece(i) & 3, pos_prev, T2.krow, T2.nclamp); A4_SB(); }              \
-    if constexpr (a4_vpiece(i) >= 0) { A4_VPIECE(a4_vpiece(i) & 3, pos_next, T1.vpos); A4_SB(); }                         \
+    if constexpr (a4_kpiece(i) >= 0) { A4_KPIECE(a4_kpiece(i) & 3, pos_prev, T2.ksoff, T2.nclamp); A4_SB(); }             \
+    if constexpr (a4_vpiece(i) >= 0) { A4_VPIECE(a4_vpiece(i) & 3, pos_next, T1.vsoff); A4_SB(); }                        \
+    if constexpr ((i) == 12) {      /* the item's last frame: the next item's Q (its tiles are being staged already); behind slot 8's vmcnt(0) */ \
+      if (T1.w != C.w && T1.nvalid != 0) { A4_SB(); const Item nx_ = decode(T1.w); load_q(nx_, qn); }                     \
+      A4_SB();                                                                                                         \
+    }                                                                                                                  \
     if constexpr ((i) == 27) { T0 = T1; T1 = T2; A4_SB(); }     /* (nothing reads T1 / T2 behind the V^T pieces: the scalar bookkeeping sits under queued MFMAs) */ \
     if constexpr ((i) == 28) { gen_next(); T2 = g_cur; A4_SB(); }                                                      \
   }
@@ -418,73 +426,127 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
 #endif
 #define A4_SLOT4(i, DRAIN) A4_SLOT(i, DRAIN) A4_SLOT((i) + 1, DRAIN) A4_SLOT((i) + 2, DRAIN) A4_SLOT((i) + 3, DRAIN)
 
-  // ---- prologue: K(0) -> position 0, V^T(0) -> positions 2 (as "V^T(-1)") and 0, K(1) -> position 1; kb-0 scores of tile 0 ----
+  // ---- prologue: K(0) -> ring position 0, V^T(0) -> 0, K(1) -> 1 ----
 #pragma unroll
-  for (int j = 0; j < 4; ++j) kpiece(j, 0, T0.krow, T0.nclamp);
+  for (int j = 0; j < 4; ++j) kpiece(j, 0, T0.ksoff, T0.nclamp);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) vpiece(j, 2 * A4_KV, T0.vpos);
+  for (int j = 0; j < 4; ++j) vpiece(j, 0, T0.vsoff);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) vpiece(j, 0, T0.vpos);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) kpiece(j, A4_KV, T1.krow, T1.nclamp);
+  for (int j = 0; j < 4; ++j) kpiece(j, A4_KV, T1.ksoff, T1.nclamp);
   A4_SB();
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // Q and K(0)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // Q and K(0) of this wave (V^T(0) and K(1) land under the first tile's kb-0 scores) ...
   A4_SB();
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                          // ... and of every wave
   A4_SB();
-  // (the Q fragments pass through an empty asm so that their loads are complete -- hipcc's own waits -- before the asm MFMAs read them)
+  int pos_cur = 0;                                       // byte offset of ring position T % 3
+  bool first_frame = true;                               // the V^T reads of the very first frame stay on position 0 (V^T(0) itself stands in for "tile -1")
+  while (true) {                                         // ---- items ----
+    // the item's Q into the AGPRs (the loads are complete: the prologue's wait / the wait behind the previous item's drain)
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[qb][ks]));
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  A4_SB();
+      for (int ks = 0; ks < 8; ++ks) { qf[qb][ks] = qn[qb][ks]; asm volatile("" : "+a"(qf[qb][ks])); }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+      lsum[qb][0] = lsum[qb][1] = 0.f;
+#if LX_A4_LSUM
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
+#endif
+      // "tile -1" of the item: P = 0 against whatever finite tile the V^T reads still point at (0 x finite = 0)
+      pw[qb][2] = u32x4{0, 0, 0, 0}; pw[qb][3] = u32x4{0, 0, 0, 0};
+#ifdef LX_A4_ELIM_VALU
+      pw[qb][0] = u32x4{1, 1, 1, 1}; pw[qb][1] = u32x4{1, 1, 1, 1}; pv[qb][0] = pv[qb][1] = 0.f;
+#endif
+    }
+    if constexpr (MODE == 2) {
+      off_cur = T0.bl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) offv[r] = off_cur;
+      asm volatile("" : "+v"(offv));
+    }
+    A4_SB();
+    // kb-0 scores of the item's first tile (K reads point at its ring position: the tile stream is continuous across items)
 #define A4_PRD(ks) A4_DSR(ring[(ks) % A4_LOOK], kaddr[ks], 0)
 #define A4_PG(ks)                                                                                                      \
   A4_MMQ(ks, 0, 0, (ks) % A4_LOOK, a4_wait(ks, 8)) A4_MMQ(ks, 0, 1, (ks) % A4_LOOK, -1)                                \
   if constexpr ((ks) + A4_LOOK < 8) { A4_PRD(((ks) + A4_LOOK) & 7); }
-  A4_PRD(0); A4_PRD(1); A4_PRD(2); A4_PRD(3);
-  if constexpr (A4_LOOK == 8) { A4_PRD(4); A4_PRD(5); A4_PRD(6); A4_PRD(7); }
-  A4_PG(0) A4_PG(1) A4_PG(2) A4_PG(3) A4_PG(4) A4_PG(5) A4_PG(6) A4_PG(7)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    A4_SB();
+    A4_PRD(0); A4_PRD(1); A4_PRD(2); A4_PRD(3);
+    if constexpr (A4_LOOK == 8) { A4_PRD(4); A4_PRD(5); A4_PRD(6); A4_PRD(7); }
+    A4_PG(0) A4_PG(1) A4_PG(2) A4_PG(3) A4_PG(4) A4_PG(5) A4_PG(6) A4_PG(7)
 #undef A4_PG
 #undef A4_PRD
-  A4_SB();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V^T(0) twice and K(1), this wave ...
-  A4_SB();
-  __builtin_amdgcn_s_barrier();                          // ... and every wave
-  A4_SB();
-  asm volatile("s_nop 7" ::: "memory");                  // (the kb-0 scores of tile 0 -> their first vector read: 11 wait states, with room)
-  A4_SB();
-  A4_RD(32) A4_RD(33) A4_RD(34) A4_RD(35)                // the ring: the first slots of frame 0 (0-5: "tile -1", P = 0)
-  if constexpr (A4_LOOK == 8) { A4_RD(36) A4_RD(37) A4_RD(38) A4_RD(39) }
-  int pos_cur = 0;                                       // byte offset of ring position T % 3
-  while (true) {
-    const int pos_next = pos_cur == 2 * A4_KV ? 0 : pos_cur + A4_KV;      // position of T+1: V^T(T+1) is staged there, the K reads move there
-    const int pos_prev = pos_cur == 0 ? 2 * A4_KV : pos_cur - A4_KV;      // position of T-1 = T+2: K(T+2) is staged there, the V^T reads come from there
-    const int dk = pos_next - pos_cur, dv = pos_cur - pos_prev;
-    if (T0.nvalid < KVBLK) {        // ragged last tile of a segment, key block 0 (complete since slot 29 of the previous frame)
+    A4_SB();
+    // the first item: V^T(0) and K(1) of this wave, then of every wave (later items: nothing is outstanding here, the tile stream's own
+    // waits and barriers have covered their first tiles); the kb-0 scores -> their first vector read: 11 wait states, with room
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A4_SB();
+    __builtin_amdgcn_s_barrier();
+    A4_SB();
+    asm volatile("s_nop 7" ::: "memory");
+    A4_SB();
+    A4_RD(32) A4_RD(33) A4_RD(34) A4_RD(35)              // the ring: the first slots of the item's first frame (0-5: "tile -1", P = 0)
+    if constexpr (A4_LOOK == 8) { A4_RD(36) A4_RD(37) A4_RD(38) A4_RD(39) }
+    while (true) {                                       // ---- frames ----
+      const int pos_next = pos_cur == 2 * A4_KV ? 0 : pos_cur + A4_KV;      // position of T+1: V^T(T+1) is staged there, the K reads move there
+      const int pos_prev = pos_cur == 0 ? 2 * A4_KV : pos_cur - A4_KV;      // position of T-1 = T+2: K(T+2) is staged there, the V^T reads come from there
+      const int dk = pos_next - pos_cur, dv = first_frame ? 0 : pos_cur - pos_prev;
+      if (T0.nvalid < KVBLK) {        // ragged last tile of a segment, key block 0 (complete since slot 29 of the previous frame)
+        A4_SB();
+        int lh4_ = 4 * lhi;
+        LX_PIN_IN_BRANCH(lh4_);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (lh4_ + 8 * (r >> 2) + (r & 3) >= T0.nvalid) sc[qb][0][r] = -1e30f;
+      }
       A4_SB();
-      int lh4_ = 4 * lhi;
-      LX_PIN_IN_BRANCH(lh4_);
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (lh4_ + 8 * (r >> 2) + (r & 3) >= T0.nvalid) sc[qb][0][r] = -1e30f;
+      A4_SLOT4(0, false) A4_SLOT4(4, false) A4_SLOT4(8, false) A4_SLOT4(12, false)
+      A4_SLOT4(16, false) A4_SLOT4(20, false) A4_SLOT4(24, false) A4_SLOT4(28, false)
+      pos_cur = pos_next;
+      first_frame = false;
+      A4_SB();
+      if (T0.w != C.w) break;         // (T0 is the NEXT tile by now: the FIFO moves behind slot 27)
     }
+    // ---- drain: P.V slice 2 (d blocks 2, 3) and slice 3 of the item's last tile ----
+    {
+      const int dv = 0, dk = 0, pos_prev = 0, pos_next = 0;
+      (void)dv; (void)dk; (void)pos_prev; (void)pos_next;
+      A4_SLOT4(0, true) A4_SLOT(4, true) A4_SLOT(5, true)
+    }
+    // MFMA results in AGPRs -> v_accvgpr_read: 18 wait states by hand; the ring reads issued for a frame that does not follow have landed
+    asm volatile("s_nop 15\n s_nop 7\n s_waitcnt lgkmcnt(0)" ::: "memory");
     A4_SB();
-    A4_SLOT4(0, false) A4_SLOT4(4, false) A4_SLOT4(8, false) A4_SLOT4(12, false)
-    A4_SLOT4(16, false) A4_SLOT4(20, false) A4_SLOT4(24, false) A4_SLOT4(28, false)
-    pos_cur = pos_next;
+    const bool more = T0.nvalid != 0;
+    // ---- epilogue: O[q, d] = O^T / l ----
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#if LX_A4_LSUM
+      const float l_tot = lacc[qb][0];      // (the MFMA summed over both half-waves' keys)
+#else
+      const float l_lane = lsum[qb][0] + lsum[qb][1];
+      const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
+#endif
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      const int q_in_seg = C.q_tile0 + wave * 64 + l31 + 32 * qb;
+      const size_t q_row = (size_t)C.q_row0 + min(q_in_seg, C.q_len - 1);
+      // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
+      if (q_in_seg < C.q_len) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + C.h * DH, oacc[qb], inv, lhi, args.wide_store != 0);
+    }
+    if (!more) break;
+    C = decode(T0.w);
     A4_SB();
-    if (T0.nvalid == 0) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next item's Q (fetched under the last frame); hipcc's own wait in front of the copy counts the same
+    A4_SB();
   }
-  // ---- drain: P.V slice 2 (d blocks 2, 3) and slice 3 of the last tile ----
-  {
-    const int dv = 0, dk = 0, pos_prev = 0, pos_next = 0;
-    (void)dv; (void)dk; (void)pos_prev; (void)pos_next;
-    A4_SLOT4(0, true) A4_SLOT(4, true) A4_SLOT(5, true)
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every LDS-DMA piece of this wave (tiles that do not exist are staged too) has landed before the wave ends
 #undef A4_SLOT4
 #undef A4_LSUM_MM
 #undef A4_FRAME_BARRIER
@@ -505,26 +567,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
 #undef A4_RD
 #undef A4_WAITR
 #undef A4_DSR
-  // MFMA results in AGPRs -> v_accvgpr_read: 18 wait states by hand; every LDS-DMA piece of this wave has landed before the wave ends
-  asm volatile("s_nop 15\n s_nop 7\n s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  A4_SB();
 #undef A4_SB
-
-  // ---- epilogue: O[q, d] = O^T / l ----
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-#if LX_A4_LSUM
-    const float l_tot = lacc[qb][0];      // (the MFMA summed over both half-waves' keys)
-#else
-    const float l_lane = lsum[qb][0] + lsum[qb][1];
-    const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
-#endif
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    const int q_in_seg = q0_in_seg + 32 * qb;
-    const size_t q_row = (size_t)q_seg_row0 + (size_t)b * q_len + min(q_in_seg, q_len - 1);
-    // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-    if (q_in_seg < q_len) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc[qb], inv, lhi, args.wide_store != 0);
-  }
 #endif
 }
 
@@ -532,9 +575,22 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args) {
 
 // mode 1: no bias on any attended pair; 2: biases. The caller (lx_attn_fwd) has validated the descriptor and decided that the
 // bounded-score contract holds and that every byte offset fits 31 bits.
-int lx_attn4_launch(const void* attn_args, int grid, int mode, void* stream) {
+int lx_attn4_cus(void) {
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return n_cu;
+}
+
+int lx_attn4_launch(const void* attn_args, int n_items, int mode, void* stream) {
   const AttnArgs& a = *(const AttnArgs*)attn_args;
-  if (mode == 2) hipLaunchKernelGGL((lx_attn4_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((lx_attn4_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  // one workgroup per CU (96 KiB of LDS, ~400 registers per lane): more items than CUs -> a persistent launch (LX_ATTN4_PERSIST=0: one
+  // workgroup per item, A/B)
+  static const bool persist = [] { const char* e = getenv("LX_ATTN4_PERSIST"); return !(e && atoi(e) == 0); }();
+  const int grid = (persist && n_items > lx_attn4_cus()) ? lx_attn4_cus() : n_items;
+  if (mode == 2) hipLaunchKernelGGL((lx_attn4_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, n_items);
+  else hipLaunchKernelGGL((lx_attn4_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, n_items);
   return 0;
 }

@@ -66,4 +66,5 @@ __device__ __forceinline__ void lx_store_o(uint16_t* row, const f32x16 (&oacc)[4
 }  // namespace
 
 // attn4.hip: launches lx_attn4_kernel (one wave per SIMD; bounded-score contract only) on a validated AttnArgs block (256-row query tiles)
-int lx_attn4_launch(const void* attn_args, int grid, int mode, void* stream);
+int lx_attn4_launch(const void* attn_args, int n_items, int mode, void* stream);
+int lx_attn4_cus(void);   // compute units of the current device (one persistent workgroup each)

@@ -617,6 +617,8 @@ class DiTEngine:
             qsegs.append((row0, L, self.vt0[s], self._qn(wq_txt if s == "txt" else wq, wq), wk_txt if s == "txt" else wk, cos, sin))
             seg_row0.append(row0); seg_len.append(L); seg_vt0.append(self.vt0[s])
         flags = (ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self._layer_nomax(wq) else 0
+        if not self.pair_plan:             # the batch-size-invariant plans: the attention kernel must not depend on the batch size either
+            flags |= ops.ATTN_INVARIANT
         if self.model_config.get("attn_fp8", False):
             # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
