@@ -83,12 +83,28 @@ def cpu_baseline(threads: int):
         t0 = time.time(); fr.block_forward(dbl, hid, enc, cond, temb, ctemb, rc, main, {}); td = time.time() - t0
         t0 = time.time(); fr.single_block_forward(sgl, torch.cat([enc, hid], 1), temb, main, cond, ctemb, rc, {}); ts = time.time() - t0
     per_image = STEPS * (19 * td + 38 * ts)
+    # "always also time the tiny-config end-to-end loop MEASURED" -- the whole oracle denoise loop (embedders, 2 double +
+    # 2 single blocks of 2 heads, norm_out / proj_out, scheduler; the composition of configs[0]: text + image + condition tokens, 4 steps)
+    tiny = fm.FluxTransformer2DModel(num_layers=2, num_single_layers=2, heads=2, head_dim=128, lora=True)
+    fm.init_synthetic_(tiny, 2)
+    hw_t = 16
+    lat, cnd = torch.randn(1, hw_t * hw_t, 64, generator=g), torch.randn(1, hw_t * hw_t, 64, generator=g)
+    pe_t, pooled_t = torch.randn(1, 512, 4096, generator=g) * 0.1, torch.randn(1, 768, generator=g)
+    ids_t = fm.prepare_latent_image_ids(hw_t, hw_t)
+    cids_t = ids_t.clone(); cids_t[:, 2] -= hw_t
+    with torch.no_grad():
+        t0 = time.time()
+        out = fr.denoise_loop(tiny, fm.FlowMatchEulerDiscreteScheduler(), lat, pe_t, pooled_t, torch.zeros(512, 3), ids_t, cnd, cids_t, num_inference_steps=4)
+        t_tiny = time.time() - t0
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32: 1 double block ({td:.2f}s) + 1 single block ({ts:.2f}s) at full width B=1 S=2560, "
-                      f"extrapolated x(19,38) blocks x28 steps"}
+                      f"extrapolated x(19,38) blocks x28 steps",
+            "tiny_measured": {"seconds": round(t_tiny, 3), "images_per_s": round(1.0 / t_tiny, 4), "finite": bool(torch.isfinite(out).all()),
+                              "config": "oracle.flux_ref.denoise_loop end to end, measured: 2 double + 2 single blocks, 2 heads x 128 (D = 256), "
+                                        "512 text + 256 image + 256 condition tokens, 4 steps, fp32, batch 1"}}
 
 
-def _gemm_traffic_mb():
+def _gemm_traffic_mb(key="b1_hw32"):
     """HBM-side bytes per GEMM launch cannot be observed from inside the process: they come from separate rocprofv3 --pmc passes
     of this workload, summarised by tools/pmc_traffic.py into profiles/pmc_traffic.json together with the hash of the kernel
     source they were measured on. A summary of a different gemm.hip is stale: report null rather than a number that no longer
@@ -98,6 +114,11 @@ def _gemm_traffic_mb():
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
         if rec.get("gemm_hip_sha16") != sha:
+            return None, None
+        w = rec.get("workloads", {}).get(key)       # per workload: b1_hw32 (headline), b16_hw32 (configs[2]), b4_hw64 (configs[4]'s per-GPU shape)
+        if w is not None:
+            return w["gemm_traffic_MB_per_launch"], w.get("source")
+        if key != "b1_hw32":
             return None, None
         return rec["gemm_traffic_MB_per_launch"], rec.get("source")
     except Exception:
@@ -208,6 +229,7 @@ _CS3_SD = None
 
 def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, events=True, seed=1234):
     """Warm-up + timed region of one workload on this rank; returns the measurement record (rank 0) or None."""
+    from loongx_amd import _lib
     from loongx_amd import dist as lxd
     from loongx_amd import ops
     from loongx_amd.flux.condition import Condition
@@ -278,12 +300,20 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
     cached = mc.get("independent_condition") and model.flux_pipe.transformer.engine.cond_cache
     fpi = flops_per_image_cond_cached(N, N) if cached else flops_per_image(N, N)
     peak_e2e = PEAK_FP8_TFLOPS if gemm_fp8 else PEAK_BF16_TFLOPS
+    # flops by matrix pipe: in the fp8-attention mode the attention products run on the e4m3 pipe (5 PF), the GEMMs on the bf16 pipe
+    S_tok = T_TXT + 2 * N
+    f_attn = STEPS * 57 * 4.0 * S_tok * S_tok * D
     res = {"value": round(value, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed_ms / steps, 2),
            "dtype": ("bf16 x2 split (fp32-class)" if precise else "fp8 e4m3 MFMA operands" if gemm_fp8 else
                      "bf16 GEMMs, fp8 e4m3 attention" if attn_fp8 else "bf16"),
            "batch_per_gpu": B, "outputs_finite": finite,
            "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
            "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / peak_e2e, 4)}
+    if attn_fp8 and not gemm_fp8 and not cached:
+        # mixed-dtype leg: each share against the peak of the pipe it runs on (the single figure above prices everything at the bf16 peak)
+        per_s = value / world / 1e12
+        res["mfma_frac_by_pipe"] = {"bf16_gemm": round(per_s * (fpi - f_attn) / PEAK_BF16_TFLOPS, 4), "fp8_attention": round(per_s * f_attn / PEAK_FP8_TFLOPS, 4),
+                                    "note": "time-weighted: flops of the bf16 GEMMs / 2.5 PF + flops of the e4m3 attention / 5 PF, per second of wall time"}
     if pw_rec is not None:
         # the matrix-core peak at the clock the part actually sustained under this load (spec peak is quoted at 2.4 GHz)
         peak_here = peak_e2e * pw_rec["sclk_MHz_avg"] / 2400.0
@@ -295,12 +325,12 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
         gm, at = s.get("gemm"), s.get("attn")
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one batch
-        traffic, traffic_src = _gemm_traffic_mb()
+        traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}")
         gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
                  "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
                  "lx_gemm_* (bf16 MFMA, fused epilogues; launch-weighted over the 8-wave 32x32x16 kernels and lx_gemm4_kernel, the one-wave-per-SIMD 16x16x32 form)")
-        if gemm_fp8 or precise or B != 1 or hw != 32:
-            traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels at the headline shape
+        if gemm_fp8 or precise:
+            traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels (the fp8-attention mode runs the same GEMMs)
         res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
                            "peak": peak_e2e, "unit": "TFLOP/s", "frac": round(ach / peak_e2e, 4), "traffic": traffic,
                            "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",
@@ -318,12 +348,21 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
             aname = ("lx_attn_fp8_pipe_kernel (e4m3 32x32x64 MFMA)" if attn_fp8 else
                      "attn_f32_kernel (v_mfma_f32_32x32x2_f32: fp32 matrix peak)" if f32_attn else
                      "attn_split_kernel (bf16 32x32x16 MFMA, 3 cross terms per product: achieved counts ALGORITHMIC flops, the MFMAs do 3x)" if precise
-                     else "lx_attn_pipe_kernel (software-pipelined QK/softmax/PV stream"
+                     else ("lx_attn4_kernel (one wave per SIMD, persistent over query tiles" if _lib.lib.lx_attn_last_kernel() == 2 else
+                           "lx_attn_pipe_kernel (8 waves, software-pipelined QK/softmax/PV stream")
                           + (", bounded-score softmax: no running maximum)" if model.transformer.engine.attn_nomax else ")"))
             res["roofline_attention"] = {"bound": "mfma", "kernel": aname, "achieved": round(aa, 1), "peak": apeak,
                                          "unit": "TFLOP/s", "frac": round(aa / apeak, 4), "launches": at["launches"],
                                          "avg_launch_us": round(at["ms"] * 1e3 / at["launches"], 1),
                                          "share_of_step_time": round(at["ms"] * to_image / (elapsed_ms / steps), 3)}
+            eng_ = model.transformer.engine
+            tab_ = getattr(eng_.w, "q_log2", None)
+            if tab_ and eng_.attn_nomax:
+                # which layers run the bounded-score kernel with THESE weights (synthetic: unit norm_q / norm_k): a checkpoint whose
+                # 16.33 max|norm_q| max|norm_k| (+ bias) exceeds 100 in some layer keeps the max-tracking kernel there
+                bounds = [e["bound"] for e in tab_.values()]
+                res["roofline_attention"]["bounded_score_layers"] = {"bounded": sum(1 for b_ in bounds if b_ <= eng_._nomax_room), "layers": len(bounds),
+                                                                     "largest_score_bound_log2": round(max(bounds), 2), "allowed": round(eng_._nomax_room, 2)}
     del model, batches, out
     torch.cuda.empty_cache()
     return res
@@ -453,6 +492,19 @@ def main():
                 sec.append(r)
                 torch.cuda.empty_cache()
             res["secondary"] = sec
+        # the driver's log keeps the TAIL of this line: the numbers that matter once more, compactly, as the last key
+        def brief(r):
+            b = {"value": r.get("value"), "gemm_frac": (r.get("roofline") or {}).get("frac"), "gemm_traffic_MB": (r.get("roofline") or {}).get("traffic"),
+                 "attn_frac": (r.get("roofline_attention") or {}).get("frac"), "e2e_frac": r.get("mfma_frac_end_to_end")}
+            par = r.get("parity")
+            if isinstance(par, dict):
+                b["parity"] = ({k: {"mean": v.get("noise_pred_relerr_mean"), "final": v.get("final_latent_relerr")} for k, v in par.items() if isinstance(v, dict)}
+                               if "noise_pred_relerr_mean" not in par else {"mean": par.get("noise_pred_relerr_mean"), "final": par.get("final_latent_relerr")})
+            return b
+        summ = {"headline": brief(res), "cpu_tiny_s": (res.get("cpu_baseline") or {}).get("tiny_measured", {}).get("seconds")}
+        for lg, r in zip(("configs2_b16", "hw64_b4_bf16", "configs4_b4_attnfp8", "precise_b1"), res.get("secondary", [])):
+            summ[lg] = brief(r) if "error" not in r else {"error": r["error"]}
+        res["summary"] = summ
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

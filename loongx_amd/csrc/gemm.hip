@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     part = r & 1;
   }
   (void)total;
-  const bool split_tile = pid >= sk_full && sk_parts == 2;
+  const bool split_tile = pid >= sk_full && sk_parts >= 2;          // (3: fault injection, the parked half never raises its flag -- tools/race_screen_g4.py)
   const int g = tile_group(args, lid);
   lx_gemm_desc P = args.p[g];
   int tm, tn;
@@ -1392,7 +1392,8 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
     }
     __syncthreads();
-    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;      // read with sc1 loads (written with sc1 stores): no fences
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                  // (compiler ordering only: no load of the partner's sums may rise above the flag)
+    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;      // read with sc1 loads (written with sc1 stores): no cache maintenance
   }
 
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
@@ -1602,7 +1603,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   if (parked) {                                        // publish: every wave's sc1 stores acknowledged, then the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the data went out as sc1 stores and is complete -- vmcnt(0) above; the workgroup-scope fence is for the COMPILER: nothing of the
+    //  parked sums may sink below the flag)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (tid == 0 && sk_parts == 2) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G4_STAMP(5)
@@ -1618,10 +1622,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1837,7 +1841,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
         float* slots = (float*)workspace;
         int* flags = (int*)((char*)workspace + (size_t)256 * SK_SLOT_FLOATS * sizeof(float));
         int* err = (int*)((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
-        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, 2, slots, flags, err);
+        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, env.g4_fault ? 3 : 2, slots, flags, err);
       } else
         hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
       LX_LAUNCH_CHECK("lx_gemm_bf16");

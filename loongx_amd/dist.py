@@ -101,9 +101,28 @@ def broadcast_packed_weights(pw, src: int = 0) -> int:
         if lo.down_lo is not None:
             flat[f"{k}::lora_down_lo"] = lo.down_lo
     n = broadcast_tensors(flat, src)
-    if hasattr(pw, "q_log2"):          # derived from the norm weights that were just overwritten (engine._setup_nomax rebuilds it)
-        del pw.q_log2
+    refresh_q_log2(pw)
     return n
+
+
+def refresh_q_log2(pw) -> None:
+    """The bounded-score attention's per-layer table (engine._setup_nomax: norm_q weights with scale * log2 e folded in, and the score
+    bound of the layer) is derived from norm weights that a broadcast has just overwritten. The scaled tensors are refreshed IN PLACE --
+    their addresses are baked into captured step graphs and LX_EPI_QKV descriptors -- the bounds are recomputed, and the version the
+    engine keys its step graphs on moves on (a layer may change sides of the bound)."""
+    tab = getattr(pw, "q_log2", None)
+    if not tab:
+        return
+    from . import ops
+    import torch
+    ents = list(tab.values())
+    mx = torch.stack([torch.stack([torch.maximum(e["wq"].abs().max(), e["wq_txt"].abs().max()), torch.maximum(e["wk"].abs().max(), e["wk_txt"].abs().max())])
+                      for e in ents]).tolist()
+    for e, (qm, km) in zip(ents, mx):
+        e["bound"] = 128.0 * ops.Q_LOG2_FACTOR * qm * km
+        e["scaled"][e["wq"].data_ptr()].copy_(e["wq"] * ops.Q_LOG2_FACTOR)
+        e["scaled"][e["wq_txt"].data_ptr()].copy_(e["wq_txt"] * ops.Q_LOG2_FACTOR)
+    pw.q_log2_version = getattr(pw, "q_log2_version", 0) + 1
 
 
 def gather_batches(local: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor]:

@@ -18,6 +18,9 @@ condition_dict = {"depth": 0, "canny": 1, "subject": 4, "coloring": 6, "deblurri
 _IMAGE_TYPES = ("depth", "canny", "subject", "coloring", "deblurring", "depth_pred", "fill", "sr", "cartoon")
 
 
+_CANNY_WARNED = False
+
+
 def canny_edges(raw_img, low: float = 100.0, high: float = 200.0):
     """`cv2.Canny(np.array(raw_img), 100, 200)` as an RGB PIL image (reference condition.py:72-76). cv2 when it is installed; otherwise
     the same algorithm in numpy (OpenCV's defaults: 3x3 Sobel with replicated borders, L1 gradient magnitude, for colour input the
@@ -32,7 +35,16 @@ def canny_edges(raw_img, low: float = 100.0, high: float = 200.0):
         return Image.fromarray(cv2.Canny(img, low, high)).convert("RGB")
     except ImportError:
         pass
-    from scipy import ndimage
+    global _CANNY_WARNED
+    if not _CANNY_WARNED:          # once per process: the fallback is a restatement that has never been compared with cv2 here
+        import warnings
+        warnings.warn("loongx_amd: cv2 is not installed -- condition_type='canny' uses the numpy / scipy restatement of cv2.Canny(img, 100, 200); "
+                      "edge maps may differ from the reference's in isolated pixels", RuntimeWarning, stacklevel=2)
+        _CANNY_WARNED = True
+    try:
+        from scipy import ndimage
+    except ImportError as e:
+        raise ImportError("condition_type='canny' needs cv2 (as the reference does) or, failing that, scipy for the restated algorithm") from e
     a = img.astype(np.int32)
     if a.ndim == 2:
         a = a[:, :, None]

@@ -195,25 +195,31 @@ class DiTEngine:
         if self._gemm_ws is None or (not sync and os.environ.get("LX_ASYNC_STATUS", "1") == "0"):
             return
         if sync:
-            try:
-                ops.gemm_workspace_status(self._gemm_ws)
-                if getattr(self, "_gemm_ws_side", None) is not None:
-                    ops.gemm_workspace_status(self._gemm_ws_side)
-            except Exception:
+            first = None
+            for ws in (self._gemm_ws, getattr(self, "_gemm_ws_side", None)):     # BOTH workspaces are checked (and their flags / error words reset)
+                if ws is None:
+                    continue
+                try:
+                    ops.gemm_workspace_status(ws)
+                except Exception as e:                                           # before the first failure is re-raised
+                    first = first or e
+            if first is not None:
                 self.pair_plan, self.graphs, self._err_event = False, {}, None
-                raise
+                raise first
             return
         n = self._gemm_ws.numel()
         if getattr(self, "_err_host", None) is None:
-            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._err_host = torch.zeros(2, dtype=torch.int32).pin_memory()     # the main and the second stream's error words
             self._err_event = None
         if self._err_event is not None and self._err_event.query():
             self._err_event = None
-            if int(self._err_host[0]) != 0:
-                self.check_status(sync=True)          # resets the workspace and raises
+            if int(self._err_host[0]) != 0 or int(self._err_host[1]) != 0:
+                self.check_status(sync=True)          # resets the workspaces and raises
         if self._err_event is None:
-            word = self._gemm_ws[n - 64 * 4: n - 63 * 4].view(torch.int32)      # [slots | 256 flags | error word + pad]
-            self._err_host.copy_(word, non_blocking=True)
+            for i, ws in enumerate((self._gemm_ws, getattr(self, "_gemm_ws_side", None))):
+                if ws is not None:
+                    word = ws[n - 64 * 4: n - 63 * 4].view(torch.int32)         # [slots | 256 flags | error word + pad]
+                    self._err_host[i:i + 1].copy_(word, non_blocking=True)
             self._err_event = torch.cuda.Event()
             self._err_event.record()
 
@@ -346,9 +352,10 @@ class DiTEngine:
                               for a, b, c, d in layers]).tolist()
             tab = {}
             for (a, b, c, d), (qm, km) in zip(layers, mx):
-                tab[a.data_ptr()] = {"wq": a, "bound": 128.0 * ops.Q_LOG2_FACTOR * qm * km,
+                tab[a.data_ptr()] = {"wq": a, "wk": b, "wq_txt": c, "wk_txt": d, "bound": 128.0 * ops.Q_LOG2_FACTOR * qm * km,
                                      "scaled": {a.data_ptr(): (a * ops.Q_LOG2_FACTOR).contiguous(), c.data_ptr(): (c * ops.Q_LOG2_FACTOR).contiguous()}}
             w.q_log2 = tab
+            w.q_log2_version = getattr(w, "q_log2_version", 0)
         fin = [abs(v) for row in self.attn_bias.values() for v in row.values() if v > -1e37]
         self._nomax_room = 100.0 - max(fin, default=0.0) * 1.4426950408889634
         self.attn_nomax = any(e["bound"] <= self._nomax_room for e in tab.values())      # (some layer of this forward runs the bounded kernel)
@@ -357,7 +364,7 @@ class DiTEngine:
         """Does the layer whose image-stream norm_q weight is `wq` run the bounded-score kernel in this forward?"""
         if not self.attn_nomax:
             return False
-        e = self.w.q_log2.get(wq.data_ptr())
+        e = getattr(self.w, "q_log2", {}).get(wq.data_ptr())
         return e is not None and e["wq"] is wq and e["bound"] <= self._nomax_room       # (an unknown / replaced weight: max tracking)
 
     def _qn(self, w_q: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
@@ -1106,6 +1113,7 @@ class DiTEngine:
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
         key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8,
+               getattr(self.w, "q_log2_version", 0),      # (a weight broadcast refreshes the scaled norm_q tensors and the per-layer bounds)
                self.cond_cache, skip)
         g = self.graphs.get(key)
         if g is None:
