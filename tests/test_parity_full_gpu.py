@@ -4,7 +4,7 @@ same one bench.py prints as `parity`.
 
 Stated tolerances (the north star asks 1e-3 rel-err):
   * bf16 mode (the throughput mode: bf16 MFMA operands, fp32 accumulate, fp32 residual stream): what it MEASURES on an MI355X is
-    recorded in DESIGN.md section 4; asserted here with <= 2x margin;
+    recorded in DESIGN.md section 4; asserted here at the north star's 1e-3 on the edited latents and 6e-3 per forward;
   * precise mode (model_config / LxFluxTransformer(precise=True): split-bf16 MFMA GEMMs + fp32 attention): <= 1e-3, asserted.
 """
 import json
@@ -14,10 +14,14 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (round 2): noise_pred 4.6e-3 ... 5.1e-3 per forward, final latents 8.0e-4 -- asserted with
-# a 2x margin
-BF16_NOISE_PRED_MAX = 1.0e-2
-BF16_FINAL_LATENT = 1.6e-3
+# measured on MI355X (rounds 2-4): noise_pred 4.5e-3 ... 5.3e-3 per forward, final latents 8.0e-4 ... 8.6e-4.
+# The final-latent bound IS the north star's 1e-3 (the measured margin is 14 %); the per-forward bound sits 13 % above the largest
+# value seen. Where the 4.6e-3 per forward comes from is measured (tools/bf16_ablation.py, profiles/r04c_bf16_ablation.txt): the bf16
+# A operands of the GEMMs, every kind in proportion to its share of the flops (ff1 2.3e-3, ff2 2.3e-3, single proj_out 1.7e-3, fused
+# single projection 1.5e-3, to_out 1.1e-3, q/k/v 3.5e-4 alone; attention's q / k / v / P together 4.1e-4), adding in quadrature -- no
+# subset cheaper than precise mode brings it under 2e-3.
+BF16_NOISE_PRED_MAX = 6.0e-3
+BF16_FINAL_LATENT = 1.0e-3
 
 
 def test_full_depth_parity_bf16():
