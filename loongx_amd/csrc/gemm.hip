@@ -1173,6 +1173,10 @@ __device__ unsigned long long lx_g4_probe_buf[8192 * 8];
 // and the one place per block that writes them to the patch (anything else makes hipcc shuffle and spill them).
 constexpr int SK_SLOT_FLOATS = 256 * 256;
 
+// SPLIT = the split-bf16 ("precise") problems of lx_gemm_split_kernel: k_segs passes over K in one accumulation (A_hi W_hi, A_lo W_hi,
+// A_hi W_lo: the K-tile index of the loop maps to (segment, tile) -> source offsets, once per K tile on the scalar unit) and the
+// hi / lo output pair of LX_EPI_SPLIT_BF16. A separate instantiation, so that the bf16 path keeps its exact instruction stream.
+template <bool SPLIT>
 __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args, const int sk_full, const int sk_parts, float* __restrict__ sk_slots,
                                                               int* __restrict__ sk_flags, int* __restrict__ sk_err) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1204,7 +1208,8 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   int M = P.M, N = P.N;
   const int K = P.K;
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
-  const int nkt = K / BK;                              // K tiles of the tile; this workgroup's share: [kt_begin, kt_end)
+  const int nk1 = K / BK;                              // K tiles of one pass over K
+  const int nkt = SPLIT ? nk1 * max(P.k_segs, 1) : nk1; // K tiles of the tile (all segments); this workgroup's share: [kt_begin, kt_end)
   const int kt_begin = split_tile && part ? nkt >> 1 : 0;
   const int kt_end = split_tile && !part ? nkt >> 1 : nkt;
 
@@ -1221,12 +1226,29 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     }
   }
   const __bf16* a_org = (const __bf16*)P.A + (size_t)m0 * P.lda;
-  const __bf16* w_org = w_tiled ? (const __bf16*)P.W + ((size_t)tn * nkt) * (BN * BK) : (const __bf16*)P.W + (size_t)n0 * P.ldw;
+  const int kw_tiles = SPLIT && P.k_segs == 3 ? 2 * nk1 : nk1;       // K tiles per weight row block ([W_hi | W_lo] with three segments)
+  const __bf16* w_org = w_tiled ? (const __bf16*)P.W + ((size_t)tn * kw_tiles) * (BN * BK) : (const __bf16*)P.W + (size_t)n0 * P.ldw;
   const lx_rsrc_t rs_a = lx_make_rsrc(a_org), rs_w = lx_make_rsrc(w_org);
   const int w_kstride_b = (w_tiled ? BN * BK : BK) * 2;
-  auto piece = [&](int p_, int kt, int stage) {       // p_ 0..7: A pieces, 8..15: W pieces of K tile kt
-    if (p_ < 8) lx_buf_to_lds(rs_a, (lptr_t)(smem + stage * G4_STAGE + (p_ * 4 + wave) * 1024), aoff[p_], kt * (BK * 2));
-    else lx_buf_to_lds(rs_w, (lptr_t)(smem + stage * G4_STAGE + A_BYTES + ((p_ - 8) * 4 + wave) * 1024), woff[p_ - 8], kt * w_kstride_b);
+  // K-tile index of the loop -> byte offsets of its A and W tiles (gemm_mainloop's a_soff / w_soff; the identity map for !SPLIT)
+  const int a_lo_b = SPLIT ? P.a_lo_off * 2 : 0;
+  auto a_soff = [&](int t) -> int {
+    if constexpr (!SPLIT) return t * (BK * 2);
+    else {
+      const int seg = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+      return (t - seg * nk1) * (BK * 2) + (seg == 1 ? a_lo_b : 0);
+    }
+  };
+  auto w_soff = [&](int t) -> int {
+    if constexpr (!SPLIT) return t * w_kstride_b;
+    else {
+      const int seg = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+      return (t - seg * nk1 + (seg == 2 ? nk1 : 0)) * w_kstride_b;
+    }
+  };
+  auto piece = [&](int p_, int a_so, int w_so, int stage) {       // p_ 0..7: A pieces, 8..15: W pieces of the K tile at (a_so, w_so)
+    if (p_ < 8) lx_buf_to_lds(rs_a, (lptr_t)(smem + stage * G4_STAGE + (p_ * 4 + wave) * 1024), aoff[p_], a_so);
+    else lx_buf_to_lds(rs_w, (lptr_t)(smem + stage * G4_STAGE + A_BYTES + ((p_ - 8) * 4 + wave) * 1024), woff[p_ - 8], w_so);
   };
   // ---- fragments: 16 rows x 32 k = 16 B per lane (row l15, k chunk lq); row blocks are 2 KiB apart and share the swizzle term ----
   int a_ad[2], w_ad[2];
@@ -1274,10 +1296,14 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     }
   }
   // prologue: K tiles 0 and 1 staged; tile 0 landed; its k-step-0 fragments read
+  {
+    const int t1 = min(kt_begin + 1, kt_end - 1);
+    const int a0 = a_soff(kt_begin), w0 = w_soff(kt_begin), a1 = a_soff(t1), w1 = w_soff(t1);
 #pragma unroll
-  for (int p_ = 0; p_ < 16; ++p_) piece(p_, kt_begin, 0);
+    for (int p_ = 0; p_ < 16; ++p_) piece(p_, a0, w0, 0);
 #pragma unroll
-  for (int p_ = 0; p_ < 16; ++p_) piece(p_, min(kt_begin + 1, kt_end - 1), 1);
+    for (int p_ = 0; p_ < 16; ++p_) piece(p_, a1, w1, 1);
+  }
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   G4_SB();
@@ -1333,6 +1359,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int n = c ^ 1;
     const int kt2 = min(kt + 2, kt_end - 1);
+    const int a_so2 = a_soff(kt2), w_so2 = w_soff(kt2);
 #pragma unroll
     for (int m = 0; m < 64; ++m) {
       if (m == 16) {
@@ -1343,7 +1370,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       }
       mm(0, m); G4_SB();
       if (m < 16) { rd(c, 1, m); G4_SB(); }
-      if (m >= 16 && (m - 16) % 6 == 0) { piece((m - 16) / 6, kt2, c); G4_SB(); }
+      if (m >= 16 && (m - 16) % 6 == 0) { piece((m - 16) / 6, a_so2, w_so2, c); G4_SB(); }
     }
 #pragma unroll
     for (int m = 0; m < 64; ++m) {
@@ -1354,7 +1381,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         G4_SB();
       }
       mm(1, m); G4_SB();
-      if (m < 40 && m % 5 == 0) { piece(8 + m / 5, kt2, c); G4_SB(); }
+      if (m < 40 && m % 5 == 0) { piece(8 + m / 5, a_so2, w_so2, c); G4_SB(); }
       if (m >= 43 && m < 59) { rd(n, 0, m - 43); G4_SB(); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1494,6 +1521,22 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
             const int rk = qkv_vt_interleave(gk * 8 + k), dk = t * 32 + (lane >> 1);
             e[t][k] = pt[rk * G4_PLD + dk];
           }
+        if (P.qkv_q8) {
+          // e4m3 V^T image (gemm_epilogue_qkv): in the f8f6f4 operand order a 64-key tile row is two 32-byte groups g, byte p of group g =
+          // key (p >> 4) * 32 + 8 * ((p & 15) >> 2) + 4 g + (p & 3): this block's 16 keys are 8 bytes of each group, the same two key
+          // sets {0-3, 8-11} / {4-7, 12-15} as the bf16 image's interleave -- lane (d, g = gk) stores its 8 keys as 8 bytes
+          const float vs = P.qkv_v_scale;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int d = t * 32 + (lane >> 1);
+            const float bd = P.bias ? P.bias[nw0 + d] : 0.f;
+            u32x2 o8 = {pack_fp8x4((e[t][0] + bd) * vs, (e[t][1] + bd) * vs, (e[t][2] + bd) * vs, (e[t][3] + bd) * vs),
+                        pack_fp8x4((e[t][4] + bd) * vs, (e[t][5] + bd) * vs, (e[t][6] + bd) * vs, (e[t][7] + bd) * vs)};
+            *(u32x2*)((uint8_t*)P.qkv_vt8 + ((size_t)(b * H + h) * 128 + d) * P.qkv_vt_ld + P.qkv_vt_pos0 + (p0 & ~63) + gk * 32 + ((p0 >> 5) & 1) * 16 +
+                      ((p0 >> 4) & 1) * 8) = o8;
+          }
+          return;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int d = t * 32 + (lane >> 1);
@@ -1535,8 +1578,14 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
             y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
           }
           if (m < M) {
-            u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-            *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
+            if (P.qkv_q8) {                              // e4m3 rows (x the tensor's scale) for lx_attn_fwd_fp8 instead of the bf16 outputs
+              const float sc8 = qkind == 0 ? P.qkv_k_scale : P.qkv_q_scale;
+              u32x2 o8 = {pack_fp8x4(y[0] * sc8, y[1] * sc8, y[2] * sc8, y[3] * sc8), pack_fp8x4(y[4] * sc8, y[5] * sc8, y[6] * sc8, y[7] * sc8)};
+              *(u32x2*)((qkind == 0 ? (uint8_t*)P.qkv_k8 : (uint8_t*)P.qkv_q8) + (size_t)m * P.qkv_ld8 + (ncol - qkind * D)) = o8;
+            } else {
+              u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+              *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
+            }
           }
         }
       }
@@ -1559,6 +1608,18 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
           if (gelu0) { v0 = gelu_tanh4(v0); v1 = gelu_tanh4(v1); }
           u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
           *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol) = o;
+          if constexpr (SPLIT) {
+            if (P.epilogue & LX_EPI_SPLIT_BF16) {     // the rounding residual x - bf16(x), as bf16, c_lo_off columns further (gemm_epilogue)
+              float r[8];
+#pragma unroll
+              for (int c_ = 0; c_ < 4; ++c_) {
+                r[c_] = v0[c_] - bf16_to_f32(f32_to_bf16(v0[c_]));
+                r[4 + c_] = v1[c_] - bf16_to_f32(f32_to_bf16(v1[c_]));
+              }
+              u32x4 ol = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
+              *(u32x4*)((uint16_t*)P.C + (size_t)m * P.ldc + ncol + P.c_lo_off) = ol;
+            }
+          }
         }
       }
     } else {
@@ -1622,10 +1683,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1795,42 +1856,46 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     LX_LAUNCH_CHECK("lx_gemm_bf16 (fp8)");
     return LX_OK;
   }
-  if (split) {   // precise mode: all 256-row tiles or all 128-row tiles (no mixed / pair plans)
-    const int ncu = device_cus() > 0 ? device_cus() : 256;
-    const double ca = (double)((t256 + ncu - 1) / ncu) * round_us(256, kmax), cb = (double)((t128 + ncu - 1) / ncu) * round_us(128, kmax);
-    const int bm = gemm_env().bm ? gemm_env().bm : (cb < ca ? 128 : 256);
-    GemmArgs all;
-    all.n = 0;
-    all.tile_start[0] = 0;
-    for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
-    for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, bm);
-    return launch_plan(all, bm, s, true);
-  }
   const int NCU = device_cus() > 0 ? device_cus() : 256;   // one workgroup per CU: a launch runs in rounds of NCU tiles
   const GemmEnv& env = gemm_env();
   const int forced = env.bm;      // 256 | 128 | 0 = plan
   // lx_gemm4_kernel (one wave per SIMD, 256-row tiles only): the launches whose epilogue it has and whose tile count fills whole rounds.
   // LX_GEMM4 = 0 never | 1 (default) where the last round is at least 3/4 full or there are >= 8 rounds | 2 whenever the epilogue allows (tests).
-  if (env.g4 && forced == 0 && !split && (workspace || env.g4 == 2)) {     // (no workspace = the batch-size-invariant plans only)
+  if (env.g4 && forced == 0 && (workspace || env.g4 == 2)) {     // (no workspace = the batch-size-invariant plans only)
     bool ok = true;
     for (int i = 0; i < n; ++i) {
       const lx_gemm_desc& p = problems[i];
-      ok = ok && (p.epilogue & 0xff) <= LX_EPI_RESID_F32 && p.K / BK >= 2 && !((p.epilogue & LX_EPI_QKV) && p.qkv_q8);   // (e4m3 q/k/v images: the 8-wave kernels)
+      ok = ok && (p.epilogue & 0xff) <= LX_EPI_RESID_F32 && p.K / BK >= 2 && (env.g4_q8 || !((p.epilogue & LX_EPI_QKV) && p.qkv_q8));   // (e4m3 q/k/v images: built and tested here, measured 0.2 % slower per image at 1024 x 1024 than the 8-wave mixed plan -- 8-byte V^T stores per lane against 16 -- profiles/r04f_attnfp8_ab.txt; LX_GEMM4_Q8=1 turns it on)
       if (p.lora_t)        // the kernel's LoRA step: two ranks per 8-byte load, one 32-deep MFMA k-step, up to four K-split slabs
         ok = ok && p.lora_r <= 8 && p.lora_r % 2 == 0 && p.lora_nsplit >= 1 && p.lora_nsplit <= 4 && p.lora_ldt % 2 == 0 && p.lora_split_stride % 2 == 0 &&
              ((((uintptr_t)p.lora_t) | ((uintptr_t)p.lora_up)) & 7) == 0;
     }
     const long rounds = (t256 + NCU - 1) / NCU;
-    const bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
+    bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
     // split form (LX_GEMM4_SK = 1 default | 0 off): the tiles of a partial last round, or all tiles of a launch with <= 128 of them and
     // a long K, by two workgroups each (half of K), meeting through the caller's workspace. One K for the whole launch, >= 16 K tiles.
     bool uniform_k4 = true;
     for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
     const long tail = t256 % NCU, full = t256 - tail;
-    const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && problems[0].K / BK >= 16 &&
-                           tail > 0 && tail * 2 <= 256 && rounds < 8;
-    const bool split_all = can_split && full == 0 && problems[0].K / BK >= env.pair_min_kt;      // (the pair kernel's shapes)
-    const bool split_tail = can_split && full > 0 && tail * 3 <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
+    for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].k_segs == problems[0].k_segs;
+    const int kt_all = kmax / BK;                      // K tiles of a tile, all segments of a split-bf16 problem counted
+    const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && kt_all >= 16 &&
+                           tail > 0 && tail * 2 <= 256 && tail * 2 <= NCU && rounds < 8;
+    bool split_all = can_split && full == 0 && kt_all >= env.pair_min_kt;      // (the pair kernel's shapes)
+    bool split_tail = can_split && full > 0 && tail * 3 <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
+    if (split) {
+      // precise mode (two or three passes over K: the K-independent cost of a round and of the exchange weigh a third as much as on the
+      // bf16 path; no q/k/v epilogue, no mixed plan to compete with): by cost -- measured slopes per K tile and round, 1.31 us for this
+      // kernel (8.9 fixed, ~6 for an exchange), 1.55 / 1.06 for the 8-wave kernels at 256 / 128 rows (tools/gemm_ksweep.py)
+      const double r4 = 8.9 + 1.31 * kt_all;
+      const bool sk_tail = can_split && tail > 0;
+      const double c4 = (double)(full / NCU) * r4 + (tail == 0 ? 0.0 : sk_tail ? 8.9 + 1.31 * (kt_all - kt_all / 2) + 6.0 : r4);
+      const double c8a = (double)((t256 + NCU - 1) / NCU) * (5.8 + 1.55 * kt_all), c8b = (double)((t128 + NCU - 1) / NCU) * (10.5 + 1.06 * kt_all);
+      fills = env.g4 == 2 || c4 < (c8a < c8b ? c8a : c8b);
+      split_all = fills && sk_tail && full == 0;
+      split_tail = fills && sk_tail && full > 0;
+      if (!fills) split_all = split_tail = false;
+    }
     if (ok && (fills || split_all || split_tail)) {
       GemmArgs all;
       all.n = 0;
@@ -1841,12 +1906,25 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
         float* slots = (float*)workspace;
         int* flags = (int*)((char*)workspace + (size_t)256 * SK_SLOT_FLOATS * sizeof(float));
         int* err = (int*)((char*)workspace + PAIR_OFF + (size_t)PAIR_MAX_WG * PAIR_SLOT_FLOATS * sizeof(float)) + PAIR_MAX_WG;
-        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, env.g4_fault ? 3 : 2, slots, flags, err);
-      } else
-        hipLaunchKernelGGL(lx_gemm4_kernel, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
+        if (split) hipLaunchKernelGGL(lx_gemm4_kernel<true>, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, env.g4_fault ? 3 : 2, slots, flags, err);
+        else hipLaunchKernelGGL(lx_gemm4_kernel<false>, dim3((unsigned)(full + 2 * tail)), dim3(G4_THREADS), 0, s, all, (int)full, env.g4_fault ? 3 : 2, slots, flags, err);
+      } else if (split)
+        hipLaunchKernelGGL(lx_gemm4_kernel<true>, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
+      else
+        hipLaunchKernelGGL(lx_gemm4_kernel<false>, dim3((unsigned)t256), dim3(G4_THREADS), 0, s, all, (int)t256, 1, (float*)nullptr, (int*)nullptr, (int*)nullptr);
       LX_LAUNCH_CHECK("lx_gemm_bf16");
       return LX_OK;
     }
+  }
+  if (split) {   // precise mode on the 8-wave kernels: all 256-row tiles or all 128-row tiles (no mixed / pair plans)
+    const double ca = (double)((t256 + NCU - 1) / NCU) * round_us(256, kmax), cb = (double)((t128 + NCU - 1) / NCU) * round_us(128, kmax);
+    const int bm = forced ? forced : (cb < ca ? 128 : 256);
+    GemmArgs all;
+    all.n = 0;
+    all.tile_start[0] = 0;
+    for (int i = 1; i <= MAX_SUB; ++i) all.tile_start[i] = 0;
+    for (int i = 0; i < n; ++i) plan_add(all, problems[i], 0, bm);
+    return launch_plan(all, bm, s, true);
   }
   // Two workgroups per 256-row tile (lx_gemm_pair_kernel) when there are at most 128 such tiles: needs one K for the whole
   // group, a 256-CU device and the scratch slots. LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144:

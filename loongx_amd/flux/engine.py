@@ -898,7 +898,7 @@ class DiTEngine:
             lo, ns = self._lora_t_p(pair, name, K, K, 0, rows) if rows <= self.TLs.shape[1] else (None, 0)
             if lo is not None:
                 kw = dict(lora_t=self.TL[:rows], lora_up=lo.up, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0))
-        ops.gemm([self._desc_p(pair, name, out, K=K, a_lo_off=K, bias=self.w.t[name + ".b"], epilogue=LX_EPI_STORE_F32, **kw)])
+        ops.gemm([self._desc_p(pair, name, out, K=K, a_lo_off=K, bias=self.w.t[name + ".b"], epilogue=LX_EPI_STORE_F32, **kw)], self.gemm_ws())
 
     def _ln_p(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
         row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
@@ -944,7 +944,7 @@ class DiTEngine:
                 kw.update(lora_t=self.TL[row0[s_]:row0[s_] + a.shape[0], t_col0:], lora_up=up, lora_mod_cols=lora_mod_cols,
                           lora_toff_max=lora_toff_max, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0))
             probs.append(self._desc_p(a, name, c, K=K, a_lo_off=a_lo_off, w_rows=w_rows, **kw))
-        ops.gemm(probs)
+        ops.gemm(probs, self.gemm_ws())       # (the workspace admits lx_gemm4_kernel<true> and its split form; None under LX_PAIR_PLAN=0)
         return lo, ns, lr0
 
     def _attention_p(self, wq, wk, wq_txt, wk_txt) -> None:
@@ -995,7 +995,7 @@ class DiTEngine:
             a = self.rows(self.YA, "cond")
             kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up, lora_nsplit=ns, lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
             ops.gemm([self._desc_p(a, p + ".out", self.rows(self.X, "img"), K=D, a_lo_off=5 * D, bias=w.t[p + ".out.b"],
-                                   epilogue=LX_EPI_RESID_F32, rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)])
+                                   epilogue=LX_EPI_RESID_F32, rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)], self.gemm_ws())
         self._ln_p(base, 3 * D, 4 * D)
         Ym = self.YA[:, D:]                                                                   # mlp hidden pair: hi at [D, 5D), lo 5D further
         self._gemm_streams_p(self.XN2, D, D, Ym, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16, c_lo_off=5 * D, gelu=True)
@@ -1060,7 +1060,7 @@ class DiTEngine:
             ops.ln_modulate_split_segs(self.X, [(self.r_img, self.B * self.N, self.N, self.mods[:, o + D:], self.mods[:, o:])], self.XN2,
                                        self.mods.stride(0), D)
             ops.gemm([self._desc_p(self.rows(self.XN2, "img"), "proj_out", self.out, K=D, a_lo_off=D, bias=w.t["proj_out.b"],
-                                   epilogue=LX_EPI_STORE_F32)])
+                                   epilogue=LX_EPI_STORE_F32)], self.gemm_ws())
             return self.out.view(self.B, self.N, cfg.in_channels)
         ops.ln_modulate(self.rows(self.X, "img"), self.mods[:, o + D:], self.mods[:, o:], self.rows(self.XN, "img"),
                         rows_per_batch=self.N, mod_ld=self.mods.stride(0))

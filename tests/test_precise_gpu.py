@@ -3,6 +3,7 @@ arithmetic for the reference's shipped fp32 configuration (train/config/seed_512
 engine vs the reference-generated goldens at fp32-class tolerance, and the north star's 1e-3 at full depth."""
 import json
 import math
+import os
 
 import pytest
 import torch
@@ -44,10 +45,44 @@ def test_split_bf16_pair_carries_16_bits(ops):
     assert relerr(hi + lo, x) < 2.0 ** -16
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 192), (2560, 768, 3072)])
+_WS = []
+
+
+def _ws(ops):
+    if not _WS:
+        _WS.append(ops.gemm_workspace(DEV))
+    return _WS[0]
+
+
+@pytest.fixture
+def gemm_plan(monkeypatch):
+    """'w8': the 8-wave split kernels (no workspace); 'g4': lx_gemm4_kernel<true> forced, whole tiles only; 'g4sk': forced, with the
+    workspace -- tails / short launches go through the two-workgroup split form. The library re-reads its switches afterwards."""
+    from loongx_amd import _lib, ops
+
+    def set_plan(plan):
+        if plan == "w8":
+            monkeypatch.setenv("LX_GEMM4", "0")
+        else:
+            monkeypatch.setenv("LX_GEMM4", "2")
+            monkeypatch.setenv("LX_GEMM4_SK", "1" if plan == "g4sk" else "0")
+        _lib.lib.lx_gemm_reload_env()
+        return _ws(ops) if plan != "w8" else None
+    yield set_plan
+    for k in ("LX_GEMM4", "LX_GEMM4_SK"):
+        os.environ.pop(k, None)
+    monkeypatch.undo()
+    _lib.lib.lx_gemm_reload_env()
+
+
+@pytest.mark.parametrize("plan", ["w8", "g4", "g4sk"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 192), (2560, 768, 3072), (2304, 7680, 1024)])
 @pytest.mark.parametrize("segs", [2, 3])
-def test_gemm_split_bf16(ops, M, N, K, segs):
-    """k_segs = 2: A as a hi/lo pair x bf16-exact W; k_segs = 3: W = [W_hi | W_lo] too. fp32-class result either way."""
+def test_gemm_split_bf16(ops, M, N, K, segs, plan, gemm_plan):
+    """k_segs = 2: A as a hi/lo pair x bf16-exact W; k_segs = 3: W = [W_hi | W_lo] too. fp32-class result either way, on the 8-wave
+    split kernels and on lx_gemm4_kernel<true> (2560 x 768: 30 tiles = the split form's all-tiles case; 2304 x 7680: 270 tiles = one
+    round + a 14-tile split tail)."""
+    ws = gemm_plan(plan)
     A = rnd(M, K, seed=1)
     W = rnd(N, K, seed=2, scale=0.05)
     if segs == 2:
@@ -62,16 +97,65 @@ def test_gemm_split_bf16(ops, M, N, K, segs):
             continue
         Wt = ops.tile_weight(Wd) if tiled else Wd
         C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-        ops.gemm([ops.gemm_desc(A2, Wt, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32, K=K, N=N, k_segs=segs, a_lo_off=K + 64)])
+        ops.gemm([ops.gemm_desc(A2, Wt, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32, K=K, N=N, k_segs=segs, a_lo_off=K + 64)], ws)
         assert relerr(C32, ref) < 3e-5, (segs, tiled)
     # hi/lo output pair with GELU
     Cp = torch.zeros(M, 2 * N + 64, dtype=torch.bfloat16, device=DEV)
     ops.gemm([ops.gemm_desc(A2, Wd, Cp, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, K=K, N=N, k_segs=segs,
-                            a_lo_off=K + 64, c_lo_off=N + 64)])
+                            a_lo_off=K + 64, c_lo_off=N + 64)], ws)
     want = torch.nn.functional.gelu(ref.double(), approximate="tanh").float()
     got = Cp[:, :N].float() + Cp[:, N + 64:2 * N + 64].float()
     assert relerr(got, want) < 5e-5
     assert relerr(Cp[:, :N].float(), want) < 4e-3                     # the hi image alone is the bf16 result
+    if ws is not None:
+        assert _status(ops, ws) == 0
+
+
+def _status(ops, ws):
+    from loongx_amd import _lib
+    return _lib.lib.lx_gemm_workspace_status(ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("plan", ["w8", "g4", "g4sk"])
+def test_gemm_split_bf16_lora_gate_residual(ops, plan, gemm_plan):
+    """The precise mode's gated-residual launch with the LoRA term as cross-term slabs (engine._gemm_streams_p): two problems (one with
+    the adapter, rank 4, three slabs), three K segments, 12 + 12 tiles, against fp64."""
+    ws = gemm_plan(plan)
+    M, N, K, r, B = 512, 768, 1024, 4, 2
+    ref_all, probs, outs, keep = [], [], [], []
+    for i in range(2):
+        A = rnd(M, K, seed=10 + i)
+        W = rnd(N, K, seed=20 + i, scale=0.03)
+        bias = rnd(N, seed=30 + i)
+        gate = rnd(B, N, seed=40 + i)
+        X0 = rnd(M, N, seed=50 + i)
+        A2 = _pair(ops, A, lo_off=K, width=2 * K)
+        hi = W.to(torch.bfloat16)
+        Wd = ops.tile_weight(torch.cat([hi, (W - hi.float()).to(torch.bfloat16)], 1).contiguous())
+        y = A.double() @ W.double().T + bias.double()
+        kw = {}
+        if i == 1:
+            down = rnd(r, K, seed=60, scale=0.05)
+            up = rnd(N, r, seed=61, scale=0.05)
+            t = A.double() @ down.double().T
+            y = y + t @ up.double().T
+            slabs = torch.zeros(3, M, r, dtype=torch.float32, device=DEV)        # the consumer adds the slabs: any decomposition of t
+            slabs[0] = (t * 0.5).float(); slabs[1] = (t * 0.25).float(); slabs[2] = (t - slabs[0].double() - slabs[1].double()).float()
+            kw = dict(lora_t=slabs[0], lora_up=up.contiguous(), lora_nsplit=3, lora_split_stride=slabs.stride(0))
+            outs.append(slabs)
+        C = X0.clone()
+        g_rows = gate.double().repeat_interleave(M // B, 0)
+        ref_all.append((X0.double() + g_rows * y).float())
+        probs.append(ops.gemm_desc(A2, Wd, C, bias=bias, epilogue=ops.LX_EPI_RESID_F32, K=K, N=N, k_segs=3, a_lo_off=K, gate=gate,
+                                   rows_per_batch=M // B, **kw))
+        outs.append(C)
+        keep.append((A2, Wd, bias, gate, kw))          # (a descriptor holds raw pointers: the operands must outlive the launch)
+    ops.gemm(probs, ws)
+    got = [o for o in outs if o.shape == (M, N)]
+    for g, want in zip(got, ref_all):
+        assert relerr(g, want) < 3e-5
+    if ws is not None:
+        assert _status(ops, ws) == 0
 
 
 def test_ln_modulate_split(ops):
