@@ -1419,6 +1419,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
     }
     __syncthreads();
+    G4_STAMP(6)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                  // (compiler ordering only: no load of the partner's sums may rise above the flag)
     partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;      // read with sc1 loads (written with sc1 stores): no cache maintenance
   }
