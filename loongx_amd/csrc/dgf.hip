@@ -77,19 +77,25 @@ __global__ __launch_bounds__(256) void duan_gate_kernel(const float* __restrict_
   }
 }
 
+// One workgroup per (64 channels, b) -- 8 x B workgroups instead of B (16 workgroups ran this for 53 us at batch 16). Every workgroup
+// recomputes what all channels share (layer statistics in fp64, the hidden layer of the gamma / beta MLP: waves over hidden units,
+// lanes over channels, so the weight rows are read coalesced); the per-channel sums keep their order (gate mean over tiles, MLP rows
+// over hidden units), so the affine is bit-identical to the one-workgroup form.
 __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gpart,
                                                         const float* __restrict__ mw1, const float* __restrict__ mb1,
                                                         const float* __restrict__ mw2, const float* __restrict__ mb2,
                                                         float* __restrict__ coef, int C, int L, int Hd, int ntile, float eps) {
   __shared__ float hid2[128];
+  __shared__ float mc[1024];
+  __shared__ float wt[128 * 65];          // (>= 64 * 129)
   __shared__ double dred[8];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* st = stats + (size_t)b * C * 4;
   // layer statistics over (C, L): combine per-row (mean, var) exactly in fp64
   double sm = 0.0;
-  for (int ch = tid; ch < C; ch += 256) sm += (double)st[ch * 4];
+  for (int ch = tid; ch < C; ch += 256) { sm += (double)st[ch * 4]; mc[ch] = st[ch * 4 + 2]; }
   for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-  if ((tid & 63) == 0) dred[tid >> 6] = sm;
+  if (lane == 0) dred[wave] = sm;
   __syncthreads();
   const double mu_l = (dred[0] + dred[1] + dred[2] + dred[3]) / (double)C;
   double sv = 0.0;
@@ -98,23 +104,45 @@ __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict_
     sv += (double)st[ch * 4 + 1] + d * d;
   }
   for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
-  if ((tid & 63) == 0) dred[4 + (tid >> 6)] = sv;
+  if (lane == 0) dred[4 + wave] = sv;
   __syncthreads();
   const double var_l = (dred[4] + dred[5] + dred[6] + dred[7]) / (double)C;
   const float mul = (float)mu_l, sig_l = sqrtf((float)var_l + eps);
-  // gamma/beta MLP on the pooled condition
-  for (int hd = tid; hd < Hd; hd += 256) {
-    float a = mb1[hd];
-    for (int ch = 0; ch < C; ++ch) a = fmaf(mw1[(size_t)hd * C + ch], st[ch * 4 + 2], a);
-    hid2[hd] = a > 0.f ? a : 0.f;
-  }
-  __syncthreads();
-  for (int ch = tid; ch < C; ch += 256) {
-    float gam = mb2[ch], bet = mb2[C + ch];
-    for (int hd = 0; hd < Hd; ++hd) {
-      gam = fmaf(mw2[(size_t)ch * Hd + hd], hid2[hd], gam);
-      bet = fmaf(mw2[(size_t)(C + ch) * Hd + hd], hid2[hd], bet);
+  // gamma/beta MLP on the pooled condition: hidden unit hd = relu(b1 + sum over channels IN CHANNEL ORDER) -- one lane walks the
+  // channels of its hidden unit (the order of the reference's matmul row is not defined; this keeps the order of the earlier kernel)
+  // (weight rows go through LDS in 64-column chunks: read coalesced, then each lane walks ITS row -- stride 65: conflict-free)
+  {
+    float a = tid < Hd ? mb1[tid] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      __syncthreads();
+      for (int e = tid; e < Hd * 64; e += 256) {
+        const int hd = e >> 6, cc = e & 63;
+        wt[hd * 65 + cc] = c0 + cc < C ? mw1[(size_t)hd * C + c0 + cc] : 0.f;
+      }
+      __syncthreads();
+      if (tid < Hd) {
+        const int n = min(64, C - c0);
+        for (int cc = 0; cc < n; ++cc) a = fmaf(wt[tid * 65 + cc], mc[c0 + cc], a);
+      }
     }
+    if (tid < Hd) hid2[tid] = a > 0.f ? a : 0.f;
+  }
+  const int ch = blockIdx.x * 64 + tid;
+  float gam = 0.f, bet = 0.f;
+  for (int half = 0; half < 2; ++half) {              // gamma rows [0, C), beta rows [C, 2C) of the second MLP layer: 64 rows x Hd at a time
+    __syncthreads();
+    for (int e = tid; e < 64 * Hd; e += 256) {
+      const int r = e / Hd, hd = e - r * Hd, cr = blockIdx.x * 64 + r;
+      wt[r * 129 + hd] = cr < C ? mw2[(size_t)(half * C + cr) * Hd + hd] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64 && ch < C) {
+      float a = mb2[half * C + ch];
+      for (int hd = 0; hd < Hd; ++hd) a = fmaf(wt[tid * 129 + hd], hid2[hd], a);
+      if (half == 0) gam = a; else bet = a;
+    }
+  }
+  if (tid < 64 && ch < C) {
     float g = 0.f;
     for (int t = 0; t < ntile; ++t) g += gpart[((size_t)b * ntile + t) * C + ch];
     g /= (float)L;
@@ -143,23 +171,25 @@ __global__ __launch_bounds__(256) void duan_apply_kernel(const float* __restrict
   if (threadIdx.x == 0) imp[row] = s / (float)L;
 }
 
+// One workgroup per (channel, b): its rank among the batch element's importances (ties: the lower channel index first, as a stable
+// descending sort keeps them), and the row zeroed when the rank is past keep_k -- C x B workgroups instead of B walking the dropped
+// rows one after the other (64 us at batch 16).
 __global__ __launch_bounds__(256) void duan_mask_kernel(const float* __restrict__ imp, float* __restrict__ y, int C, int L, int keep_k) {
-  __shared__ int drop[1024];
-  const int b = blockIdx.x;
+  __shared__ float red[4];
+  const int b = blockIdx.y, ch = blockIdx.x;
   const float* ib = imp + (size_t)b * C;
-  for (int ch = threadIdx.x; ch < C; ch += 256) {
-    const float v = ib[ch];
-    int rank = 0;
-    for (int o = 0; o < C; ++o) {
-      const float w = ib[o];
-      rank += (w > v) || (w == v && o < ch);
-    }
-    drop[ch] = rank >= keep_k;
+  const float v = ib[ch];
+  float cnt = 0.f;
+  for (int o = threadIdx.x; o < C; o += 256) {
+    const float w = ib[o];
+    cnt += ((w > v) || (w == v && o < ch)) ? 1.f : 0.f;
   }
-  __syncthreads();
-  for (int ch = 0; ch < C; ++ch) {
-    if (!drop[ch]) continue;
-    float* yr = y + ((size_t)b * C + ch) * L;
+  const int rank = (int)(block_sum(cnt, red) + 0.5f);      // (counts <= 1024: exact in fp32)
+  if (rank < keep_k) return;
+  float* yr = y + ((size_t)b * C + ch) * L;
+  if ((L & 3) == 0 && (((uintptr_t)yr) & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < L; i += 1024) *(f32x4*)(yr + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
     for (int i = threadIdx.x; i < L; i += 256) yr[i] = 0.f;
   }
 }
@@ -197,9 +227,9 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   } else {
     hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
   }
-  hipLaunchKernelGGL(duan_coef_kernel, dim3(B), dim3(256), 0, s, stats, gpart, mw1, mb1, mw2, mb2, coef, C, L, Hd, ntile, eps);
+  hipLaunchKernelGGL(duan_coef_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, stats, gpart, mw1, mb1, mw2, mb2, coef, C, L, Hd, ntile, eps);
   hipLaunchKernelGGL(duan_apply_kernel, dim3(C, B), dim3(256), 0, s, x, coef, y, imp, C, L);
-  hipLaunchKernelGGL(duan_mask_kernel, dim3(B), dim3(256), 0, s, imp, y, C, L, keep_k);
+  hipLaunchKernelGGL(duan_mask_kernel, dim3(C, B), dim3(256), 0, s, imp, y, C, L, keep_k);
   LX_LAUNCH_CHECK("lx_duan_fwd");
   return LX_OK;
 }
