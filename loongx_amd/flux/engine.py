@@ -62,6 +62,16 @@ class DiTEngine:
         self.gemm_fp8 = False
         self.w8: Dict[str, torch.Tensor] = {}          # name -> tiled e4m3 weight / name + ".rs" -> row de-scale, built on first use
         self._gemm_ws: Optional[torch.Tensor] = None
+        # Adapter rows on merged weights (LX_LORA_MERGE=1; off by default): W' = bf16(W + lora_scale * B_up A_down) per LoRA-carrying
+        # block weight (+11.5 GB at FLUX.1-dev scale), built once per (weights, scale). The adapter streams' problems of a grouped
+        # launch then read W' instead of W: the 88 lx_lora_down launches of a step -- each one's input is the output of the kernel in
+        # front of it, 0.69-0.75 ms of a 35.6 ms step on its critical path, profiles/r04l_lora_down_share.txt -- and the LoRA k-step of
+        # the GEMM tile prologue go. Measured (profiles/r04n_lora_merge_ab.txt, alternating on one box): 1.0368 / 1.0363 images/s
+        # against 1.0350 / 1.0372 -- the image and condition rows no longer share a weight panel through L2 / MALL and the GEMMs give
+        # the 2 % back (0.445 vs 0.457 of peak). Kept as a tested option. bf16 modes only, not with add_cond_attn.
+        self.lora_merge = os.environ.get("LX_LORA_MERGE", "0") == "1"
+        self.wl: Dict[str, torch.Tensor] = {}
+        self._wl_key = None
         # Step-invariant condition stream (model_config independent_condition / union_cond_attn = False: the condition queries see
         # only condition keys, its timestep c_t is fixed, so its hidden states, keys and values are the same at every denoise step):
         # the first forward after set_conditioning() computes all three streams and leaves the condition keys / V^T of every layer in
@@ -173,6 +183,8 @@ class DiTEngine:
             self.graphs = {}
             self.cond_ready = False
             self.sched = None
+            if self.wl:                  # merged adapter weights follow the scale (rebuilt in place)
+                self._setup_lora_merge()
 
     def gemm_ws(self, side: bool = False) -> Optional[torch.Tensor]:
         """The caller-owned GEMM workspace of lx_gemm_bf16_ws (the default launch plans: split-K pairs, lx_gemm4_kernel). One per stream:
@@ -413,6 +425,8 @@ class DiTEngine:
             self._setup_fp8()
         if self.model_config.get("attn_fp8", False) and not self.precise:
             self._fp8_images()                                                                    # never first allocated inside a capture
+        if C or self.latent_lora:
+            self._setup_lora_merge()
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
@@ -479,7 +493,7 @@ class DiTEngine:
             b0 = base_by_stream[s]
             segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
         lora = None
-        if lora_name is not None and self.ln_lora and self.cfg.inner_dim in (3072, 256):
+        if lora_name is not None and self.ln_lora and self.cfg.inner_dim in (3072, 256) and not self._merge_active(lora_name):
             lo = self.w.lora.get(lora_name)
             rows = self._lora_rows(include_txt)
             if lo is not None and rows is not None and not (self.C == 0 and not self.latent_lora) and self.lora_scale != 0.0:
@@ -491,6 +505,44 @@ class DiTEngine:
         if self.lora_scale != 1.0:
             self.TL[lora[2]:lora[2] + lora[3], : lo.down.shape[0]].mul_(self.lora_scale)
         return lo, lora[2], 1
+
+    def _merge_active(self, name: str) -> bool:
+        """This launch group's adapter rows read the merged weight (no lx_lora_down, no LoRA operands)."""
+        return (self.lora_merge and not self.precise and not self.gemm_fp8 and self.lora_scale != 0.0 and name in self.wl
+                and (self.C > 0 or self.latent_lora) and not self.model_config.get("add_cond_attn", False))
+
+    def _setup_lora_merge(self) -> None:
+        """W' = bf16(W + lora_scale * up_m . down_m) for every LoRA-carrying block weight, module by module for the fused ones (column
+        block n // D picks down-projection rows min(n // D, n_mod - 1): lora_mod_cols / lora_toff_max of the unmerged launch), in the
+        same tiled image as W. Rebuilt IN PLACE when the scale or the weights change (captured graphs hold the addresses)."""
+        if not self.lora_merge or self.precise or self.gemm_fp8 or self.lora_scale == 0.0 or not self.w.lora:
+            return
+        key = (id(self.w), getattr(self.w, "lora_version", 0), getattr(self.w, "q_log2_version", 0), self.lora_scale, len(self.w.lora))
+        if key == self._wl_key:
+            return
+        D = self.cfg.inner_dim
+        for name, lo in self.w.lora.items():
+            if not (name[0] in "ds" and name[1].isdigit()):       # block weights only (x_embedder: one launch per step, left as it is)
+                continue
+            W = self.w.t[name + ".w"]
+            tiled = getattr(W, "lx_tiled", False)
+            W32 = (ops.untile_weight(W) if tiled else W).float()
+            N = W32.shape[0]
+            r = lo.up.shape[1]
+            n_mod = lo.down.shape[0] // r
+            down = lo.down.float()
+            for m in range(n_mod):
+                n0 = m * D if n_mod > 1 else 0
+                n1 = N if m == n_mod - 1 else (m + 1) * D
+                W32[n0:n1].addmm_(lo.up[n0:n1].float(), down[m * r:(m + 1) * r], alpha=self.lora_scale)
+            merged = W32.to(torch.bfloat16)
+            merged = ops.tile_weight(merged) if tiled else merged.contiguous()
+            dst = self.wl.get(name)
+            if dst is not None and dst.shape == merged.shape:
+                dst.copy_(merged)
+            else:
+                self.wl[name] = merged
+        self._wl_key = key
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
@@ -507,6 +559,8 @@ class DiTEngine:
     def _lora_t(self, A: torch.Tensor, name: str, include_txt: bool = False):
         lo = self.w.lora.get(name)
         if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0 or self._lora_rows(include_txt) is None:
+            return None, None
+        if self._merge_active(name):          # the adapter rows read W' = W + B A: nothing to project down
             return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
@@ -525,7 +579,11 @@ class DiTEngine:
         w = self.w
         lora_needed = only is None or "cond" in only or self.latent_lora
         nsplit = self.TL_SPLIT
-        if lora is not None:               # (Lora, first row[, slabs]) already projected down by the caller (_ln, or one lx_lora_down for several launches)
+        merged = self.wl[main] if (lora_needed and self._merge_active(main) and self._lora_rows(txt is None) is not None) else None
+        lr0m = self._lora_rows(txt is None)[0] if merged is not None else 0
+        if merged is not None:             # adapter rows on W' = W + B A: no down-projection, no LoRA operands
+            lo, lr0 = None, None
+        elif lora is not None:               # (Lora, first row[, slabs]) already projected down by the caller (_ln, or one lx_lora_down for several launches)
             lo, lr0 = lora[:2] if lora_needed else (None, None)
             if len(lora) > 2:
                 nsplit = lora[2]
@@ -539,6 +597,10 @@ class DiTEngine:
             name = txt if (s == "txt" and txt is not None) else main
             a, c = self.rows(A, s), self.rows(Cbuf, s)
             W, bias = w.t[name + ".w"], w.t[name + ".b"]
+            if merged is not None and name == main and (s == "cond" or (s == "img" and self.latent_lora) or
+                                                        (s == "txt" and self.latent_lora and txt is None)):
+                if {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s] >= lr0m:
+                    W = merged
             if cols is not None:
                 tiled = getattr(W, "lx_tiled", False)
                 W, bias, c = W[c0:c1], bias[c0:c1], c[:, c0:c1]

@@ -116,6 +116,7 @@ class PackedWeights:
     t: Dict[str, torch.Tensor] = field(default_factory=dict)     # name -> tensor
     lora: Dict[str, Lora] = field(default_factory=dict)          # name -> Lora (absent => no adapter)
     precise_ready: bool = False                                   # every weight is bf16-exact or carries its residual
+    lora_version: int = 0                                         # bumped by install_lora
 
     def nbytes(self) -> int:
         n = sum(v.numel() * v.element_size() for v in self.t.values())
@@ -355,6 +356,7 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
     for k in [k for k in pw.t if k.startswith("mod.lora_")]:
         del pw.t[k]
     pw.t.update(new_t)
+    pw.lora_version += 1                 # engines rebuild what they derived from the adapters (merged weights: DiTEngine._setup_lora_merge)
     return n
 
 

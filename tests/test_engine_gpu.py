@@ -289,3 +289,43 @@ def test_lora_down_inside_ln_modulate_matches_the_separate_launch(monkeypatch, G
         assert eng.ln_lora == (v == "1")
         outs[v] = _run(eng, G)
     assert relerr(outs["1"], outs["0"]) < 2e-3 and relerr(outs["1"], G["fwd_cond"]) < TOL
+
+
+@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
+def test_merged_adapter_weights_match_the_unmerged_launches(monkeypatch, G, mc):
+    """LX_LORA_MERGE=1 (opt-in): the adapter rows' problems read W' = bf16(W + scale * B A) and the step has no lx_lora_down launch
+    behind the condition embedder; against the unmerged path (fp32-class LoRA term on bf16 W) and the reference goldens, with the
+    scale moved (merged weights rebuilt in place) and back, and with the adapters off (base weights on every stream)."""
+    from loongx_amd import ops
+    calls = [0]
+    real = ops.lora_down
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "lora_down", counted)
+    outs, n_down = {}, {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("LX_LORA_MERGE", v)
+        eng = _engine(tiny_transformer())
+        assert eng.lora_merge == (v == "1")
+        calls[0] = 0
+        outs[v] = _run(eng, G, model_config=mc)
+        n_down[v] = calls[0]
+        if v == "1":
+            eng.set_lora_scale(0.5)
+            half = _run(eng, G, model_config=mc)
+            eng.set_lora_scale(0.0)
+            off = _run(eng, G, model_config=mc)
+            eng.set_lora_scale(1.0)
+            assert torch.equal(_run(eng, G, model_config=mc), outs["1"])          # rebuilt in place: the same image of W'
+        else:
+            eng.set_lora_scale(0.5)
+            half0 = _run(eng, G, model_config=mc)
+            eng.set_lora_scale(0.0)
+            off0 = _run(eng, G, model_config=mc)
+    assert n_down["1"] < n_down["0"] and n_down["1"] <= 3                         # (x_embedder keeps its adapter launches: condition rows, latents)
+    assert relerr(outs["1"], outs["0"]) < 3e-3
+    assert relerr(half, half0) < 3e-3 and torch.equal(off, off0)
+    if not mc:
+        assert relerr(outs["1"], G["fwd_cond"]) < TOL

@@ -21,10 +21,21 @@ def per_dispatch(path, counter):
     return tot, n, {k: round(v[0] / v[1], 1) for k, v in by.items()}
 
 
+# optional 4th / 5th argument: a workload key (b1_hw32 = headline | b16_hw32 = configs[2] | b4_hw64 = configs[4]'s per-GPU shape) and
+# an existing pmc_traffic.json to merge the record into (`workloads[key]`); without them the record is the headline's, as before
 f_tot, f_n, f_by = per_dispatch(sys.argv[1], "FETCH_SIZE")
 w_tot, w_n, w_by = per_dispatch(sys.argv[2], "WRITE_SIZE")
 sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
 mb = (2.0 * f_tot / max(f_n, 1) + w_tot / max(w_n, 1)) * 1024 / 1e6
+if len(sys.argv) > 5:
+    rec = json.load(open(sys.argv[5]))
+    if rec.get("gemm_hip_sha16") != sha:
+        raise SystemExit(f"{sys.argv[5]} was measured on another gemm.hip ({rec.get('gemm_hip_sha16')} != {sha})")
+    rec.setdefault("workloads", {})[sys.argv[4]] = {"gemm_traffic_MB_per_launch": round(mb, 1), "source": sys.argv[3],
+                                                     "fetch_KiB_per_launch_by_kernel (uncorrected)": f_by, "write_KiB_per_launch_by_kernel": w_by,
+                                                     "launches": {"fetch_pass": f_n, "write_pass": w_n}}
+    print(json.dumps(rec, indent=1))
+    raise SystemExit(0)
 print(json.dumps({"gemm_hip_sha16": sha, "gemm_traffic_MB_per_launch": round(mb, 1), "source": sys.argv[3],
                   "fetch_KiB_per_launch_by_kernel (uncorrected)": f_by, "write_KiB_per_launch_by_kernel": w_by,
                   "launches": {"fetch_pass": f_n, "write_pass": w_n}}, indent=1))
