@@ -1166,11 +1166,13 @@ __device__ unsigned long long lx_g4_probe_buf[8192 * 8];
 #endif
 
 // Split form (sk_parts == 2): the tiles at positions >= sk_full of the tile order -- a partial last round, or every tile of a launch
-// with at most 128 of them -- are computed by TWO workgroups, half of K each, next to each other in the grid. The second one runs the
-// plain fp32-store epilogue into its 256 x 256 slot of the caller's workspace and raises a flag; the first one (which also holds the
-// LoRA term) waits (bounded: the workspace's error word reports a time-out, as the pair kernel's does), and its epilogue adds the
-// parked sums row by row where it reads its own from the patch -- the accumulators themselves are never touched outside the main loop
-// and the one place per block that writes them to the patch (anything else makes hipcc shuffle and spill them).
+// with at most 128 of them -- are computed by TWO workgroups, half of K each, next to each other in the grid, and FINISHED by both:
+// each parks (plain fp32 rows, sc1 stores into its 256 x 256 slot of the caller's workspace) the four 16-row blocks per wave that the
+// other one owns, raises a flag, waits for the partner's (bounded: the workspace's error word reports a time-out, as the pair
+// kernel's does), and runs the epilogue on its own four blocks, adding the partner's sums row by row where it reads its own from the
+// patch -- the accumulators themselves are never touched outside the main loop and the one place per block that writes them to the
+// patch (anything else makes hipcc shuffle and spill them). Round 3's form (one half parks all eight blocks, the other finishes all
+// eight) left the epilogue -- a chain of blocks, each a memory round trip long -- on half of the workgroups: section 9 of DESIGN.md.
 constexpr int SK_SLOT_FLOATS = 256 * 256;
 
 // SPLIT = the split-bf16 ("precise") problems of lx_gemm_split_kernel: k_segs passes over K in one accumulation (A_hi W_hi, A_lo W_hi,
@@ -1196,7 +1198,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     part = r & 1;
   }
   (void)total;
-  const bool split_tile = pid >= sk_full && sk_parts >= 2;          // (3: fault injection, the parked half never raises its flag -- tools/race_screen_g4.py)
+  const bool split_tile = pid >= sk_full && sk_parts >= 2;          // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
   const int g = tile_group(args, lid);
   lx_gemm_desc P = args.p[g];
   int tm, tn;
@@ -1395,34 +1397,47 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   __syncthreads();
   G4_STAMP(4)
 
-  // ---- split tiles: the second half parks through the plain fp32-store epilogue, the first half waits for it ----
-  const bool parked = split_tile && part == 1;
+  // ---- split tiles: BOTH halves finish half of the tile. Part p parks (fp32, sc1 stores into its own slot) the four 16-row blocks of
+  // every wave that the other part owns -- part 0 owns blocks 0-3, part 1 blocks 4-7 -- raises its flag, waits for the partner's
+  // (bounded), and runs the real epilogue on its own four blocks with the partner's sums added. A wave's epilogue is a chain of
+  // blocks, each a memory round trip long (tools/g4_probe_split.py: 8 blocks = 36-38 us for the gated residual, on whole tiles too;
+  // half of the blocks = half of the time): with one half parking all eight blocks and the other finishing all eight, the launch paid
+  // 12.6 us of parking + the wait + a full 38-us epilogue on 120 of the 256 CUs.
   const float* partner = nullptr;                      // the other half's sums (tile-local [256][256] fp32), added in the epilogue
+  float* my_slot = nullptr;
+  if (split_tile) {
+    my_slot = sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS;
+    partner = sk_slots + (size_t)((pid - sk_full) ^ 1) * SK_SLOT_FLOATS;    // read with sc1 loads (written with sc1 stores): no cache maintenance
+  }
   auto pld4 = [&](size_t off_floats) {                 // 16 B of the partner's slot, agent scope (sc1: not from this CU's L1 / a stale L2 line)
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lx_make_rsrc(partner), (int)(off_floats * 4), 0, PAIR_AUX_SC1);
     return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
   const int lm0 = wm * 128, ln0 = wn * 128;            // this wave's tile-local origin
-  if (parked) {
-    P.C = sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS;
-    P.ldc = 256; P.epilogue = LX_EPI_STORE_F32; P.bias = nullptr;
-    m0 = 0; n0 = 0; M = 256; N = 256;
-  } else if (split_tile) {
+  // publish my parked blocks, then wait for the partner's: every wave's sc1 stores acknowledged (vmcnt(0)) before the flag; the
+  // workgroup-scope fences are for the COMPILER (nothing of the parked sums may sink below the flag, no load of the partner's may rise
+  // above it). Bounded: a partner that never shows up sets the workspace's error word (lx_gemm_workspace_status), nothing hangs.
+  auto exchange = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (tid == 0) {
+      const int me = pid - sk_full, other = me ^ 1;
+      if (!(sk_parts == 3 && part == 1))               // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
+        __hip_atomic_store(sk_flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       bool ok = true;
-      while (__hip_atomic_load(sk_flags + (pid - sk_full + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      while (__hip_atomic_load(sk_flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 20)) { ok = false; break; }
       }
-      if (ok) __hip_atomic_store(sk_flags + (pid - sk_full + 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ok) __hip_atomic_store(sk_flags + other, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (each flag: raised by its owner, reset by its reader)
       else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
     }
     __syncthreads();
     G4_STAMP(6)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                  // (compiler ordering only: no load of the partner's sums may rise above the flag)
-    partner = sk_slots + (size_t)(pid - sk_full + 1) * SK_SLOT_FLOATS;      // read with sc1 loads (written with sc1 stores): no cache maintenance
-  }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
 
   // ---- epilogue: 16-row blocks through a wave-private fp32 patch, so that every global access is a 16-byte row access ----
   const int epi = P.epilogue & 0xff;
@@ -1464,8 +1479,27 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 #pragma unroll
     for (int j = 0; j < 8; ++j) *(f32x4*)(pt + l15 * G4_PLD + j * 16 + 4 * lq) = acc[i][j];
   };
-  auto block = [&](auto ic_) {
-    constexpr int i = decltype(ic_)::value;
+  // a block the OTHER half of a split tile owns: its sums as they are, row layout, into this workgroup's slot -- agent-scope
+  // write-through stores (the owner reads them with sc1 loads: no cache maintenance on either side); the next block's accumulators go
+  // into the other patch as in block() below
+  auto park = [&](auto ic_, auto nx_) {
+    constexpr int i = decltype(ic_)::value, nx = decltype(nx_)::value;
+    const float* pt = patch + (i & 1) * (16 * G4_PLD);
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (nx >= 0) { if (mw0 + nx * 16 < M) put(std::integral_constant<int, nx>{}); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (mw0 + i * 16 >= M) return;
+    const lx_rsrc_t rs_slot = lx_make_rsrc(my_slot);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = t * 2 + (lane >> 5);
+      const f32x4 v = *(const f32x4*)(pt + row * G4_PLD + c4);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs_slot,
+                                             (int)(((size_t)(wm * 128 + i * 16 + row) * 256 + wn * 128 + c4) * 4), 0, PAIR_AUX_SC1);
+    }
+  };
+  auto block = [&](auto ic_, auto nx_) {               // block i; nx = the block behind it in this workgroup's order (-1: none)
+    constexpr int i = decltype(ic_)::value, nx = decltype(nx_)::value;
     const int mb = mw0 + i * 16;
     if (mb >= M) return;                               // (wave-uniform; the blocks behind it are out of range as well)
     const float* pt = patch + (i & 1) * (16 * G4_PLD);
@@ -1482,9 +1516,9 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // block i + 1 goes into the other patch HERE, at one place per block and outside every epilogue branch: with the accumulator reads
+    // the next block goes into the other patch HERE, at one place per block and outside every epilogue branch: with the accumulator reads
     // inside the (tile-uniform) branches hipcc has to reconcile 256 AGPR assignments at every join, through VGPRs and scratch
-    if constexpr (i < 7) { if (mb + 16 < M) put(std::integral_constant<int, i + 1>{}); }
+    if constexpr (nx >= 0) { if (mw0 + nx * 16 < M) put(std::integral_constant<int, nx>{}); }
     __builtin_amdgcn_sched_barrier(0);
     if (partner) {
       // split owner: the other half's sums of this block are added INTO the patch, row layout (two 16-B sc1 loads per lane and four-row
@@ -1651,25 +1685,29 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
             }
             v = o;
           }
-          if (parked)      // agent-scope write-through: the owner reads it with sc1 loads, no cache maintenance on either side
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                                   lx_make_rsrc(P.C), (int)(((size_t)m * 256 + ncol) * 4), 0, PAIR_AUX_SC1);
-          else *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
+          *(f32x4*)((float*)P.C + (size_t)m * P.ldc + ncol) = v;
         }
       }
     }
   };
-  if (mw0 < M) put(std::integral_constant<int, 0>{});
-  block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
-  block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{}); block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
-  if (parked) {                                        // publish: every wave's sc1 stores acknowledged, then the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // (the data went out as sc1 stores and is complete -- vmcnt(0) above; the workgroup-scope fence is for the COMPILER: nothing of the
-    //  parked sums may sink below the flag)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (tid == 0 && sk_parts == 2) __hip_atomic_store(sk_flags + (pid - sk_full), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define G4_B(I, NX) block(std::integral_constant<int, I>{}, std::integral_constant<int, NX>{})
+#define G4_K(I, NX) park(std::integral_constant<int, I>{}, std::integral_constant<int, NX>{})
+  if (!split_tile) {                                   // a whole tile: its own straight line (a branch in the middle of it cost 3 % per launch)
+    if (mw0 < M) put(std::integral_constant<int, 0>{});
+    G4_B(0, 1); G4_B(1, 2); G4_B(2, 3); G4_B(3, 4); G4_B(4, 5); G4_B(5, 6); G4_B(6, 7); G4_B(7, -1);
+  } else if (part == 0) {                              // parks 4-7, then owns 0-3
+    if (mw0 + 64 < M) put(std::integral_constant<int, 4>{});
+    G4_K(4, 5); G4_K(5, 6); G4_K(6, 7); G4_K(7, 0);
+    exchange();
+    G4_B(0, 1); G4_B(1, 2); G4_B(2, 3); G4_B(3, -1);
+  } else {                                             // parks 0-3, then owns 4-7
+    if (mw0 < M) put(std::integral_constant<int, 0>{});
+    G4_K(0, 1); G4_K(1, 2); G4_K(2, 3); G4_K(3, 4);
+    exchange();
+    G4_B(4, 5); G4_B(5, 6); G4_B(6, 7); G4_B(7, -1);
   }
+#undef G4_B
+#undef G4_K
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G4_STAMP(5)
 #endif
@@ -1684,10 +1722,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8, sk_tail_div; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0), env_int("LX_GEMM4_TAIL_DIV", 3)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1883,7 +1921,7 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && kt_all >= 16 &&
                            tail > 0 && tail * 2 <= 256 && tail * 2 <= NCU && rounds < 8;
     bool split_all = can_split && full == 0 && kt_all >= env.pair_min_kt;      // (the pair kernel's shapes)
-    bool split_tail = can_split && full > 0 && tail * 3 <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
+    bool split_tail = can_split && full > 0 && tail * env.sk_tail_div <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
     if (split) {
       // precise mode (two or three passes over K: the K-independent cost of a round and of the exchange weigh a third as much as on the
       // bf16 path; no q/k/v epilogue, no mixed plan to compete with): by cost -- measured slopes per K tile and round, 1.31 us for this

@@ -1,6 +1,6 @@
 """Phase times of lx_gemm4_kernel's split form per workgroup (a -DLX_G4_PROBE build: LX_AMD_LIB=loongx_amd/lib/liblx_amd_g4probe.so):
-M = 2560, N = 3072 (120 tiles -> 240 workgroups: even = owner, odd = parked half), gated fp32 residual epilogue. PK = K.
-stamps: 0 start | 1 K tile 0 landed | 2 main loop starts | 3 main loop done | 4 DMA landed + barrier | 6 owner: partner's flag seen | 5 done."""
+M = 2560, N = 3072 (120 tiles -> 240 workgroups: even = part 0 (parks blocks 4-7, owns 0-3), odd = part 1), gated fp32 residual epilogue. PK = K.
+stamps: 0 start | 1 K tile 0 landed | 2 main loop starts | 3 main loop done | 4 DMA landed + barrier | 6 own blocks parked, partner's flag seen | 5 done."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 os.environ["LX_GEMM4"] = "2"; os.environ["LX_GEMM_PAIR_MIN_KT"] = "16"
@@ -30,15 +30,16 @@ t0 = t[:, 0].min()
 own, park = t[0::2], t[1::2]
 print(f"K = {K}: launch {s.elapsed_time(e) * 1e3 / 20:.1f} us (probe build); stamps relative to the launch's first workgroup start, mean (min, max) us")
 def row(nm, x): print(f"  {nm:44s} {float(x.mean()):7.2f} ({float(x.min()):6.2f}, {float(x.max()):6.2f})")
-row("owner: start -> K tile 0 landed [1-0]", own[:, 1] - own[:, 0])
-row("owner: main loop [3-2]", own[:, 3] - own[:, 2])
-row("parked: main loop [3-2]", park[:, 3] - park[:, 2])
-row("owner: drain + barrier [4-3]", own[:, 4] - own[:, 3])
-row("parked: epilogue (sc1 stores + flag) [5-4]", park[:, 5] - park[:, 4])
-row("owner: wait for the flag [6-4]", own[:, 6] - own[:, 4])
-row("owner: epilogue with partner loads [5-6]", own[:, 5] - own[:, 6])
-row("owner: whole life [5-0]", own[:, 5] - own[:, 0])
-row("parked: whole life [5-0]", park[:, 5] - park[:, 0])
+row("part 0: start -> K tile 0 landed [1-0]", own[:, 1] - own[:, 0])
+row("part 0: main loop [3-2]", own[:, 3] - own[:, 2])
+row("part 1: main loop [3-2]", park[:, 3] - park[:, 2])
+row("part 0: drain + barrier [4-3]", own[:, 4] - own[:, 3])
+row("part 0: park blocks 4-7 + flags [6-4]", own[:, 6] - own[:, 4])
+row("part 1: park blocks 0-3 + flags [6-4]", park[:, 6] - park[:, 4])
+row("part 0: epilogue of blocks 0-3 [5-6]", own[:, 5] - own[:, 6])
+row("part 1: epilogue of blocks 4-7 [5-6]", park[:, 5] - park[:, 6])
+row("part 0: whole life [5-0]", own[:, 5] - own[:, 0])
+row("part 1: whole life [5-0]", park[:, 5] - park[:, 0])
 print("  (stamps are s_memtime ticks x 0.01; calibrate against the main loop: K / 128 K tiles per half)")
 
 # reference: the same gated-residual epilogue on WHOLE tiles (M = 4096, N = 4096: 256 tiles, one round, no exchange)
@@ -54,5 +55,20 @@ n2 = 256 * 8
 host2 = (ctypes.c_ulonglong * n2)()
 assert _lib.lib.lx_g4_probe_read(host2, n2) == 0
 t2 = torch.tensor(list(host2), dtype=torch.float64).view(256, 8) * 0.01
+row("whole tiles: start -> K tile 0 landed [1-0]", t2[:, 1] - t2[:, 0])
+row("whole tiles: fragment reads [2-1]", t2[:, 2] - t2[:, 1])
 row("whole tiles: main loop [3-2]", t2[:, 3] - t2[:, 2])
+row("whole tiles: drain + barrier [4-3]", t2[:, 4] - t2[:, 3])
 row("whole tiles: gated-residual epilogue [5-4]", t2[:, 5] - t2[:, 4])
+row("whole tiles: whole life [5-0]", t2[:, 5] - t2[:, 0])
+# and the bf16 + GELU store epilogue (ff1's), same tiles
+C3 = torch.empty(M2, N2, device=dev, dtype=torch.bfloat16)
+d3 = ops.gemm_desc(A2, W2, C3, bias=bias2, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU)
+for _ in range(5): ops.gemm([d3], ws)
+torch.cuda.synchronize()
+assert _lib.lib.lx_g4_probe_read(host2, n2) == 0
+t3 = torch.tensor(list(host2), dtype=torch.float64).view(256, 8) * 0.01
+row("whole tiles, bf16 + GELU: start -> K tile 0 landed [1-0]", t3[:, 1] - t3[:, 0])
+row("whole tiles, bf16 + GELU: main loop [3-2]", t3[:, 3] - t3[:, 2])
+row("whole tiles, bf16 + GELU: epilogue [5-4]", t3[:, 5] - t3[:, 4])
+row("whole tiles, bf16 + GELU: whole life [5-0]", t3[:, 5] - t3[:, 0])
