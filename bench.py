@@ -115,7 +115,7 @@ def _gemm_traffic_mb(key="b1_hw32"):
         sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
         if rec.get("gemm_hip_sha16") != sha:
             return None, None
-        w = rec.get("workloads", {}).get(key)       # per workload: b1_hw32 (headline), b16_hw32 (configs[2]), b4_hw64 (configs[4]'s per-GPU shape)
+        w = rec.get("workloads", {}).get(key)       # per workload: b1_hw32 (headline), b16_hw32 (configs[2]), b4_hw64 (configs[4]'s per-GPU shape), b1_hw32_precise
         if w is not None:
             return w["gemm_traffic_MB_per_launch"], w.get("source")
         if key != "b1_hw32":
@@ -325,12 +325,12 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
         gm, at = s.get("gemm"), s.get("attn")
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one batch
-        traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}")
+        traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}" + ("_precise" if precise else ""))
         gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
-                 "lx_gemm_split_kernel (bf16 32x32x16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
+                 "lx_gemm4_kernel<true> / lx_gemm_split_kernel (split-bf16 operands on the bf16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
                  "lx_gemm_* (bf16 MFMA, fused epilogues; launch-weighted over the 8-wave 32x32x16 kernels and lx_gemm4_kernel, the one-wave-per-SIMD 16x16x32 form)")
-        if gemm_fp8 or precise:
-            traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 kernels (the fp8-attention mode runs the same GEMMs)
+        if gemm_fp8:
+            traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 / split-bf16 kernels (the fp8-attention mode runs the bf16 GEMMs)
         res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
                            "peak": peak_e2e, "unit": "TFLOP/s", "frac": round(ach / peak_e2e, 4), "traffic": traffic,
                            "traffic_unit": "MB per launch (rocprofv3 PMC: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)",

@@ -1594,16 +1594,17 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
           const int row = t * 4 + (lane >> 4);
           pv[t][0] = *(const f32x4*)(pt + row * G4_PLD + c8); pv[t][1] = *(const f32x4*)(pt + row * G4_PLD + c8 + 4);
         }
+        float yy[4][8];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int row = t * 4 + (lane >> 4), m = mb + row;
           f32x4 v0 = pv[t][0], v1 = pv[t][1];
           float ss = 0.f;
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; ss = __builtin_fmaf(v0[c_], v0[c_], ss); ss = __builtin_fmaf(v1[c_], v1[c_], ss); }
           ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
           const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-          float x[8], y[8];
+          float x[8];
+          float (&y)[8] = yy[t];
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) { x[c_] = v0[c_] * r * nw0v[c_]; x[4 + c_] = v1[c_] * r * nw1v[c_]; }
 #pragma unroll
@@ -1612,15 +1613,26 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
             y[2 * q] = x[2 * q] * co - x[2 * q + 1] * si;
             y[2 * q + 1] = x[2 * q + 1] * co + x[2 * q] * si;
           }
-          if (m < M) {
-            if (P.qkv_q8) {                              // e4m3 rows (x the tensor's scale) for lx_attn_fwd_fp8 instead of the bf16 outputs
-              const float sc8 = qkind == 0 ? P.qkv_k_scale : P.qkv_q_scale;
-              u32x2 o8 = {pack_fp8x4(y[0] * sc8, y[1] * sc8, y[2] * sc8, y[3] * sc8), pack_fp8x4(y[4] * sc8, y[5] * sc8, y[6] * sc8, y[7] * sc8)};
-              *(u32x2*)((qkind == 0 ? (uint8_t*)P.qkv_k8 : (uint8_t*)P.qkv_q8) + (size_t)m * P.qkv_ld8 + (ncol - qkind * D)) = o8;
-            } else {
-              u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-              *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
-            }
+        }
+        // the four row stores back to back, the output kind decided ONCE per block (a tile-uniform branch inside the row loop costs a
+        // wait at every join: the parked-store branch of the fp32 path cost 4 us per round)
+        if (P.qkv_q8) {                                  // e4m3 rows (x the tensor's scale) for lx_attn_fwd_fp8 instead of the bf16 outputs
+          const float sc8 = qkind == 0 ? P.qkv_k_scale : P.qkv_q_scale;
+          uint8_t* const o8p = (qkind == 0 ? (uint8_t*)P.qkv_k8 : (uint8_t*)P.qkv_q8) + (ncol - qkind * D);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int m = mb + t * 4 + (lane >> 4);
+            const float (&y)[8] = yy[t];
+            u32x2 o8 = {pack_fp8x4(y[0] * sc8, y[1] * sc8, y[2] * sc8, y[3] * sc8), pack_fp8x4(y[4] * sc8, y[5] * sc8, y[6] * sc8, y[7] * sc8)};
+            if (m < M) *(u32x2*)(o8p + (size_t)m * P.qkv_ld8) = o8;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int m = mb + t * 4 + (lane >> 4);
+            const float (&y)[8] = yy[t];
+            u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+            if (m < M) *(u32x4*)(out + (size_t)m * out_ld + ncol) = o;
           }
         }
       }
@@ -1725,7 +1737,7 @@ static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64
 struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8, sk_tail_div; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0), env_int("LX_GEMM4_TAIL_DIV", 3)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0), env_int("LX_GEMM4_TAIL_DIV", 0)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1921,7 +1933,12 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && kt_all >= 16 &&
                            tail > 0 && tail * 2 <= 256 && tail * 2 <= NCU && rounds < 8;
     bool split_all = can_split && full == 0 && kt_all >= env.pair_min_kt;      // (the pair kernel's shapes)
-    bool split_tail = can_split && full > 0 && tail * env.sk_tail_div <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
+    // a tail of up to a third of a round; up to half a round where the exchange is a small part of the tile: long K (>= 96 K tiles) and no
+    // q/k/v epilogue in the launch (the 1024 x 1024 batch-4 N = 3072 projections, 1632 tiles = 6 rounds + 96: 0.2594 / 0.2584 -> 0.2651 /
+    // 0.2650 images/s, profiles/r04z_*; the double blocks' q/k/v launch at batch 1, 104 tail tiles at K = 3072: 146 vs 136 us for the
+    // 8-wave mixed plan's half-height tiles -- stays there). LX_GEMM4_TAIL_DIV = d forces tail * d <= CUs (A/B).
+    const int tail_div = env.sk_tail_div > 0 ? env.sk_tail_div : (!qkv && kt_all >= 96 ? 2 : 3);
+    bool split_tail = can_split && full > 0 && tail * tail_div <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
     if (split) {
       // precise mode (two or three passes over K: the K-independent cost of a round and of the exchange weigh a third as much as on the
       // bf16 path; no q/k/v epilogue, no mixed plan to compete with): by cost -- measured slopes per K tile and round, 1.31 us for this

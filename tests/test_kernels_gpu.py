@@ -148,6 +148,26 @@ def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
         assert relerr(got.cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("bm", PLANS)
+@pytest.mark.parametrize("rpb", [8, 24, 40])
+def test_gemm_gate_rows_straddling_batches(ops, bm, rpb, monkeypatch):
+    """Gated residual with batches that do not line up with the kernels' row blocks: 24 / 40 rows per batch put a batch boundary inside
+    16- and 32-row blocks (lx_gemm4_kernel keeps two gate vectors per block: its first and last row's), 8 rows per batch is below
+    what that form handles (the planner keeps such launches on the 8-wave kernels)."""
+    ws = _plan(monkeypatch, bm)
+    nb, N, K = 7, 512, 128
+    M = nb * rpb
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3, scale=0.1)
+    gate = rnd(nb, N, seed=4)
+    X = rnd(M, N, seed=5)
+    X0 = X.clone()
+    ops.gemm([ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=rpb)], ws)
+    ref = X0 + gate.repeat_interleave(rpb, dim=0) * (A.float() @ W.float().T + bias)
+    assert relerr(X.cpu(), ref.cpu()) < 2e-5
+
+
 def test_gemm_lora_module_offsets(ops):
     """Fused [k|v|q|mlp]-style output: LoRA column blocks pick their own r-slice of t."""
     M, K, r, mod = 200, 128, 4, 256

@@ -85,7 +85,11 @@ SMALL = dict(in_channels=3, out_channels=3, latent_channels=16, block_out_channe
 @pytest.mark.parametrize("cfg,hw", [(SMALL, 32), (dict(), 64)])
 def test_vae_encode_decode_vs_oracle(ops, cfg, hw):
     """Whole encoder and decoder (resnets, down / up samplers, mid-block attention, output heads) vs the fp32 oracle; the second
-    case is the full FLUX.1 VAE shape (128, 256, 512, 512) x 2 layers, 84 M parameters."""
+    case is the full FLUX.1 VAE shape (128, 256, 512, 512) x 2 layers, 84 M parameters. The VAE computes in bf16 (im2col + the DiT's
+    bf16 MFMA GEMM, bf16 activations between layers); measured on MI355X (round-4 audit, LX_TEST_RECORD): latent mean 6.9e-3 / 1.09e-2
+    (small / full shape), std 1.5e-3 / 2.2e-3, sample 2.9e-3 / 4.4e-3, decoded image 7.0e-3 / 1.27e-2 -- the bounds are 2x those, and never above the 2e-2 of the earlier rounds."""
+    full = not cfg
+    b_mean, b_std, b_smp, b_img = (2e-2, 4.5e-3, 9e-3, 2e-2) if full else (1.4e-2, 3e-3, 6e-3, 1.4e-2)
     ref, lx = _pair(cfg, seed=3)
     nd = len(ref.config.block_out_channels) - 1
     img = torch.rand(2, 3, hw, hw, generator=torch.Generator().manual_seed(1)) * 2 - 1
@@ -93,15 +97,15 @@ def test_vae_encode_decode_vs_oracle(ops, cfg, hw):
         want = ref.encode(img).latent_dist
     got = lx.encode(img.to(DEV)).latent_dist
     assert got.mean.shape == (2, 16, hw >> nd, hw >> nd)
-    assert relerr(got.mean.cpu(), want.mean) < 2e-2 and relerr(got.std.cpu(), want.std) < 2e-2
+    assert relerr(got.mean.cpu(), want.mean) < b_mean and relerr(got.std.cpu(), want.std) < b_std
     noise = torch.randn(want.mean.shape, generator=torch.Generator().manual_seed(2))
-    assert relerr(got.sample(noise=noise.to(DEV)).cpu(), want.sample(noise=noise)) < 2e-2
+    assert relerr(got.sample(noise=noise.to(DEV)).cpu(), want.sample(noise=noise)) < b_smp
     z = torch.randn(2, 16, hw >> nd, hw >> nd, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         wimg = ref.decode(z, return_dict=False)[0]
     gimg = lx.decode(z.to(DEV), return_dict=False)[0]
     assert gimg.shape == (2, 3, hw, hw) and gimg.dtype == torch.float32
-    assert relerr(gimg.cpu(), wimg) < 2e-2
+    assert relerr(gimg.cpu(), wimg) < b_img
     assert torch.equal(gimg, lx.decode(z.to(DEV)).sample)        # deterministic
 
 

@@ -38,6 +38,8 @@ if has legs; then
   [[ -f $O/pmc_traffic.json ]] || cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json
   pmc_pair l2 b16_hw32 --config 2
   python $R/tools/pmc_traffic.py /tmp/l2_f/p_results.db /tmp/l2_w/p_results.db "profiles/${TAG}_b16_hw32_pmc_FETCH.txt + ${TAG}_b16_hw32_pmc_WRITE.txt" b16_hw32 $O/pmc_traffic.json > $O/pmc_traffic.tmp && mv $O/pmc_traffic.tmp $O/pmc_traffic.json
+  pmc_pair lp b1_hw32_precise --precise
+  python $R/tools/pmc_traffic.py /tmp/lp_f/p_results.db /tmp/lp_w/p_results.db "profiles/${TAG}_b1_hw32_precise_pmc_FETCH.txt + ${TAG}_b1_hw32_precise_pmc_WRITE.txt" b1_hw32_precise $O/pmc_traffic.json > $O/pmc_traffic.tmp && mv $O/pmc_traffic.tmp $O/pmc_traffic.json
   pmc_pair l4 b4_hw64 --hw 64 --batch 4
   python $R/tools/pmc_traffic.py /tmp/l4_f/p_results.db /tmp/l4_w/p_results.db "profiles/${TAG}_b4_hw64_pmc_FETCH.txt + ${TAG}_b4_hw64_pmc_WRITE.txt" b4_hw64 $O/pmc_traffic.json > $O/pmc_traffic.tmp && mv $O/pmc_traffic.tmp $O/pmc_traffic.json
 fi
