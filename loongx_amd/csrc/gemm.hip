@@ -1734,10 +1734,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (LX_GEMM_BM, LX_GEMM_PAIR, LX_GEMM_PAIR_MIN_KT, LX_GEMM_MIXED_ONE_GRID)
-struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8, sk_tail_div; };
+struct GemmEnv { int bm, pair, pair_min_kt, one_grid, g4, sk, g4_fault, g4_q8, sk_tail_div, sk_max_rounds; };
 static GemmEnv read_gemm_env() {
   return GemmEnv{env_int("LX_GEMM_BM", 0), env_int("LX_GEMM_PAIR", 1), env_int("LX_GEMM_PAIR_MIN_KT", 96), env_int("LX_GEMM_MIXED_ONE_GRID", 1),
-                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0), env_int("LX_GEMM4_TAIL_DIV", 0)};
+                 env_int("LX_GEMM4", 1), env_int("LX_GEMM4_SK", 1), env_int("LX_GEMM4_FAULT", 0), env_int("LX_GEMM4_Q8", 0), env_int("LX_GEMM4_TAIL_DIV", 0), env_int("LX_GEMM4_SK_ROUNDS", 16)};
 }
 static GemmEnv g_gemm_env = read_gemm_env();
 static const GemmEnv& gemm_env() { return g_gemm_env; }
@@ -1925,13 +1925,15 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     bool fills = env.g4 == 2 || (t256 >= NCU && (rounds * NCU - t256 <= NCU / 4 || rounds >= 8));
     // split form (LX_GEMM4_SK = 1 default | 0 off): the tiles of a partial last round, or all tiles of a launch with <= 128 of them and
     // a long K, by two workgroups each (half of K), meeting through the caller's workspace. One K for the whole launch, >= 16 K tiles.
+    // (launches of up to LX_GEMM4_SK_ROUNDS = 16 rounds: 7 until round 4 -- at batch 16 the N = 3072 projections are 1920 tiles = 7.5 rounds,
+    //  whole tiles paid the half-empty eighth round: configs[2] 1.1318 / 1.1288 -> 1.1419 / 1.1418 images/s, profiles/r04aa_*)
     bool uniform_k4 = true;
     for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].K == problems[0].K;
     const long tail = t256 % NCU, full = t256 - tail;
     for (int i = 1; i < n; ++i) uniform_k4 = uniform_k4 && problems[i].k_segs == problems[0].k_segs;
     const int kt_all = kmax / BK;                      // K tiles of a tile, all segments of a split-bf16 problem counted
     const bool can_split = env.sk && workspace && ws_bytes >= SK_WS_BYTES && ((uintptr_t)workspace & 255) == 0 && uniform_k4 && kt_all >= 16 &&
-                           tail > 0 && tail * 2 <= 256 && tail * 2 <= NCU && rounds < 8;
+                           tail > 0 && tail * 2 <= 256 && tail * 2 <= NCU && rounds <= env.sk_max_rounds;
     bool split_all = can_split && full == 0 && kt_all >= env.pair_min_kt;      // (the pair kernel's shapes)
     // a tail of up to a third of a round; up to half a round where the exchange is a small part of the tile: long K (>= 96 K tiles) and no
     // q/k/v epilogue in the launch (the 1024 x 1024 batch-4 N = 3072 projections, 1632 tiles = 6 rounds + 96: 0.2594 / 0.2584 -> 0.2651 /
