@@ -5,8 +5,8 @@ sc1 loads, a bounded spin on a flag; gemm.hip). A stale read would not time out 
     python tools/race_screen_g4.py [--runs 2000] [--no-side]
 
 For each launch shape that takes the split form with the default plans -- ff2 (K = 12288), the single blocks' proj_out (K = 15360)
-and the fused single-block projection (N = 21504, LX_EPI_QKV epilogue, split tail) at batch 1, and the same three at the
-1024x1024 row counts -- RUNS back-to-back launches on identical inputs are compared bit for bit with the first, while a second
+and the fused single-block projection (N = 21504, LX_EPI_QKV epilogue, split tail) at batch 1, the same three at the
+1024x1024 row counts, the multi-round split tails of the 1024x1024 batch-4 and batch-16 shapes, and two split-bf16 (precise mode) launches -- RUNS back-to-back launches on identical inputs are compared bit for bit with the first, while a second
 stream with its OWN workspace keeps ff1-sized launches (N = 12288, K = 3072) in flight, as the engine's second stream does.
 Then, in a child process with LX_GEMM4_FAULT=1 (the parked half never raises its flag), the owner's bounded wait has to report the
 time-out through the workspace's error word (ops.gemm_workspace_status raises)."""
@@ -41,6 +41,25 @@ def resid_problem(M, K):
     def fn(ws):
         C.copy_(X0)
         ops.gemm([ops.gemm_desc(A, W, C, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=M)], workspace=ws)
+        return C
+    return fn
+
+
+def split_bf16_problem(M, K, segs=3):
+    """The precise mode's gated-residual launch on lx_gemm4_kernel<true>: A as a hi / lo pair, W = [W_hi | W_lo] (three K segments)."""
+    A = torch.randn(M, K, device=dev)
+    A2 = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device=dev)
+    ops.split_bf16(A.contiguous(), A2, K)
+    W = torch.randn(D, K, device=dev) * 0.02
+    hi = W.to(torch.bfloat16)
+    Wd = ops.tile_weight(torch.cat([hi, (W - hi.float()).to(torch.bfloat16)], 1).contiguous() if segs == 3 else hi.contiguous())
+    bias, gate, X0 = torch.randn(D, device=dev), torch.randn(1, D, device=dev), torch.randn(M, D, device=dev)
+    C = torch.empty_like(X0)
+
+    def fn(ws):
+        C.copy_(X0)
+        ops.gemm([ops.gemm_desc(A2, Wd, C, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=M, K=K, N=D, k_segs=segs, a_lo_off=K)],
+                 workspace=ws)
         return C
     return fn
 
@@ -102,7 +121,11 @@ cases = [("ff2 M=2560 K=12288 (batch 1, 120 tiles: every tile split)", lambda: r
          ("fused [k|v|q|mlp] projection M=2560 N=21504 K=3072, LX_EPI_QKV (840 tiles: split tail)", lambda: fused_projection(1, (512, 1024, 1024))),
          ("ff2 M=8704 K=12288 (1024x1024, batch 1)", lambda: resid_problem(8704, 4 * D)),
          ("single proj_out M=8704 K=15360", lambda: resid_problem(8704, 5 * D)),
-         ("fused projection M=8704 N=21504 K=3072, LX_EPI_QKV", lambda: fused_projection(1, (512, 4096, 4096)))]
+         ("fused projection M=8704 N=21504 K=3072, LX_EPI_QKV", lambda: fused_projection(1, (512, 4096, 4096))),
+         ("ff2 M=34816 K=12288 (1024x1024 batch 4: 1632 tiles = 6 rounds + a 96-tile split tail)", lambda: resid_problem(34816, 4 * D)),
+         ("ff2 M=40960 K=12288 (batch 16: 1920 tiles = 7 rounds + a 128-tile split tail)", lambda: resid_problem(40960, 4 * D)),
+         ("precise to_out M=2560 K=3072 x 3 segments (lx_gemm4_kernel<true>, every tile split)", lambda: split_bf16_problem(2560, D)),
+         ("precise ff2 M=2560 K=12288 x 3 segments", lambda: split_bf16_problem(2560, 4 * D))]
 bad_total = 0
 for name, make in cases:
     fn = make()
