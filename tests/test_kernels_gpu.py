@@ -247,6 +247,28 @@ def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
     ops.gemm_workspace_status(ws)
 
 
+def test_gemm4_split_form_with_a_ragged_tile_row(ops):
+    """Default plans: a long-K launch of 60 tiles goes through lx_gemm4_kernel's split form (two workgroups per tile, each parking the
+    four row blocks the other one finishes). The last tile row has 96 of 256 rows: in it part 0 owns blocks 0-3 of the upper waves and
+    parks only two live blocks, the lower waves have nothing at all. Gated fp32 residual against fp32, and bit-identical run to run."""
+    ws = _ws()
+    M, N, K = 2400, 1536, 6144
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = ops.tile_weight(rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16))
+    Wr = ops.untile_weight(W)
+    bias, gate, X0 = rnd(N, seed=3, scale=0.1), rnd(3, N, seed=4), rnd(M, N, seed=5)
+
+    def run():
+        X = X0.clone()
+        ops.gemm([ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=800)], ws)
+        return X
+    X = run()
+    ref = X0 + gate.repeat_interleave(800, 0) * (A.float() @ Wr.float().T + bias)
+    assert relerr(X.cpu(), ref.cpu()) < 2e-5
+    assert torch.equal(X, run())
+    ops.gemm_workspace_status(ws)
+
+
 def test_gemm_workspace_error_word_position(ops):
     """The engine polls the workspace's error word asynchronously (FluxEngine.check_status(sync=False)) at a FIXED position: the int 64
     ints before the end (include/lx.h). Raising it by hand must be what lx_gemm_workspace_status reports -- and resets."""
