@@ -55,6 +55,7 @@ n2 = 256 * 8
 host2 = (ctypes.c_ulonglong * n2)()
 assert _lib.lib.lx_g4_probe_read(host2, n2) == 0
 t2 = torch.tensor(list(host2), dtype=torch.float64).view(256, 8) * 0.01
+row("whole tiles: start -> first DMA piece issued [7-0]", t2[:, 7] - t2[:, 0])
 row("whole tiles: start -> K tile 0 landed [1-0]", t2[:, 1] - t2[:, 0])
 row("whole tiles: fragment reads [2-1]", t2[:, 2] - t2[:, 1])
 row("whole tiles: main loop [3-2]", t2[:, 3] - t2[:, 2])
