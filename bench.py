@@ -92,14 +92,17 @@ def cpu_baseline(threads: int):
     pe_t, pooled_t = torch.randn(1, 512, 4096, generator=g) * 0.1, torch.randn(1, 768, generator=g)
     ids_t = fm.prepare_latent_image_ids(hw_t, hw_t)
     cids_t = ids_t.clone(); cids_t[:, 2] -= hw_t
+    tiny_threads = min(threads, 16)      # (small operands: with 256 threads the thread pool's hand-offs dominate -- 280 s instead of seconds)
+    torch.set_num_threads(tiny_threads)
     with torch.no_grad():
         t0 = time.time()
         out = fr.denoise_loop(tiny, fm.FlowMatchEulerDiscreteScheduler(), lat, pe_t, pooled_t, torch.zeros(512, 3), ids_t, cnd, cids_t, num_inference_steps=4)
         t_tiny = time.time() - t0
+    torch.set_num_threads(threads)
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32: 1 double block ({td:.2f}s) + 1 single block ({ts:.2f}s) at full width B=1 S=2560, "
                       f"extrapolated x(19,38) blocks x28 steps",
-            "tiny_measured": {"seconds": round(t_tiny, 3), "images_per_s": round(1.0 / t_tiny, 4), "finite": bool(torch.isfinite(out).all()),
+            "tiny_measured": {"seconds": round(t_tiny, 3), "images_per_s": round(1.0 / t_tiny, 4), "cores": tiny_threads, "finite": bool(torch.isfinite(out).all()),
                               "config": "oracle.flux_ref.denoise_loop end to end, measured: 2 double + 2 single blocks, 2 heads x 128 (D = 256), "
                                         "512 text + 256 image + 256 condition tokens, 4 steps, fp32, batch 1"}}
 
