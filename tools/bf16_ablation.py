@@ -36,10 +36,13 @@ from oracle import flux_ref as fr
 from oracle.parity import build_pair, relerr
 
 ACTIVE = set()
+FMT = {"gemm": torch.bfloat16, "attn": torch.bfloat16}     # the 16-bit format of the GEMM A operands / of q, k, v, P (--fmt)
 
 
-def r16(x):
-    return x.to(torch.bfloat16).to(x.dtype)
+def r16(x, which="gemm"):
+    if FMT[which] == torch.float16:      # saturating, as the product's converts are
+        x = x.clamp(-65504.0, 65504.0)
+    return x.to(FMT[which]).to(x.dtype)
 
 
 def hook_inputs(mod, kind):
@@ -71,6 +74,11 @@ def tag(tr):
         for m in (b.attn.to_q, b.attn.to_k, b.attn.to_v, b.proj_mlp):
             lin(m, "s_fused")
         lin(b.proj_out, "s_out")
+    # round 5: the three GEMMs outside the blocks whose A operand the product also stores in 16 bits (the first pass of this tool
+    # left them out: they are the 2e-3 between its "every site" row and the engine)
+    lin(tr.x_embedder, "x_emb")                      # latents / condition latents -> D
+    hook_inputs(tr.context_embedder, "ctx_emb")      # T5 states -> D
+    hook_inputs(tr.proj_out, "final")                # norm_out's output -> 64 channels
 
 
 class FProxy:
@@ -84,9 +92,9 @@ class FProxy:
         if not ({"attn_qk", "attn_v", "attn_p", "attn_explicit"} & ACTIVE):
             return TF.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
         if "attn_qk" in ACTIVE:
-            q, k = r16(q), r16(k)
+            q, k = r16(q, "attn"), r16(k, "attn")
         if "attn_v" in ACTIVE:
-            v = r16(v)
+            v = r16(v, "attn")
         out = torch.empty_like(q)
         scale = q.shape[-1] ** -0.5
         for h0 in range(0, q.shape[1], 4):                       # four heads at a time: [4, S, S] fp32 scores
@@ -96,12 +104,14 @@ class FProxy:
             p = torch.exp(s - s.amax(dim=-1, keepdim=True))      # (rounding to bf16 is scale-free up to the position in the binade)
             l = p.sum(dim=-1, keepdim=True)
             if "attn_p" in ACTIVE:
-                p = r16(p)
+                p = r16(p, "attn")
             out[:, h0:h0 + 4] = (p @ v[:, h0:h0 + 4]) / l
         return out
 
 
-SITES = ["d_qkv", "d_out", "d_ff1", "d_ff2", "s_fused", "s_out", "attn_qk", "attn_v", "attn_p"]
+SITES = ["d_qkv", "d_out", "d_ff1", "d_ff2", "s_fused", "s_out", "attn_qk", "attn_v", "attn_p", "x_emb", "ctx_emb", "final"]
+GEMM_SITES = SITES[:6] + SITES[9:]
+ATTN_SITES = SITES[6:9]
 
 
 @torch.no_grad()
@@ -110,6 +120,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bf16_ablation.json"))
     ap.add_argument("--steps", default="0,13,27")
     ap.add_argument("--quick", action="store_true", help="2 + 2 blocks (plumbing check)")
+    ap.add_argument("--fmt", default="bf16", choices=["bf16", "fp16", "both"], help="16-bit operand format of the GEMM A operands")
+    ap.add_argument("--short", action="store_true", help="skip the leave-one-out rows")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     nl, ns = (2, 2) if a.quick else (19, 38)
@@ -159,15 +171,25 @@ def main():
 
     measure("fp32 oracle through the explicit-softmax path (no rounding)", {"attn_explicit"})      # (sanity: the hooks themselves are exact)
     ACTIVE.clear()
-    one = {s: measure(f"only {s} rounded to bf16", {s}) for s in SITES}
-    every = measure("every site rounded (model of the bf16 mode)", set(SITES))
-    rss = float(np.sqrt(sum(v * v for v in one.values())))
-    print(f"root-sum-square of the single-site errors: {rss:.4e} (independent roundings add in quadrature)")
-    for s in SITES:
-        measure(f"every site but {s}", set(SITES) - {s})
-    measure("GEMM A operands only (d_qkv d_out d_ff1 d_ff2 s_fused s_out)", set(SITES[:6]))
-    measure("attention operands only (q k v P)", set(SITES[6:]))
-    measure("every site but the two largest", set(SITES) - set(sorted(one, key=one.get)[-2:]))
+    summary = {}
+    for fmt in (["bf16", "fp16"] if a.fmt == "both" else [a.fmt]):
+        FMT["gemm"] = FMT["attn"] = torch.float16 if fmt == "fp16" else torch.bfloat16
+        one = {s: measure(f"[{fmt}] only {s} rounded", {s}) for s in SITES}
+        every = measure(f"[{fmt}] every site rounded (model of the {fmt}-operand mode)", set(SITES))
+        rss = float(np.sqrt(sum(v * v for v in one.values())))
+        print(f"[{fmt}] root-sum-square of the single-site errors: {rss:.4e} (independent roundings add in quadrature)")
+        gemm_only = measure(f"[{fmt}] GEMM A operands only ({' '.join(GEMM_SITES)})", set(GEMM_SITES))
+        attn_only = measure(f"[{fmt}] attention operands only (q k v P)", set(ATTN_SITES))
+        summary[fmt] = {"every": every, "rss": rss, "gemm_only": gemm_only, "attn_only": attn_only, "one": one}
+        if not a.short:
+            for s in SITES:
+                measure(f"[{fmt}] every site but {s}", set(SITES) - {s})
+            measure(f"[{fmt}] every site but the two largest", set(SITES) - set(sorted(one, key=one.get)[-2:]))
+    if a.fmt in ("fp16", "both"):
+        # the mode the review proposes: fp16 GEMM A operands, attention operands (q, k, v, P) still bf16
+        FMT["gemm"], FMT["attn"] = torch.float16, torch.bfloat16
+        summary["fp16_gemm_bf16_attn"] = measure("fp16 GEMM A operands + bf16 attention operands (the proposed mode)", set(SITES))
+    FMT["gemm"] = FMT["attn"] = torch.bfloat16
 
     # the engine itself (bf16 mode, default plans) on the same points
     errs = []
@@ -176,7 +198,7 @@ def main():
         errs.append(relerr(tranformer_forward(lx, cond, cids, None, mc0, return_dict=False, **kw)[0], want))
     eng = float(np.mean(errs))
     print(f"{'the engine (bf16 mode)':64s} {eng:.4e}   {['%.3e' % e for e in errs]}")
-    out = {"blocks": [nl, ns], "tokens": [n_txt, N, N], "steps_compared": cmp_steps, "rows": rows, "single_site_rss": round(rss, 6),
+    out = {"blocks": [nl, ns], "tokens": [n_txt, N, N], "steps_compared": cmp_steps, "rows": rows, "summary": summary,
            "engine_bf16_relerr_mean": round(eng, 6), "engine_bf16_relerr_per_step": [round(e, 6) for e in errs]}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
