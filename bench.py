@@ -222,6 +222,7 @@ def workload_name(cfg_no, B, hw, allmod, mc, precise):
     return (f"{tag}: " + ("EEG-only CS3 conditioning" if not allmod else "EEG+fNIRS+PPG+motion CS3 + DGF fusion") +
             f", {16 * hw}x{16 * hw} edit (512 txt + {N} img + {N} cond tokens), 28 steps, FLUX.1-dev shape (19+38 blocks, D=3072), "
             "LoRA r=4 on the condition stream" + (", precise mode" if precise else "") +
+            (", fp16 GEMM operand images" if str(mc.get("operands", "bf16")) == "fp16" else "") +
             (", fp8 GEMM + attention paths" if (mc.get("gemm_fp8") and mc.get("attn_fp8")) else ", fp8 GEMM path (lossy: 1e-1 per forward)" if mc.get("gemm_fp8")
              else ", fp8 (e4m3) attention path, bf16 GEMMs" if mc.get("attn_fp8") else "") +
             (", model_config independent_condition (condition stream computed once per image: flops counted as executed)" if mc.get("independent_condition") else ""))
@@ -295,9 +296,11 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
     elapsed_ms = lxd.barrier_max_ms(elapsed_ms, dev)
     model.transformer.engine.check_status(sync=True)              # a split-K pair time-out would invalidate the region
     finite = bool(torch.isfinite(out).all())
+    f16_sat = model.transformer.engine.f16_overflow_count() if model.transformer.engine.f16 else None
     if rank != 0:
         return None
     gemm_fp8, attn_fp8 = bool(mc.get("gemm_fp8")), bool(mc.get("attn_fp8"))
+    f16 = bool(model.transformer.engine.f16)
     images = world * B * steps
     value = images / (elapsed_ms / 1e3)
     cached = mc.get("independent_condition") and model.flux_pipe.transformer.engine.cond_cache
@@ -308,8 +311,9 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
     f_attn = STEPS * 57 * 4.0 * S_tok * S_tok * D
     res = {"value": round(value, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed_ms / steps, 2),
            "dtype": ("bf16 x2 split (fp32-class)" if precise else "fp8 e4m3 MFMA operands" if gemm_fp8 else
-                     "bf16 GEMMs, fp8 e4m3 attention" if attn_fp8 else "bf16"),
-           "batch_per_gpu": B, "outputs_finite": finite,
+                     ("fp16" if f16 else "bf16") + " GEMMs, fp8 e4m3 attention" if attn_fp8 else
+                     "fp16 GEMM operands (bf16 attention operands), fp32 accumulate" if f16 else "bf16"),
+           "batch_per_gpu": B, "outputs_finite": finite, **({"f16_saturated_waves": f16_sat} if f16_sat is not None else {}),
            "model_tflops_per_gpu": round(value * fpi / world / 1e12, 1),
            "mfma_frac_end_to_end": round(value * fpi / world / 1e12 / peak_e2e, 4)}
     if attn_fp8 and not gemm_fp8 and not cached:
@@ -331,7 +335,10 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
         traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}" + ("_precise" if precise else ""))
         gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
                  "lx_gemm4_kernel<true> / lx_gemm_split_kernel (split-bf16 operands on the bf16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
+                 "lx_gemm_* (fp16 MFMA operands: v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fused epilogues; launch-weighted over the 8-wave kernels and lx_gemm4_kernel)" if f16 else
                  "lx_gemm_* (bf16 MFMA, fused epilogues; launch-weighted over the 8-wave 32x32x16 kernels and lx_gemm4_kernel, the one-wave-per-SIMD 16x16x32 form)")
+        if f16:
+            traffic, traffic_src = None, None          # (same bytes by construction -- 16-bit images of the same shapes -- but the committed PMC passes are of the bf16 kernels)
         if gemm_fp8:
             traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 / split-bf16 kernels (the fp8-attention mode runs the bf16 GEMMs)
         res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),
@@ -393,6 +400,9 @@ def main():
                     help="model_config independent_condition (block.py:115-120): the condition queries see only condition keys, so the "
                          "condition stream is step-invariant and the engine computes it once per image (not the metric's configuration)")
     ap.add_argument("--modalities", type=str, default=None, help="eeg (configs[1]) | all (EEG+fNIRS+PPG+motion, CS3+DGF fuse: configs[2]/[3])")
+    ap.add_argument("--operands", type=str, default=None, choices=("bf16", "fp16"),
+                    help="16-bit format of the GEMM operand images: bf16 (default) | fp16 (v_mfma_f32_*_f16, same rate, 11 significand bits: the "
+                         "north star's 1e-3 per forward; model_config[\"operands\"])")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(a.gpus))
@@ -410,7 +420,7 @@ def main():
     from loongx_amd.flux.weights import FluxConfig, synthetic_weights
 
     # ---- workload -------------------------------------------------------------------------------------------------------------
-    plain = not (a.config or a.batch or a.hw or a.modalities or a.precise or a.fp8 or a.attn_fp8 or a.gemm_fp8 or a.independent_condition)
+    plain = not (a.config or a.batch or a.hw or a.modalities or a.precise or a.fp8 or a.attn_fp8 or a.gemm_fp8 or a.independent_condition or a.operands)
     mc = {"union_cond_attn": True}
     cfg_no = a.config
     if a.config:
@@ -431,6 +441,8 @@ def main():
         mc["gemm_fp8"] = True
     if a.independent_condition:
         mc["independent_condition"] = True
+    if a.operands:
+        mc["operands"] = a.operands
 
     cfg = FluxConfig()
     t0 = time.time()
@@ -457,7 +469,7 @@ def main():
         res.update(rec)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-        xmc = {k: True for k in ("attn_fp8", "gemm_fp8", "independent_condition") if mc.get(k)}
+        xmc = {k: mc[k] for k in ("attn_fp8", "gemm_fp8", "independent_condition", "operands") if mc.get(k)}
         if world == 1 and not a.no_parity:
             try:
                 # the brain side is part of the checked composition, as it is part of the timed workload (batch 1 per checker run)

@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 303 /* 0.3.3: + lx_attn_last_kernel (which attention kernel lx_attn_fwd launched: the one-wave-per-SIMD lx_attn4_kernel serves multi-round bounded-score launches); no layout change. 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
+#define LX_VERSION 400 /* 0.4.0: fp16 operand format (LX_OPERANDS_F16, lx_gemm_desc.f16_ovf in col_scale's slot, LX_ATTN_O_F16 + lx_attn_desc.f16_ovf appended, + lx_ln_modulate_f16_segs, lx_lora_down_f16, lx_convert dst 2 = fp16); the split-K pair kernel and its area of the workspace are gone (lx_gemm_workspace_bytes() shrank; the error word is still the int 64 ints before the end).
+                          * 0.3.3: 0.3.3: + lx_attn_last_kernel (which attention kernel lx_attn_fwd launched: the one-wave-per-SIMD lx_attn4_kernel serves multi-round bounded-score launches); no layout change. 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
                           * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
 
 typedef enum lx_status {
@@ -66,9 +67,17 @@ enum {
                           * norm_q) + RoPE to the k and q columns in fp32 BEFORE the single bf16 rounding and stores them in place,
                           * and writes the v columns straight into the V^T image the attention kernel reads (and nowhere else):
                           * lx_qkv_prep of the same buffer is then not needed. See the qkv_* fields. */
-  LX_OPERANDS_FP8 = 0x800 /* OR-able flag: A and W are OCP e4m3 bytes (lda / ldw in bytes, K % 128 == 0), products on the
+  LX_OPERANDS_FP8 = 0x800, /* OR-able flag: A and W are OCP e4m3 bytes (lda / ldw in bytes, K % 128 == 0), products on the
                             64-deep f8f6f4 MFMA at twice the bf16 rate; acc[m,n] *= col_scale[n] before everything else.
                             BASELINE configs[4]; opt-in (model_config["gemm_fp8"]). Every problem of a launch must carry it. */
+  LX_OPERANDS_F16 = 0x2000 /* OR-able flag: A and W are IEEE fp16 (same 16-bit layouts, tiling and leading dimensions as bf16), products on
+                            v_mfma_f32_*_f16 at the bf16 rate, fp32 accumulate: 11 significand bits on the operands instead of 8 -- the
+                            reference computes every Linear in fp32 (train/config/seed_512.yaml:2) and the bf16 mode's whole per-forward
+                            error is the 8-bit rounding of the A operands (tools/bf16_ablation.py). A 16-bit store (LX_EPI_STORE_BF16 kind)
+                            then writes fp16 as well -- the next GEMM's operand -- rounded to nearest even and SATURATED to +-65504; the
+                            launch adds the number of producer waves that clipped a value to *f16_ovf (when non-NULL). LX_EPI_QKV outputs
+                            (k, q, V^T: the attention kernel's operands) stay bf16. Every problem of a launch must carry it; not with
+                            LX_OPERANDS_FP8 / k_segs >= 2 / LX_EPI_SPLIT_BF16. model_config["operands"] = "fp16" / dtype=torch.float16. */
 };
 
 typedef struct lx_gemm_desc {
@@ -95,7 +104,12 @@ typedef struct lx_gemm_desc {
   int32_t k_segs, a_lo_off;
   int32_t c_lo_off;          /* LX_EPI_SPLIT_BF16: column distance of the lo image of the output */
   float out_scale;           /* LX_EPI_STORE_FP8: multiplier applied before the e4m3 rounding */
-  const float* col_scale;    /* LX_OPERANDS_FP8: [N] fp32, 1 / (activation scale * weight scale of row n); NULL => 1 */
+  union {                    /* one pointer slot for the two operand modes that exclude each other (the descriptor travels by value in the
+                              * 4 KiB kernarg segment, eight at a time, twice for the mixed-height plan: it cannot grow) */
+    const float* col_scale;  /* LX_OPERANDS_FP8: [N] fp32, 1 / (activation scale * weight scale of row n); NULL => 1 */
+    int32_t* f16_ovf;        /* LX_OPERANDS_F16 with a 16-bit store: device counter, += the number of producer waves of this launch that
+                              * saturated a value to +-65504 (NULL: not reported). Zeroed and read by the caller. */
+  };
   /* LX_EPI_QKV (replaces lx_qkv_prep for this problem's rows; block.py:60-99 attn.norm_q / norm_k + apply_rotary_emb):
    * columns [0, qkv_d) = k, [qkv_d, 2 qkv_d) = v, [2 qkv_d, 3 qkv_d) = q; qkv_d % 256 == 0; rows_per_batch % 32 == 0 (one
    * token stream: row m is position (m % rows_per_batch) of batch m / rows_per_batch); N may stop short of 3 qkv_d at a
@@ -163,6 +177,9 @@ int lx_gemm_workspace_status(void* workspace, void* stream);
  * spreads a tall-skinny product over the whole chip without atomics; the consumer (lx_gemm_bf16) adds the slabs. */
 int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
                  int split_stride, void* stream);
+/* The same on fp16 images of X and Adown (the operands of an LX_OPERANDS_F16 launch; v_mfma_f32_16x16x32_f16) */
+int lx_lora_down_f16(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                     int split_stride, void* stream);
 /* The multi-term form (precise mode: x = x_hi + x_lo, A = A_hi [+ A_lo]): slab s of T (slab_stride floats apart, same row stride) =
  * X[s][M, K] . Adown[s][R, K]^T over the whole K, for n_terms <= 4 (X, Adown) pairs in ONE launch; the consumer GEMM adds the slabs
  * (lora_nsplit = n_terms). Same arithmetic per slab as lx_lora_down(X[s], ldx[s], Adown[s], T + s * slab_stride, ..., n_split = 1). */
@@ -198,6 +215,10 @@ int lx_ln_modulate(const float* X, int ldx, const float* shift, const float* sca
 typedef struct lx_ln_seg { int32_t row0, n_rows, rows_per_batch, _pad; const float* shift; const float* scale; } lx_ln_seg;
 int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
                         float eps, void* stream);
+/* The same with Y as IEEE fp16 -- the A operand of an LX_OPERANDS_F16 GEMM: rounded to nearest even, saturated to +-65504;
+ * *f16_ovf (device, may be NULL) += the number of waves (= rows) that clipped a value. */
+int lx_ln_modulate_f16_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                            float eps, int32_t* f16_ovf, void* stream);
 /* The same, and for the rows [lora_row0, lora_row0 + lora_rows) of Y (the token streams that run with their adapters on,
  * lora_controller.py:5-42) also the LoRA down-projection of the row just written: T[row - lora_row0, 0..R) (fp32, ldt) =
  * Y_row(bf16) . Adown[R, D]^T (bf16), R <= 16 -- what lx_lora_down(Y rows, Adown, T, n_split = 1) computes, without the
@@ -249,6 +270,7 @@ typedef struct lx_attn_desc {
   int32_t n_qseg;        /* 0 / n_seg: every segment has queries. k < n_seg: only segments 0..k-1 do (keys and values of all n_seg segments
                           * are still attended to): the rows of the other segments of O are not written */
   int32_t flags;         /* LX_ATTN_* below (0 = the plain contract above) */
+  int32_t* f16_ovf;      /* LX_ATTN_O_F16: device counter, += the number of waves that saturated an output value (NULL: not reported) */
 } lx_attn_desc;
 /* LX_ATTN_Q_LOG2: q already carries scale * log2(e) (e.g. folded into the norm_q weight handed to LX_EPI_QKV / lx_qkv_prep): the kernel
  * takes q.k as the exp2 argument as it is (`scale` is ignored).
@@ -260,7 +282,10 @@ typedef struct lx_attn_desc {
 /* LX_ATTN_INVARIANT: the choice of kernel must not depend on the batch size of the launch (the planner otherwise picks between two kernels
  * whose row sums are accumulated in different orders -- equal to rounding, not bit for bit): what a data-parallel shard needs to reproduce
  * the single-GPU batch exactly (the engine sets it together with its batch-size-invariant GEMM plans, LX_PAIR_PLAN=0). */
-enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4 };
+/* LX_ATTN_O_F16: O is written as IEEE fp16 (nearest even, saturated to +-65504) instead of bf16: the A operand of an LX_OPERANDS_F16
+ * output projection (to_out / proj_out). Q, K and V^T stay bf16 (4e-4 of the per-forward budget, tools/bf16_ablation.py). Also accepted
+ * by lx_attn_fwd_fp8 (the only flag it takes). */
+enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4, LX_ATTN_O_F16 = 8 };
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 /* Which kernel the calling thread's last successful lx_attn_fwd launched (a planner decision, exposed for benchmarks and tests):
  * LX_ATTN_KERNEL_8WAVE: the 8-wave kernels of attn.hip (two waves per SIMD, 32 query rows per wave);
@@ -349,7 +374,8 @@ int lx_lora_down_fp8(const void* X8, int ldx, float x_descale, const void* Adown
 
 /* x(fp32) += dsigma * v   (FlowMatchEulerDiscreteScheduler.step, generate.py:349); v is bf16 or fp32 */
 int lx_euler_step(float* x, const void* v, int v_is_bf16, float dsigma, size_t n, void* stream);
-/* dst(fp32)[i] = src(fp32|bf16)[i] ; dst(bf16) = src(fp32) : layout plumbing between streams */
+/* dst(fp32)[i] = src(fp32|bf16)[i] ; dst(bf16) = src(fp32) : layout plumbing between streams. dst_bf16: 0 fp32 | 1 bf16 | 2 IEEE fp16
+ * (saturated to +-65504: the operand image of an LX_OPERANDS_F16 GEMM) */
 int lx_convert(void* dst, int dst_bf16, const void* src, int src_bf16, size_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LX_AMD_LIB", os.path.join(_HERE, "lib", "liblx_amd.so"))
 
 LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_RESID_F32, LX_EPI_GELU, LX_W_TILED, LX_EPI_SPLIT_BF16 = 0, 1, 2, 0x100, 0x200, 0x400
-LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_EPI_QKV = 3, 0x800, 0x1000
+LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_EPI_QKV, LX_OPERANDS_F16 = 3, 0x800, 0x1000, 0x2000
 LX_GEMM_MAX_GROUP = 4
 
 
@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
                 ("lora_toff_max", C.c_int32), ("epilogue", C.c_int32), ("gelu_col_start", C.c_int32),
                 ("lora_nsplit", C.c_int32), ("lora_split_stride", C.c_int32),
                 ("k_segs", C.c_int32), ("a_lo_off", C.c_int32), ("c_lo_off", C.c_int32), ("out_scale", C.c_float),
-                ("col_scale", C.c_void_p),
+                ("col_scale", C.c_void_p),          # (LX_OPERANDS_F16: the same slot is f16_ovf -- a union in lx.h)
                 ("qkv_norm_q", C.c_void_p), ("qkv_norm_k", C.c_void_p), ("qkv_rope", C.c_void_p), ("qkv_vt", C.c_void_p),
                 ("qkv_k", C.c_void_p),
                 ("qkv_d", C.c_int32), ("qkv_vt_ld", C.c_int32), ("qkv_vt_pos0", C.c_int32), ("qkv_k_ld", C.c_int32),
@@ -45,10 +45,11 @@ class AttnDesc(C.Structure):
                 ("q_col", C.c_int32), ("k_col", C.c_int32), ("o_col", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
                 ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
-                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32), ("flags", C.c_int32)]
+                ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32), ("flags", C.c_int32),
+                ("f16_ovf", C.c_void_p)]
 
 
-LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT = 1, 2, 4
+LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT, LX_ATTN_O_F16 = 1, 2, 4, 8
 
 
 class AttnF32Desc(C.Structure):
@@ -80,12 +81,14 @@ _SIGS = {
     "lx_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmDesc), _I, _P, _Z, _P]),
     "lx_gemm_workspace_status": (C.c_int, [_P, _P]),
     "lx_lora_down": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lx_lora_down_f16": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lx_lora_down_terms": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), _I, _P, _I, _I, _I, _I, _I, _P]),
     "lx_linear_skinny": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lx_timestep_embed": (C.c_int, [_P, _P, _I, _I, _P]),
     "lx_rope_table": (C.c_int, [_P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),
     "lx_ln_modulate": (C.c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "lx_ln_modulate_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P]),
+    "lx_ln_modulate_f16_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _P]),
     "lx_ln_modulate_lora_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),

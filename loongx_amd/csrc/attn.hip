@@ -220,8 +220,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const
   // ---- epilogue: O[q, d] = O^T / l ; lane holds d = db*32 + 8*(r>>2) + 4*lhi + (r&3) --------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
+  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -723,8 +722,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
 #endif
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
+  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -908,8 +906,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
+  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -1320,8 +1317,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 #endif
   const float l_tot = __shfl(lacc[0], l31, 64);          // lanes 0-31 hold the sum of query l31
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-  if (q_valid) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi, args.wide_store != 0);
+  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 }  // namespace
@@ -1371,7 +1367,7 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
   hipStream_t st = (hipStream_t)stream;
-  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT | LX_ATTN_O_F16)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
                "lx_attn_fwd: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
   bool any_bias = false;                       // a finite non-zero bias on a pair that is attended to
   for (int s = 0; s < nq; ++s)
@@ -1425,7 +1421,7 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG(d->ldq % 16 == 0 && d->ldk % 16 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd_fp8: ldq/ldk %% 16 (bytes), ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
-  LX_CHECK_ARG(d->flags == 0, "lx_attn_fwd_fp8: flags must be 0 (the e4m3 kernels fold their own scales)");
+  LX_CHECK_ARG((d->flags & ~LX_ATTN_O_F16) == 0, "lx_attn_fwd_fp8: the only flag is LX_ATTN_O_F16 (the e4m3 kernels fold their own scales)");
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
   const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;

@@ -537,8 +537,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       const int q_in_seg = C.q_tile0 + wave * 64 + l31 + 32 * qb;
       const size_t q_row = (size_t)C.q_row0 + min(q_in_seg, C.q_len - 1);
-      // (the swap inside lx_store_o exchanges data between the two half-waves of a row: both halves of a row are valid or invalid together)
-      if (q_in_seg < C.q_len) lx_store_o((uint16_t*)D.O + q_row * D.ldo + D.o_col + C.h * DH, oacc[qb], inv, lhi, args.wide_store != 0);
+      lx_store_o(args, q_in_seg < C.q_len, (uint16_t*)D.O + q_row * D.ldo + D.o_col + C.h * DH, oacc[qb], inv, lhi);
     }
     if (!more) break;
     C = decode(T0.w);

@@ -35,16 +35,19 @@ struct AttnArgs {
 // wide: for each pair of groups (rq, rq+1) one v_permlane32_swap per dword hands the lower half-wave the upper half's group rq and
 // the upper half-wave the lower half's group rq+1: every lane then owns 16 contiguous bytes -> 8 dwordx4 stores per lane instead of
 // 16 dwordx2, same bytes, same addresses (the store tail of a row-per-lane epilogue is store-ISSUE bound: guide T21).
-__device__ __forceinline__ void lx_store_o(uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi, bool wide) {
+// F16 (lx_attn_desc.flags & LX_ATTN_O_F16): O is the fp16 operand image of an LX_OPERANDS_F16 projection (to_out / proj_out), rounded to
+// nearest even and saturated; `mx` collects max |o| for the overflow report.
+template <bool F16>
+__device__ __forceinline__ void lx_store_o_fmt(uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi, bool wide, float& mx) {
   if (wide) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int rq = 0; rq < 4; rq += 2) {
-        const uint32_t a0 = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        const uint32_t a1 = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
-        const uint32_t b0 = pack_bf16x2(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv);
-        const uint32_t b1 = pack_bf16x2(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv);
+        const uint32_t a0 = pack_op16x2<F16>(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, mx);
+        const uint32_t a1 = pack_op16x2<F16>(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, mx);
+        const uint32_t b0 = pack_op16x2<F16>(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv, mx);
+        const uint32_t b1 = pack_op16x2<F16>(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv, mx);
         const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         *(u32x4*)(row + db * 32 + 8 * (rq + lhi)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
@@ -56,10 +59,21 @@ __device__ __forceinline__ void lx_store_o(uint16_t* row, const f32x16 (&oacc)[4
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         u32x2 o;
-        o[0] = pack_bf16x2(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv);
+        o[0] = pack_op16x2<F16>(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, mx);
+        o[1] = pack_op16x2<F16>(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, mx);
         *(u32x2*)(op + db * 32 + rq * 8) = o;
       }
+  }
+}
+// (the swap inside exchanges data between the two half-waves of a row: both halves of a row must be valid or invalid together; `valid`
+//  guards the stores of rows past the segment, `args` names the output format and the overflow word)
+__device__ __forceinline__ void lx_store_o(const AttnArgs& args, bool valid, uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi) {
+  float mx = 0.f;
+  if (args.d.flags & LX_ATTN_O_F16) {
+    if (valid) lx_store_o_fmt<true>(row, oacc, inv, lhi, args.wide_store != 0, mx);
+    report_f16_overflow(mx, (int*)args.d.f16_ovf);
+  } else if (valid) {
+    lx_store_o_fmt<false>(row, oacc, inv, lhi, args.wide_store != 0, mx);
   }
 }
 

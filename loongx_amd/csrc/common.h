@@ -57,6 +57,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+// ---- IEEE fp16 operand images (LX_OPERANDS_F16: 11 significand bits on the matrix pipe's A operand instead of bf16's 8) -------------
+// fp32 pair -> fp16 pair, round-to-nearest-even (v_cvt_pk_f16_f32), SATURATED to +-65504 (v_med3_f32: fp16 has 5 exponent bits; the
+// reference clips its fp16 residual stream the same way, block.py:275-276, 336-337). `mx` collects max |x| of everything converted
+// (v_max3_f32 with |.| modifiers: half an instruction per element) so that the producer can REPORT a saturation instead of hiding it.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define LX_F16_MAX 65504.0f
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float lo, float hi, float& mx) {
+  mx = fmaxf(fmaxf(fabsf(lo), fabsf(hi)), mx);
+  const f16x2 v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -LX_F16_MAX, LX_F16_MAX), (_Float16)__builtin_amdgcn_fmed3f(hi, -LX_F16_MAX, LX_F16_MAX)};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// the 16-bit store of a producer whose consumer is a GEMM: bf16 (the default operand format) or fp16
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi, float& mx) {
+  if constexpr (F16) return pack_f16x2_sat(lo, hi, mx);
+  else return pack_bf16x2(lo, hi);
+}
+// a saturated conversion happened somewhere in this wave's share: count it in the caller's overflow word (NULL: not asked for).
+// One atomic per WAVE that saw one, none otherwise -- the word says "how many producer waves clipped", 0 = the images are exact roundings.
+__device__ __forceinline__ void report_f16_overflow(float mx, int* ovf) {
+  if (ovf != nullptr && __builtin_amdgcn_ballot_w64(mx > LX_F16_MAX) != 0 && (threadIdx.x & 63) == 0) atomicAdd(ovf, 1);
+}
+
 __device__ __forceinline__ float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) == x * sigmoid(2u)
   // v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division here compiles to v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup

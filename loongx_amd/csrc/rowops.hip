@@ -23,9 +23,12 @@ struct LnSegs {   // up to 3 row segments (token streams), each with its own mod
 // bf16 Adown), fp32 accumulation in a different order.
 struct LnLora { const uint16_t* A; float* T; int R, ldt, row0, rows; };
 
-template <int NCH, int RQ = 0>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
+// F16: Y is the fp16 operand image of an LX_OPERANDS_F16 GEMM (nearest even, saturated to +-65504; *f16_ovf counts the waves that clipped).
+template <int NCH, int RQ = 0, bool F16 = false>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
-                                                          uint16_t* __restrict__ Y, int ldy, int M, int D, float eps, const LnLora lo = LnLora{}) {
+                                                          uint16_t* __restrict__ Y, int ldy, int M, int D, float eps, const LnLora lo = LnLora{},
+                                                          int* __restrict__ f16_ovf = nullptr) {
+  static_assert(!(F16 && RQ > 0), "the fused adapter down-projection reads its own bf16 rounding");
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   int sg = 0, acc_rows = 0;
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   uint16_t* yr = Y + (size_t)row * ldy;
   const bool with_lora = RQ > 0 && row >= lo.row0 && row < lo.row0 + lo.rows;      // wave-uniform
   float t[RQ > 0 ? 4 * RQ : 1];
+  float f16_mx = 0.f;
 #pragma unroll
   for (int j = 0; j < (RQ > 0 ? 4 * RQ : 1); ++j) t[j] = 0.f;
 #pragma unroll
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mean) * rstd * (1.0f + a[c]) + bsh[c];
     u32x2 w;
-    w[0] = pack_bf16x2(o[0], o[1]);
-    w[1] = pack_bf16x2(o[2], o[3]);
+    w[0] = pack_op16x2<F16>(o[0], o[1], f16_mx);
+    w[1] = pack_op16x2<F16>(o[2], o[3], f16_mx);
     *(u32x2*)(yr + col) = w;
     if constexpr (RQ > 0) {
       if (with_lora) {
@@ -103,11 +107,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
       }
     }
   }
+  if constexpr (F16) report_f16_overflow(f16_mx, f16_ovf);
 }
 
 // generic D (multiple of 4): three passes over the (L2-resident) row
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
-                                                           uint16_t* __restrict__ Y, int ldy, int M, int D, float eps) {
+                                                           uint16_t* __restrict__ Y, int ldy, int M, int D, float eps, int* __restrict__ f16_ovf = nullptr) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   int sg = 0, acc_rows = 0;
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restri
   const float* sh = shift + (size_t)b * mod_ld;
   const float* sc = scale + (size_t)b * mod_ld;
   uint16_t* yr = Y + (size_t)row * ldy;
+  float f16_mx = 0.f;
   for (int c = lane * 4; c < D; c += 256) {
     const f32x4 v = *(const f32x4*)(xr + c);
     const f32x4 a = *(const f32x4*)(sc + c);
@@ -144,10 +151,11 @@ __global__ __launch_bounds__(256) void ln_modulate_generic(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (v[k] - mean) * rstd * (1.0f + a[k]) + bsh[k];
     u32x2 w;
-    w[0] = pack_bf16x2(o[0], o[1]);
-    w[1] = pack_bf16x2(o[2], o[3]);
+    w[0] = pack_op16x2<F16>(o[0], o[1], f16_mx);
+    w[1] = pack_op16x2<F16>(o[2], o[3], f16_mx);
     *(u32x2*)(yr + c) = w;
   }
+  if constexpr (F16) report_f16_overflow(f16_mx, f16_ovf);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -444,6 +452,7 @@ struct LoraTerms {
   int n;                  // 0: K-split form (X[0], A[0]); > 0: one slab per term
 };
 
+template <bool F16 = false>      // F16: X and A are fp16 images (the operands of an LX_OPERANDS_F16 GEMM), v_mfma_f32_16x16x32_f16
 __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms terms, float* __restrict__ T, int ldt, int M, int K, int R, int Ks,
                                                              int split_stride) {
   __shared__ f32x4 red[8][64];
@@ -469,7 +478,10 @@ __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms ter
 #pragma unroll
     for (int u = 0; u < NS; ++u) { af[u] = *(const bf16x8*)(ap + k + u * 256); xf[u] = *(const bf16x8*)(xp + k + u * 256); }
 #pragma unroll
-    for (int u = 0; u < NS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], xf[u], acc, 0, 0, 0);
+    for (int u = 0; u < NS; ++u) {
+      if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[u]), __builtin_bit_cast(f16x8, xf[u]), acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], xf[u], acc, 0, 0, 0);
+    }
     k += NS * 256;
   };
   while (k + 7 * 256 < kend) chunk(std::integral_constant<int, 8>{});
@@ -580,7 +592,10 @@ __global__ void convert_kernel(void* __restrict__ dst, int dst_bf16, const void*
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = src_bf16 ? bf16_to_f32(((const uint16_t*)src)[i]) : ((const float*)src)[i];
-    if (dst_bf16) ((uint16_t*)dst)[i] = f32_to_bf16(v);
+    if (dst_bf16 == 2) {          // fp16 (saturated): the operand image of an LX_OPERANDS_F16 GEMM
+      float mx = 0.f;
+      ((uint16_t*)dst)[i] = (uint16_t)(pack_f16x2_sat(v, 0.f, mx) & 0xffffu);
+    } else if (dst_bf16) ((uint16_t*)dst)[i] = f32_to_bf16(v);
     else ((float*)dst)[i] = v;
   }
 }
@@ -588,7 +603,7 @@ __global__ void convert_kernel(void* __restrict__ dst, int dst_bf16, const void*
 }  // namespace
 
 static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, void* Y, int ldy, int D, float eps, void* stream,
-                     const LnLora* lora = nullptr) {
+                     const LnLora* lora = nullptr, bool f16 = false, int* f16_ovf = nullptr) {
   int M = 0;
   for (int i = 0; i < segs.n; ++i) {
     LX_CHECK_ARG(segs.shift[i] && segs.scale[i] && segs.n_rows[i] > 0 && segs.rows_per_batch[i] > 0, "lx_ln_modulate: bad segment %d", i);
@@ -608,16 +623,23 @@ static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, vo
                  "lx_ln_modulate_lora_segs: bad adapter arguments (R=%d)", lora->R);
     LX_CHECK_ARG(((uintptr_t)lora->A & 7) == 0, "lx_ln_modulate_lora_segs: Adown must be 8-byte aligned");
     const int rq = (lora->R + 3) / 4;
-#define LX_LN_LORA(NCH, RQ) hipLaunchKernelGGL((ln_modulate_kernel<NCH, RQ>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora)
+#define LX_LN_LORA(NCH, RQ) hipLaunchKernelGGL((ln_modulate_kernel<NCH, RQ>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, (int*)nullptr)
     if (D == 3072) { if (rq == 1) LX_LN_LORA(12, 1); else if (rq == 2) LX_LN_LORA(12, 2); else if (rq == 3) LX_LN_LORA(12, 3); else LX_LN_LORA(12, 4); }
     else { if (rq == 1) LX_LN_LORA(1, 1); else if (rq == 2) LX_LN_LORA(1, 2); else if (rq == 3) LX_LN_LORA(1, 3); else LX_LN_LORA(1, 4); }
 #undef LX_LN_LORA
     LX_LAUNCH_CHECK("lx_ln_modulate_lora_segs");
     return LX_OK;
   }
-  if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{});
-  else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{});
-  else hipLaunchKernelGGL(ln_modulate_generic, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps);
+  if (f16) {
+    if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12, 0, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
+    else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1, 0, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
+    else hipLaunchKernelGGL(ln_modulate_generic<true>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, f16_ovf);
+    LX_LAUNCH_CHECK("lx_ln_modulate_f16_segs");
+    return LX_OK;
+  }
+  if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, (int*)nullptr);
+  else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, (int*)nullptr);
+  else hipLaunchKernelGGL(ln_modulate_generic<false>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, (int*)nullptr);
   LX_LAUNCH_CHECK("lx_ln_modulate");
   return LX_OK;
 }
@@ -641,6 +663,19 @@ extern "C" int lx_ln_modulate_segs(const float* X, int ldx, const lx_ln_seg* seg
     segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
   }
   return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream);
+}
+
+extern "C" int lx_ln_modulate_f16_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                                       float eps, int32_t* f16_ovf, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_ln_modulate_f16_segs: 1..3 segments");
+  LX_CHECK_ARG(((uintptr_t)f16_ovf & 3) == 0, "lx_ln_modulate_f16_segs: f16_ovf must be 4-byte aligned");
+  LnSegs segs;
+  segs.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.n_rows[i] = seg[i].n_rows; segs.rows_per_batch[i] = seg[i].rows_per_batch;
+    segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
+  }
+  return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream, nullptr, true, (int*)f16_ovf);
 }
 
 extern "C" int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
@@ -730,20 +765,31 @@ extern "C" int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_co
   return LX_OK;
 }
 
-extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+static int lora_down_launch(const char* name, bool f16, const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
                             int split_stride, void* stream) {
-  LX_CHECK_ARG(X && Adown && T && M > 0, "lx_lora_down: NULL operand");
-  LX_CHECK_ARG(R >= 1 && R <= 16, "lx_lora_down: R=%d must be in [1,16]", R);
-  LX_CHECK_ARG(K % 32 == 0 && ldx % 8 == 0 && ldt >= R, "lx_lora_down: K %% 32, ldx %% 8 and ldt >= R required (K=%d)", K);
-  LX_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Adown & 15) == 0 && ((uintptr_t)T & 15) == 0, "lx_lora_down: operands must be 16-byte aligned");
+  LX_CHECK_ARG(X && Adown && T && M > 0, "%s: NULL operand", name);
+  LX_CHECK_ARG(R >= 1 && R <= 16, "%s: R=%d must be in [1,16]", name, R);
+  LX_CHECK_ARG(K % 32 == 0 && ldx % 8 == 0 && ldt >= R, "%s: K %% 32, ldx %% 8 and ldt >= R required (K=%d)", name, K);
+  LX_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Adown & 15) == 0 && ((uintptr_t)T & 15) == 0, "%s: operands must be 16-byte aligned", name);
   LX_CHECK_ARG(n_split >= 1 && n_split <= 16 && (n_split == 1 || split_stride >= (M - 1) * ldt + R) && split_stride % 4 == 0,
-               "lx_lora_down: bad n_split=%d / split_stride=%d", n_split, split_stride);
+               "%s: bad n_split=%d / split_stride=%d", name, n_split, split_stride);
   const int Ks = ((K / 32 + n_split - 1) / n_split) * 32;
   LoraTerms lt = {};
   lt.X[0] = (const uint16_t*)X; lt.A[0] = (const uint16_t*)Adown; lt.ldx[0] = ldx; lt.n = 0;
-  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, Ks, split_stride);
-  LX_LAUNCH_CHECK("lx_lora_down");
+  if (f16) hipLaunchKernelGGL(lora_down_mfma_kernel<true>, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, Ks, split_stride);
+  else hipLaunchKernelGGL(lora_down_mfma_kernel<false>, dim3((M + 15) / 16, n_split), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, Ks, split_stride);
+  LX_LAUNCH_CHECK(name);
   return LX_OK;
+}
+
+extern "C" int lx_lora_down(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                            int split_stride, void* stream) {
+  return lora_down_launch("lx_lora_down", false, X, ldx, Adown, T, ldt, M, K, R, n_split, split_stride, stream);
+}
+
+extern "C" int lx_lora_down_f16(const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,
+                                int split_stride, void* stream) {
+  return lora_down_launch("lx_lora_down_f16", true, X, ldx, Adown, T, ldt, M, K, R, n_split, split_stride, stream);
 }
 
 extern "C" int lx_lora_down_terms(const void* const* X, const int* ldx, const void* const* Adown, int n_terms, float* T, int ldt, int M, int K,
@@ -757,7 +803,7 @@ extern "C" int lx_lora_down_terms(const void* const* X, const int* ldx, const vo
     LX_CHECK_ARG(X[i] && Adown[i] && ldx[i] % 8 == 0 && ((uintptr_t)X[i] & 15) == 0 && ((uintptr_t)Adown[i] & 15) == 0, "lx_lora_down_terms: term %d: NULL / misaligned operand or ldx %% 8", i);
     lt.X[i] = (const uint16_t*)X[i]; lt.A[i] = (const uint16_t*)Adown[i]; lt.ldx[i] = ldx[i];
   }
-  hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + 15) / 16, n_terms), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, K, slab_stride);
+  hipLaunchKernelGGL(lora_down_mfma_kernel<false>, dim3((M + 15) / 16, n_terms), dim3(512), 0, (hipStream_t)stream, lt, T, ldt, M, K, R, K, slab_stride);
   LX_LAUNCH_CHECK("lx_lora_down_terms");
   return LX_OK;
 }

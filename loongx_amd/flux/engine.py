@@ -61,6 +61,16 @@ class DiTEngine:
         # fp8 GEMM path (model_config["gemm_fp8"]; BASELINE configs[4]): e4m3 operand images on the 64-deep f8f6f4 MFMA
         self.gemm_fp8 = False
         self.w8: Dict[str, torch.Tensor] = {}          # name -> tiled e4m3 weight / name + ".rs" -> row de-scale, built on first use
+        # fp16 operand mode (model_config["operands"] = "fp16", default `operands_default`; OminiModel(dtype=torch.float16)): every GEMM of
+        # the forward multiplies IEEE fp16 images (11 significand bits) instead of bf16 ones (8) on v_mfma_f32_*_f16, same rate, same
+        # layouts; fp32 accumulation, residual stream and everything between the GEMMs as in the bf16 mode; attention operands (q, k, V^T)
+        # stay bf16. The bf16 mode's per-forward error IS the 8-bit rounding of the GEMM A operands (tools/bf16_ablation.py: 4.58e-3, with
+        # fp16 images 7.0e-4), and bf16 weights convert to fp16 exactly down to 2^-24 granularity. fp16 has 5 exponent bits: the producers
+        # saturate at +-65504 and count the waves that did in `f16_ovf` (f16_overflow_count()).
+        self.operands_default = "bf16"
+        self.f16 = False
+        self.w16: Dict[str, torch.Tensor] = {}         # name -> fp16 image of the (tiled) weight / name + ".down" -> fp16 LoRA down-projection
+        self.f16_ovf: Optional[torch.Tensor] = None
         self._gemm_ws: Optional[torch.Tensor] = None
         # Adapter rows on merged weights (LX_LORA_MERGE=1; off by default): W' = bf16(W + lora_scale * B_up A_down) per LoRA-carrying
         # block weight (+11.5 GB at FLUX.1-dev scale), built once per (weights, scale). The adapter streams' problems of a grouped
@@ -104,6 +114,7 @@ class DiTEngine:
         self.X = torch.zeros(M, D, dtype=f32, device=dev)
         self.XN = torch.zeros(M, D, dtype=bf16, device=dev)
         self.Y = torch.zeros(M, 7 * D, dtype=bf16, device=dev)
+        self.XN16, self.Y16 = self.XN.view(torch.float16), self.Y.view(torch.float16)    # the same bytes as fp16 operand images (operands = "fp16")
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
@@ -114,6 +125,7 @@ class DiTEngine:
         self.TLs = torch.zeros(max(self.TL_SPLIT, 3), M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]
         self.lat16 = torch.zeros(B * N, cfg.in_channels, dtype=bf16, device=dev)
+        self.lat16h = self.lat16.view(torch.float16)
         self.out = torch.zeros(B * N, cfg.in_channels, dtype=f32, device=dev)
         self.temb = torch.zeros(B, D, dtype=f32, device=dev)
         self.temb_base = torch.zeros(B, D, dtype=f32, device=dev)
@@ -173,6 +185,42 @@ class DiTEngine:
             self.Q8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
             self.K8 = torch.zeros(self.M, D, dtype=u8, device=self.device)
             self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
+
+    def _setup_f16(self) -> None:
+        """fp16 images of every weight a GEMM of the forward reads (block weights, embedders, final projection: +17 GB at FLUX.1-dev scale;
+        the stacked modulation weights stay bf16 -- their activations are bf16 hi / lo pairs already) and of the LoRA down-projections,
+        built once per weight set. bf16 -> fp16 is exact for |w| >= 2^-14 and to 2^-24 absolute below (fp16 subnormals, which the MFMA
+        honours: tests/test_f16_gpu.py); the share of weights that lose bits is kept in `w16_inexact_share`."""
+        if self.f16_ovf is None:
+            self.f16_ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
+        key = (id(self.w), getattr(self.w, "weights_version", 0), len(self.w.lora))
+        if self.w16 and self._w16_key == key:
+            return
+        self.w16 = {}
+        lost = total = 0
+        for name, W in self.w.t.items():
+            if not name.endswith(".w") or name.startswith("mod.") or name.startswith("tte.") or W.dtype != torch.bfloat16:
+                continue
+            h = W.to(torch.float16)
+            if getattr(W, "lx_tiled", False):
+                h.lx_tiled = True                          # an elementwise conversion keeps the tiled image
+            lost += int((h.to(torch.bfloat16) != W).sum())
+            total += W.numel()
+            self.w16[name[:-2]] = h
+        for name, lo in self.w.lora.items():
+            self.w16[name + ".down"] = lo.down.to(torch.float16)
+        self.w16_inexact_share = lost / max(total, 1)
+        self._w16_key = key
+
+    def f16_overflow_count(self, reset: bool = True) -> int:
+        """Producer waves that saturated a value to +-65504 since the last reset (fp16 operand mode; synchronises). 0 = every operand
+        image is the nearest-even rounding of its fp32 value."""
+        if self.f16_ovf is None:
+            return 0
+        n = int(self.f16_ovf.item())
+        if reset and n:
+            self.f16_ovf.zero_()
+        return n
 
     def set_lora_scale(self, s: float) -> None:
         """Multiplier on every adapter term (reference lora_controller.py: scale_layer). Changes what the captured step graphs
@@ -423,6 +471,7 @@ class DiTEngine:
         self.gemm_fp8 = bool(self.model_config.get("gemm_fp8", False)) and not self.precise
         if self.gemm_fp8:
             self._setup_fp8()
+        self._pick_operands()
         if self.model_config.get("attn_fp8", False) and not self.precise:
             self._fp8_images()                                                                    # never first allocated inside a capture
         if C or self.latent_lora:
@@ -436,21 +485,21 @@ class DiTEngine:
             if C:
                 self._embed_p(condition_latents.reshape(B * C, -1), "x_embedder", self.X_cond_init, lora=True)
         else:
-            pe = prompt_embeds.to(device=dev, dtype=bf16).reshape(B * T, -1).contiguous()
-            ops.gemm([ops.gemm_desc(pe, w.t["context_embedder.w"], self.X_txt_init, bias=w.t["context_embedder.b"],
-                                    epilogue=LX_EPI_STORE_F32)])
+            pe = prompt_embeds.to(device=dev, dtype=self._op_dtype()).reshape(B * T, -1).contiguous()
+            ops.gemm([ops.gemm_desc(pe, self._W("context_embedder"), self.X_txt_init, bias=w.t["context_embedder.b"],
+                                    epilogue=LX_EPI_STORE_F32, **self._f16_kw())])
         # x_embedder(condition_latents) with LoRA active -> cached condition rows
         if C and not self.precise:
-            cl = condition_latents.to(device=dev, dtype=bf16).reshape(B * C, -1).contiguous()
+            cl = condition_latents.to(device=dev, dtype=self._op_dtype()).reshape(B * C, -1).contiguous()
             lo = w.lora.get("x_embedder") if self.lora_scale != 0.0 else None
             tl = None
             if lo is not None:
                 tl = self.TL[: B * C, : cfg.lora_r]
-                ops.lora_down(cl, lo.down, tl)
+                ops.lora_down(cl, self._down("x_embedder", lo), tl)
                 if self.lora_scale != 1.0:
                     tl.mul_(self.lora_scale)
-            ops.gemm([ops.gemm_desc(cl, w.t["x_embedder.w"], self.X_cond_init, bias=w.t["x_embedder.b"], epilogue=LX_EPI_STORE_F32,
-                                    lora_t=tl, lora_up=lo.up if lo is not None else None)])
+            ops.gemm([ops.gemm_desc(cl, self._W("x_embedder"), self.X_cond_init, bias=w.t["x_embedder.b"], epilogue=LX_EPI_STORE_F32,
+                                    lora_t=tl, lora_up=lo.up if lo is not None else None, **self._f16_kw())])
         # RoPE tables: [text; image] and condition (transformer.py:130-134)
         ids = torch.cat([txt_ids.to(dev, f32).reshape(-1, 3), img_ids.to(dev, f32).reshape(-1, 3)], 0)
         # tables live in persistent buffers: the captured step graph holds their addresses
@@ -481,6 +530,32 @@ class DiTEngine:
         self.cond_cached = False          # a new condition stream: the per-layer key / value images are stale
         self.sched = None
 
+    # ------------------------------------------------------------------------------------------ operand format
+    def _pick_operands(self) -> None:
+        """model_config["operands"]: "bf16" (default) | "fp16" -- the 16-bit format of every GEMM operand image of the forward."""
+        fmt = str(self.model_config.get("operands", self.operands_default)).lower()
+        if fmt not in ("bf16", "fp16", "f16", "float16", "bfloat16"):
+            raise ValueError(f'model_config["operands"] = {fmt!r}: "bf16" or "fp16"')
+        self.f16 = fmt in ("fp16", "f16", "float16") and not self.precise and not self.gemm_fp8
+        if self.f16:
+            self._setup_f16()
+
+    def _op_dtype(self):
+        return torch.float16 if self.f16 else torch.bfloat16
+
+    def _op(self, t: torch.Tensor) -> torch.Tensor:
+        """a (slice of a) 16-bit operand buffer in the format the GEMMs of this forward read"""
+        return t.view(torch.float16) if self.f16 else t
+
+    def _W(self, name: str) -> torch.Tensor:
+        return self.w16[name] if self.f16 else self.w.t[name + ".w"]
+
+    def _down(self, name: str, lo) -> torch.Tensor:
+        return self.w16[name + ".down"] if self.f16 else lo.down
+
+    def _f16_kw(self) -> Dict:
+        return dict(f16=True, f16_ovf=self.f16_ovf) if self.f16 else {}
+
     # ------------------------------------------------------------------------------------------ building blocks
     def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int, lora_name: Optional[str] = None, include_txt: bool = False):
         """AdaLN LayerNorm + modulation of every stream of this forward into XN. `lora_name`: the adapter whose modules read XN next
@@ -493,12 +568,15 @@ class DiTEngine:
             b0 = base_by_stream[s]
             segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
         lora = None
-        if lora_name is not None and self.ln_lora and self.cfg.inner_dim in (3072, 256) and not self._merge_active(lora_name):
+        if lora_name is not None and self.ln_lora and not self.f16 and self.cfg.inner_dim in (3072, 256) and not self._merge_active(lora_name):
             lo = self.w.lora.get(lora_name)
             rows = self._lora_rows(include_txt)
             if lo is not None and rows is not None and not (self.C == 0 and not self.latent_lora) and self.lora_scale != 0.0:
                 r0, n = rows
                 lora = (lo.down, self.TL[r0:r0 + n], r0, n)
+        if self.f16:
+            ops.ln_modulate_segs(self.X, segs, self.XN16, self.mods.stride(0), f16_ovf=self.f16_ovf)
+            return None
         ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0), lora=lora)
         if lora is None:
             return None
@@ -508,7 +586,7 @@ class DiTEngine:
 
     def _merge_active(self, name: str) -> bool:
         """This launch group's adapter rows read the merged weight (no lx_lora_down, no LoRA operands)."""
-        return (self.lora_merge and not self.precise and not self.gemm_fp8 and self.lora_scale != 0.0 and name in self.wl
+        return (self.lora_merge and not self.precise and not self.gemm_fp8 and not self.f16 and self.lora_scale != 0.0 and name in self.wl
                 and (self.C > 0 or self.latent_lora) and not self.model_config.get("add_cond_attn", False))
 
     def _setup_lora_merge(self) -> None:
@@ -564,7 +642,7 @@ class DiTEngine:
             return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
-        ops.lora_down(A[r0:r0 + n], lo.down, t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
+        ops.lora_down(self._op(A[r0:r0 + n]), self._down(name, lo), t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
         if self.lora_scale != 1.0:
             self.TLs[:, r0:r0 + n, : lo.down.shape[0]].mul_(self.lora_scale)
         return lo, r0
@@ -595,8 +673,10 @@ class DiTEngine:
             if only is not None and s not in only:
                 continue
             name = txt if (s == "txt" and txt is not None) else main
-            a, c = self.rows(A, s), self.rows(Cbuf, s)
-            W, bias = w.t[name + ".w"], w.t[name + ".b"]
+            a, c = self._op(self.rows(A, s)), self.rows(Cbuf, s)
+            W, bias = self._W(name), w.t[name + ".b"]
+            if self.f16 and (epilogue & 0xff) == LX_EPI_STORE_BF16 and qkv is None:
+                c = c.view(torch.float16)               # a 16-bit store of this mode is the next GEMM's fp16 operand
             if merged is not None and name == main and (s == "cond" or (s == "img" and self.latent_lora) or
                                                         (s == "txt" and self.latent_lora and txt is None)):
                 if {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s] >= lr0m:
@@ -612,7 +692,7 @@ class DiTEngine:
                 W, bias, c = W[:n_out], bias[:n_out], c[:, :n_out]
                 if tiled:
                     W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
-            kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start)
+            kw = dict(bias=bias, epilogue=epilogue, rows_per_batch=L, gelu_col_start=gelu_col_start, **self._f16_kw())
             if qkv is not None:                # (wq, wk, wq_txt, wk_txt[, layer]): RMSNorm + RoPE + V^T in this launch's epilogue
                 rope = self.rope_cs_cond if s == "cond" else (self.rope_cs_main[: self.T] if s == "txt" else self.rope_cs_main[self.T:])
                 kw["qkv"] = dict(norm_q=self._qn(qkv[2] if s == "txt" else qkv[0], qkv[0]), norm_k=qkv[3] if s == "txt" else qkv[1], rope=rope,
@@ -688,6 +768,9 @@ class DiTEngine:
         flags = (ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED) if self._layer_nomax(wq) else 0
         if not self.pair_plan:             # the batch-size-invariant plans: the attention kernel must not depend on the batch size either
             flags |= ops.ATTN_INVARIANT
+        okw = dict(f16_ovf=self.f16_ovf) if self.f16 else {}      # O is the output projection's A operand: fp16 in the fp16 operand mode
+        if self.f16:
+            flags |= ops.ATTN_O_F16
         if self.model_config.get("attn_fp8", False):
             # opt-in fp8 (e4m3) attention (BASELINE configs[4]): q / k / v^T go to byte images, both attention products run on
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
@@ -695,18 +778,18 @@ class DiTEngine:
             if not prepped:                # otherwise the projection epilogue already wrote the three byte images
                 ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8)
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
-                             seg_vt0=seg_vt0, bias=bias)
+                             seg_vt0=seg_vt0, bias=bias, flags=ops.ATTN_O_F16 if self.f16 else 0, **okw)
             return
         if cached:
             # keys from the layer's key image, V^T from the layer's V^T image (the condition stream's part written by the first
             # forward of this conditioning); in a cond_skip forward only the text / image segments have queries
             ops.attn_fwd(Y, self.KC[layer], self.VTC[layer], Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0,
-                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0, flags=flags)
+                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0, flags=flags, **okw)
             return
         if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
             ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
-                     seg_vt0=seg_vt0, bias=bias, flags=flags)
+                     seg_vt0=seg_vt0, bias=bias, flags=flags, **okw)
 
     # ------------------------------------------------------------------------------------------ blocks
     def double_block(self, i: int) -> None:
@@ -733,8 +816,8 @@ class DiTEngine:
             a = self.rows(Ya, "cond")
             kw = dict(lora_t=self.rows(self.TL, "cond"), lora_up=lo.up, lora_nsplit=self.TL_SPLIT,
                       lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
-            ops.gemm([ops.gemm_desc(a, w.t[p + ".out.w"], self.rows(self.X, "img"), bias=w.t[p + ".out.b"], epilogue=LX_EPI_RESID_F32,
-                                    rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw)])
+            ops.gemm([ops.gemm_desc(self._op(a), self._W(p + ".out"), self.rows(self.X, "img"), bias=w.t[p + ".out.b"], epilogue=LX_EPI_RESID_F32,
+                                    rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw, **self._f16_kw())])
         self._ln(base, 3 * D, 4 * D)                                                       # norm2 + (scale_mlp, shift_mlp)
         self._gemm_streams(self.XN, Yf, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU)
         gate = {s: base[s] + 5 * D for s in base}
@@ -1095,16 +1178,17 @@ class DiTEngine:
                 self._time_text_embed(self.t1000, self.temb, self.temb_base)
                 self._compute_mods(self.temb, self.mods, lora=self.latent_lora)
             return
-        ops.convert(self.lat16, latents.reshape(self.B * self.N, -1).contiguous())
+        lat = self._op(self.lat16)
+        ops.convert(lat, latents.reshape(self.B * self.N, -1).contiguous())
         lo = w.lora.get("x_embedder") if (self.latent_lora and self.lora_scale != 0.0) else None
         tl = None
         if lo is not None:
             tl = self.TL[: self.B * self.N, : cfg.lora_r]
-            ops.lora_down(self.lat16, lo.down, tl)
+            ops.lora_down(lat, self._down("x_embedder", lo), tl)
             if self.lora_scale != 1.0:
                 tl.mul_(self.lora_scale)
-        ops.gemm([ops.gemm_desc(self.lat16, w.t["x_embedder.w"], self.rows(self.X, "img"), bias=w.t["x_embedder.b"],
-                                epilogue=LX_EPI_STORE_F32, lora_t=tl, lora_up=lo.up if lo is not None else None)])
+        ops.gemm([ops.gemm_desc(lat, self._W("x_embedder"), self.rows(self.X, "img"), bias=w.t["x_embedder.b"],
+                                epilogue=LX_EPI_STORE_F32, lora_t=tl, lora_up=lo.up if lo is not None else None, **self._f16_kw())])
         self.rows(self.X, "txt").copy_(self.X_txt_init)
         if self.C and not self.cond_skip:
             self.rows(self.X, "cond").copy_(self.X_cond_init)
@@ -1124,10 +1208,11 @@ class DiTEngine:
             ops.gemm([self._desc_p(self.rows(self.XN2, "img"), "proj_out", self.out, K=D, a_lo_off=D, bias=w.t["proj_out.b"],
                                    epilogue=LX_EPI_STORE_F32)], self.gemm_ws())
             return self.out.view(self.B, self.N, cfg.in_channels)
-        ops.ln_modulate(self.rows(self.X, "img"), self.mods[:, o + D:], self.mods[:, o:], self.rows(self.XN, "img"),
-                        rows_per_batch=self.N, mod_ld=self.mods.stride(0))
-        ops.gemm([ops.gemm_desc(self.rows(self.XN, "img"), w.t["proj_out.w"], self.out, bias=w.t["proj_out.b"],
-                                epilogue=LX_EPI_STORE_F32)])
+        xn = self._op(self.rows(self.XN, "img"))
+        ops.ln_modulate(self.rows(self.X, "img"), self.mods[:, o + D:], self.mods[:, o:], xn,
+                        rows_per_batch=self.N, mod_ld=self.mods.stride(0), **(dict(f16_ovf=self.f16_ovf) if self.f16 else {}))
+        ops.gemm([ops.gemm_desc(xn, self._W("proj_out"), self.out, bias=w.t["proj_out.b"],
+                                epilogue=LX_EPI_STORE_F32, **self._f16_kw())])
         return self.out.view(self.B, self.N, cfg.in_channels)
 
     def _forward_eager(self, latents: torch.Tensor, timestep: torch.Tensor, mods_ready: bool = False) -> torch.Tensor:
@@ -1174,12 +1259,12 @@ class DiTEngine:
         self.g_t.copy_(timestep.to(device=self.device, dtype=torch.float32).reshape(-1))
         # The captured launches reference only engine-owned buffers, so one graph serves every image with the same
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
-        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8,
+        key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8, self.f16,
                getattr(self.w, "q_log2_version", 0),      # (a weight broadcast refreshes the scaled norm_q tensors and the per-layer bounds)
                self.cond_cache, skip)
         g = self.graphs.get(key)
         if g is None:
-            mode = (self.precise, self.gemm_fp8, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0, skip)
+            mode = (self.precise, self.gemm_fp8, self.f16, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0, skip)
             self.cond_skip = skip
             try:
                 if mode not in self._warmed:                          # lazy code-object loads / buffer allocations must not happen inside capture
@@ -1213,15 +1298,16 @@ class DiTEngine:
     # ------------------------------------------------------------------------------------------ block-level entry points
     # (used by the reference-API mirrors in block.py: same arithmetic as forward(), driven one block at a time)
     def load_streams(self, enc: Optional[torch.Tensor], hid: torch.Tensor, cond: Optional[torch.Tensor], dst: str = "X") -> None:
-        """Copy [B,L,D] per-stream tensors into the stream-major rows of X (fp32) or XN (bf16)."""
+        """Copy [B,L,D] per-stream tensors into the stream-major rows of X (fp32) or XN (the 16-bit operand image of this mode)."""
         self.block_level_entry()
-        buf = self.X if dst == "X" else self.XN
+        buf = self.X if dst == "X" else self._op(self.XN)
         for s, t in (("txt", enc), ("img", hid), ("cond", cond)):
             if t is not None:
                 self.rows(buf, s).copy_(t.reshape(-1, t.shape[-1]))
 
     def read_stream(self, s: str, L: int, src: str = "X", cols: Optional[slice] = None) -> torch.Tensor:
-        buf = {"X": self.X, "XN": self.XN, "Y": self.Y}[src]
+        # (Y: the block-level callers read the attention output / MLP columns, which the fp16 operand mode holds as fp16)
+        buf = {"X": self.X, "XN": self._op(self.XN), "Y": self._op(self.Y)}[src]
         r = self.rows(buf, s)
         if cols is not None:
             r = r[:, cols]
@@ -1264,6 +1350,8 @@ class DiTEngine:
             self._setup_precise()
         elif self.model_config.get("attn_fp8", False):
             self._fp8_images()
+        self.gemm_fp8 = False
+        self._pick_operands()
         self.attn_bias = self._attn_bias()
         self._setup_nomax()
         f32 = torch.float32

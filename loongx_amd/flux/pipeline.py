@@ -116,7 +116,8 @@ class LxFluxPipeline:
         """A LOCAL diffusers-format FLUX.1 directory (the reference passes a hub id to FluxPipeline.from_pretrained,
         src/train/model.py:399-401; the box has no hub access): `transformer/` (safetensors, sharded or single) is packed for the
         MI355X engine; `vae/` becomes an `LxAutoencoderKL`; `text_encoder*/` + `tokenizer*/` a `FluxTextEncoders` (transformers on
-        ROCm). Missing optional parts leave the corresponding slot empty. dtype float32 selects the engine's precise mode."""
+        ROCm). Missing optional parts leave the corresponding slot empty. dtype float32 selects the engine's precise mode, float16 its
+        fp16 operand mode (bfloat16: bf16 operands)."""
         import json
         import os
         from safetensors.torch import load_file
@@ -149,7 +150,8 @@ class LxFluxPipeline:
                              pooled_projection_dim=c.get("pooled_projection_dim", 768), guidance_embeds=c.get("guidance_embeds", True),
                              axes_dims_rope=tuple(c.get("axes_dims_rope", (16, 56, 56))))
         tsd = load_dir(tdir)
-        tr = LxFluxTransformer.from_state_dict(tsd, cfg or FluxConfig.from_state_dict(tsd), device, lora_scale, precise=dtype == torch.float32)
+        tr = LxFluxTransformer.from_state_dict(tsd, cfg or FluxConfig.from_state_dict(tsd), device, lora_scale, precise=dtype == torch.float32,
+                                              operands="fp16" if dtype == torch.float16 else "bf16")
         vae = text = None
         vdir = os.path.join(path, "vae")
         if load_vae and os.path.isdir(vdir):

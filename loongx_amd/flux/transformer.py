@@ -34,12 +34,15 @@ def prepare_params(hidden_states: torch.Tensor, encoder_hidden_states: torch.Ten
 class LxFluxTransformer:
     """Holds the fused weights on one MI355X and the engine that runs them."""
 
-    def __init__(self, weights: PackedWeights, device="cuda", precise: bool = False):
+    def __init__(self, weights: PackedWeights, device="cuda", precise: bool = False, operands: str = "bf16"):
         """precise=True: fp32-class arithmetic by default (the reference's shipped `dtype: float32`, train/config/seed_512.yaml:2):
-        split-bf16 MFMA GEMMs + fp32 attention; a call's model_config["precise"] overrides the default either way."""
+        split-bf16 MFMA GEMMs + fp32 attention; a call's model_config["precise"] overrides the default either way.
+        operands="fp16" (dtype=torch.float16): the GEMM operand images are IEEE fp16 instead of bf16 by default (same speed class, 1/8 of
+        the rounding error: DiTEngine.operands_default; model_config["operands"] overrides per call)."""
         cfg = weights.cfg
         self.engine = DiTEngine(weights, device)
         self.engine.precise_default = bool(precise)
+        self.engine.operands_default = operands
         self.config = SimpleNamespace(in_channels=cfg.in_channels, num_layers=cfg.num_layers,
                                       num_single_layers=cfg.num_single_layers, attention_head_dim=cfg.attention_head_dim,
                                       num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
@@ -62,12 +65,13 @@ class LxFluxTransformer:
         self.engine.sched = None
 
     @classmethod
-    def from_state_dict(cls, sd, cfg: FluxConfig, device="cuda", lora_scale: float = 1.0, prefix: str = "", precise: bool = False):
-        return cls(pack_state_dict(sd, cfg, device, lora_scale, prefix, precise=precise), device, precise=precise)
+    def from_state_dict(cls, sd, cfg: FluxConfig, device="cuda", lora_scale: float = 1.0, prefix: str = "", precise: bool = False,
+                        operands: str = "bf16"):
+        return cls(pack_state_dict(sd, cfg, device, lora_scale, prefix, precise=precise), device, precise=precise, operands=operands)
 
     @classmethod
-    def synthetic(cls, cfg: Optional[FluxConfig] = None, device="cuda", seed: int = 0, precise: bool = False):
-        return cls(synthetic_weights(cfg or FluxConfig(), device, seed), device, precise=precise)
+    def synthetic(cls, cfg: Optional[FluxConfig] = None, device="cuda", seed: int = 0, precise: bool = False, operands: str = "bf16"):
+        return cls(synthetic_weights(cfg or FluxConfig(), device, seed), device, precise=precise, operands=operands)
 
     def named_modules(self):
         for i, b in enumerate(self.transformer_blocks):

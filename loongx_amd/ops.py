@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (LX_EPI_QKV, LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_STORE_FP8, LX_OPERANDS_FP8, LX_W_TILED,
+from ._lib import (LX_EPI_QKV, LX_EPI_GELU, LX_EPI_RESID_F32, LX_EPI_SPLIT_BF16, LX_EPI_STORE_BF16, LX_EPI_STORE_F32, LX_EPI_STORE_FP8, LX_OPERANDS_F16, LX_OPERANDS_FP8, LX_W_TILED,
                    AttnDesc, GemmDesc, check, lib)
 
 
@@ -38,7 +38,7 @@ def tile_weight(W: torch.Tensor) -> torch.Tensor:
     e4m3 weights (uint8 [N,K], K % 128 == 0) tile the same way with 128 elements per 128-B block row (16 per chunk)."""
     N, K = W.shape
     e = 16 // W.element_size()                       # elements per 16-B chunk
-    assert W.dtype in (torch.bfloat16, torch.uint8) and N % 256 == 0 and K % (8 * e) == 0
+    assert W.dtype in (torch.bfloat16, torch.float16, torch.uint8) and N % 256 == 0 and K % (8 * e) == 0
     t = W.reshape(N // 256, 256, K // (8 * e), 8, e).permute(0, 2, 1, 3, 4)       # [nb, kb, row, chunk, e]
     r = torch.arange(256, device=W.device)
     src = torch.arange(8, device=W.device)[None, :] ^ ((r >> 1) & 7)[:, None]    # position p holds chunk p ^ f(r)
@@ -71,13 +71,20 @@ def quantize_weight_fp8(W: torch.Tensor):
 def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, epilogue=LX_EPI_STORE_BF16,
               gate=None, rows_per_batch=None, lora_t=None, lora_up=None, lora_mod_cols=0, lora_toff_max=0,
               gelu_col_start=0, M=None, N=None, K=None, lora_nsplit=1, lora_split_stride=0, k_segs=0, a_lo_off=0,
-              c_lo_off=0, fp8=False, col_scale=None, out_scale=0.0, qkv=None) -> GemmDesc:
+              c_lo_off=0, fp8=False, col_scale=None, out_scale=0.0, qkv=None, f16=False, f16_ovf=None) -> GemmDesc:
     """A [M,K] bf16 (row stride A.stride(0)), W [N,K] bf16, C_ [M,N] bf16|fp32 (strided views welcome).
     Precise mode: k_segs = 2 | 3 with A's lo image a_lo_off columns after the hi image (pass K explicitly: A then has more than K
     columns) and, for 3, W = [N, 2K] = [W_hi | W_lo] (pass N, K); c_lo_off != 0 adds LX_EPI_SPLIT_BF16 (hi/lo output pair)."""
     if fp8:      # e4m3 byte operands (LX_OPERANDS_FP8): acc * col_scale[n] first, then the usual epilogue
         _req(A, torch.uint8, "A"); _req(W, torch.uint8, "W")
         epilogue |= LX_OPERANDS_FP8
+    elif f16:    # IEEE fp16 operands (LX_OPERANDS_F16): a 16-bit store writes fp16 too (saturated; f16_ovf = int32 device counter of clipping waves)
+        _req(A, torch.float16, "A"); _req(W, torch.float16, "W")
+        assert col_scale is None and not k_segs and not c_lo_off
+        epilogue |= LX_OPERANDS_F16
+        if f16_ovf is not None:
+            _req(f16_ovf, torch.int32, "f16_ovf")
+            col_scale = f16_ovf                       # (one pointer slot for the two operand modes: a union in lx.h)
     else:
         _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
     d = GemmDesc()
@@ -132,7 +139,10 @@ def gemm_desc(A: torch.Tensor, W: torch.Tensor, C_: torch.Tensor, *, bias=None, 
         d._keep = (qkv["norm_q"], qkv["norm_k"], rope, qkv["vt"], kimg, qkv.get("q8"), qkv.get("k8"))     # the descriptor holds raw pointers: keep temporaries alive until launch
     kind = epilogue & 0xff
     want = torch.bfloat16 if kind == LX_EPI_STORE_BF16 else (torch.uint8 if kind == LX_EPI_STORE_FP8 else torch.float32)
-    _req(C_, want, "C")
+    if f16 and kind == LX_EPI_STORE_BF16 and qkv is None:
+        want = torch.float16                          # (with LX_EPI_QKV the buffer holds bf16 k / q beside fp16 columns: either view passes)
+    if not (f16 and qkv is not None and kind == LX_EPI_STORE_BF16 and C_.dtype in (torch.float16, torch.bfloat16)):
+        _req(C_, want, "C")
     return d
 
 
@@ -204,8 +214,17 @@ def gemm(problems: Sequence[GemmDesc], workspace: Optional[torch.Tensor] = None)
 
 
 def lora_down(X: torch.Tensor, Adown: torch.Tensor, T: torch.Tensor, n_split: int = 1, split_stride: int = 0) -> None:
-    """T (slab 0) [M,R] fp32; with n_split > 1 slab s lives split_stride floats further (same row stride)."""
-    _req(X, torch.bfloat16, "X"); _req(Adown, torch.bfloat16, "Adown"); _req(T, torch.float32, "T")
+    """T (slab 0) [M,R] fp32; with n_split > 1 slab s lives split_stride floats further (same row stride).
+    X and Adown both bf16, or both fp16 (the operand images of the fp16-operand mode: lx_lora_down_f16)."""
+    _req(T, torch.float32, "T")
+    if X.dtype == torch.float16:
+        _req(Adown, torch.float16, "Adown")
+        if not X.is_cuda:
+            raise ValueError("X: must live on the GPU (the hot path has no CPU fallback)")
+        check(lib.lx_lora_down_f16(X.data_ptr(), X.stride(0), Adown.data_ptr(), T.data_ptr(), T.stride(0), X.shape[0], X.shape[1],
+                                   Adown.shape[0], n_split, split_stride, _stream()), "lx_lora_down_f16")
+        return
+    _req(X, torch.bfloat16, "X"); _req(Adown, torch.bfloat16, "Adown")
     check(lib.lx_lora_down(X.data_ptr(), X.stride(0), Adown.data_ptr(), T.data_ptr(), T.stride(0), X.shape[0], X.shape[1],
                            Adown.shape[0], n_split, split_stride, _stream()), "lx_lora_down")
 
@@ -250,8 +269,11 @@ def rope_table(ids: torch.Tensor, axes=(16, 56, 56), theta: float = 10000.0, out
     return cos, sin
 
 
-def ln_modulate(X, shift, scale, Y, rows_per_batch, eps=1e-6, mod_ld=None) -> None:
-    _req(X, torch.float32, "X"); _req(Y, torch.bfloat16, "Y"); _req(shift, torch.float32, "shift"); _req(scale, torch.float32, "scale")
+def ln_modulate(X, shift, scale, Y, rows_per_batch, eps=1e-6, mod_ld=None, f16_ovf=None) -> None:
+    _req(X, torch.float32, "X"); _req(shift, torch.float32, "shift"); _req(scale, torch.float32, "scale")
+    if Y.dtype == torch.float16:          # the fp16 operand image: the one-segment form of lx_ln_modulate_f16_segs
+        return ln_modulate_segs(X, [(0, X.shape[0], rows_per_batch, shift, scale)], Y, shift.stride(0) if mod_ld is None else mod_ld, eps, f16_ovf=f16_ovf)
+    _req(Y, torch.bfloat16, "Y")
     check(lib.lx_ln_modulate(X.data_ptr(), X.stride(0), shift.data_ptr(), scale.data_ptr(),
                              shift.stride(0) if mod_ld is None else mod_ld, Y.data_ptr(), Y.stride(0), X.shape[0], X.shape[1],
                              rows_per_batch, eps, _stream()), "lx_ln_modulate")
@@ -263,8 +285,9 @@ def qkv_prep(QKV, q_col, k_col, v_col, row0, n_rows, rows_per_batch, H, wq, wk, 
                           _p(cos), _p(sin), _p(VT), VT.shape[-1] if VT is not None else 0, vt_pos0, _stream()), "lx_qkv_prep")
 
 
-def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6, lora=None) -> None:
-    """segs: list of (row0, n_rows, rows_per_batch, shift_tensor, scale_tensor); one launch.
+def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6, lora=None, f16_ovf=None) -> None:
+    """segs: list of (row0, n_rows, rows_per_batch, shift_tensor, scale_tensor); one launch. Y bf16, or fp16 (the A operand of an
+    fp16-operand GEMM: saturated, f16_ovf = int32 device counter of the rows that clipped).
     lora = (Adown [R, D] bf16, T [rows, >= R] fp32 (row stride T.stride(0)), first row, row count): also the LoRA down-projection of
     those rows of Y, T[row - first] = Y_row . Adown^T (what lora_down(Y[first:first+count], Adown, T) computes; D = 3072 | 256)."""
     n = len(segs)
@@ -272,6 +295,11 @@ def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6, lora=None) -> None:
     for i, (row0, n_rows, rpb, sh, sc) in enumerate(segs):
         arr[i].row0, arr[i].n_rows, arr[i].rows_per_batch = row0, n_rows, rpb
         arr[i].shift, arr[i].scale = sh.data_ptr(), sc.data_ptr()
+    if Y.dtype == torch.float16:
+        assert lora is None
+        check(lib.lx_ln_modulate_f16_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, Y.data_ptr(), Y.stride(0), X.shape[1], eps, _p(f16_ovf),
+                                          _stream()), "lx_ln_modulate_f16_segs")
+        return
     if lora is not None:
         A, T, r0, cnt = lora
         _req(A, torch.bfloat16, "Adown"); _req(T, torch.float32, "T")
@@ -308,16 +336,17 @@ def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt
     return d
 
 
-ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT
+ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16 = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT, L.LX_ATTN_O_F16
 Q_LOG2_FACTOR = (1.0 / math.sqrt(128.0)) * 1.4426950408889634       # what LX_ATTN_Q_LOG2 expects q to carry already
 
 
-def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0, flags=0) -> None:
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0, flags=0, f16_ovf=None) -> None:
     """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values).
     flags: ATTN_Q_LOG2 [| ATTN_BOUNDED] (include/lx.h): q carries scale * log2 e; the caller bounds the scores -> no running max."""
     d = _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
     d.n_qseg = n_qseg
     d.flags = flags
+    d.f16_ovf = _p(f16_ovf)               # (ATTN_O_F16: O is written as fp16, saturated; int32 device counter of clipping waves)
     if TIMER is not None:
         S = sum(seg_len)
         Sq = sum(seg_len[:n_qseg]) if n_qseg else S
@@ -349,8 +378,10 @@ def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8,
                                    _stream()), "lx_qkv_prep_fp8_segs")
 
 
-def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None) -> None:
+def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, flags=0, f16_ovf=None) -> None:
+    """flags: 0 | ATTN_O_F16 (O written as fp16 for an fp16-operand output projection)"""
     d = _attn_desc(Q8, K8, VT8, O, 0, 0, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
+    d.flags, d.f16_ovf = flags, _p(f16_ovf)
     args = (C.byref(d), 1.0 / (FP8_Q_SCALE * FP8_K_SCALE), 1.0 / FP8_V_SCALE, _stream())
     if TIMER is not None:
         S = sum(seg_len)
@@ -477,8 +508,9 @@ def euler_step(x: torch.Tensor, v: torch.Tensor, dsigma: float) -> None:
 
 def convert(dst: torch.Tensor, src: torch.Tensor) -> None:
     assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
-    check(lib.lx_convert(dst.data_ptr(), int(dst.dtype == torch.bfloat16), src.data_ptr(), int(src.dtype == torch.bfloat16),
-                         dst.numel(), _stream()), "lx_convert")
+    fmt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+    assert src.dtype != torch.float16, "lx_convert reads fp32 or bf16"
+    check(lib.lx_convert(dst.data_ptr(), fmt[dst.dtype], src.data_ptr(), fmt[src.dtype], dst.numel(), _stream()), "lx_convert")
 
 
 # ---- VAE row kernels (include/lx.h "FLUX VAE") ------------------------------------------------------------------------

@@ -446,6 +446,8 @@ class OminiModel(CS3DGF):
         self.transformer = pipe.transformer
         if self.precise and hasattr(self.transformer, "engine"):
             self.transformer.engine.precise_default = True
+        if self._dtype == torch.float16 and hasattr(self.transformer, "engine"):      # dtype=torch.float16: fp16 GEMM operand images
+            self.transformer.engine.operands_default = "fp16"
 
     def _build_brain(self, sd: Dict[str, torch.Tensor]) -> None:
         CS3DGF.__init__(self, sd, self.device)
@@ -468,7 +470,8 @@ class OminiModel(CS3DGF):
         tkeys = [k for k in sd if k.startswith("transformer.")]
         if tkeys:
             cfg = self.flux_config or FluxConfig.from_state_dict(sd, "transformer.")
-            tr = LxFluxTransformer.from_state_dict(sd, cfg, self.device, self.lora_scale, prefix="transformer.", precise=self.precise)
+            tr = LxFluxTransformer.from_state_dict(sd, cfg, self.device, self.lora_scale, prefix="transformer.", precise=self.precise,
+                                                   operands="fp16" if self._dtype == torch.float16 else "bf16")
             if self.flux_pipe is None:
                 self._set_pipe(LxFluxPipeline(tr))
             else:                                            # keep the pipeline's VAE / text encoders, swap the transformer
@@ -499,7 +502,8 @@ class OminiModel(CS3DGF):
     def synthetic(cls, flux_config=None, model_config=None, device="cuda", seed: int = 0, dtype: torch.dtype = torch.bfloat16):
         from ..flux.pipeline import LxFluxPipeline
         from ..flux.transformer import LxFluxTransformer
-        tr = LxFluxTransformer.synthetic(flux_config, device, seed, precise=dtype == torch.float32)
+        tr = LxFluxTransformer.synthetic(flux_config, device, seed, precise=dtype == torch.float32,
+                                         operands="fp16" if dtype == torch.float16 else "bf16")
         return cls.from_pipe(LxFluxPipeline(tr), synthetic_cs3_state_dict(seed), model_config, device, dtype=dtype)
 
     def load_lora(self, checkpoint_path: str):

@@ -162,6 +162,11 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
     mode = "precise (split-bf16 MFMA, fp32 attention)" if precise else "bf16 MFMA operands, fp32 accumulate / residual"
     if mc.get("gemm_fp8") or mc.get("attn_fp8"):
         mode = "fp8 e4m3 operands (" + " + ".join(k for k in ("gemm_fp8", "attn_fp8") if mc.get(k)) + "), fp32 accumulate / residual"
+    f16 = str(mc.get("operands", "bf16")).lower() in ("fp16", "f16", "float16") and not precise and not mc.get("gemm_fp8")
+    if f16:
+        mode = ("fp16 MFMA GEMM operands (bf16 attention operands), fp32 accumulate / residual" if not mc.get("attn_fp8")
+                else "fp16 MFMA GEMM operands + e4m3 attention operands, fp32 accumulate / residual")
+        brain_rec = dict(brain_rec, f16_saturated_waves=lx.engine.f16_overflow_count(), f16_weights_inexact_share=lx.engine.w16_inexact_share)
     rec = {"mode": mode,
            "oracle": "oracle/flux_ref.py fp32 on the same GPU (torch-ROCm), identical weights and inputs",
            "blocks": [num_layers, num_single_layers], "steps": steps, "tokens": [n_txt, N, N],

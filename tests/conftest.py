@@ -19,7 +19,7 @@ def golden_dir():
     return GOLDEN
 
 
-_GEMM_SWITCHES = ("LX_GEMM_BM", "LX_GEMM_PAIR", "LX_GEMM_PAIR_MIN_KT", "LX_GEMM_MIXED_ONE_GRID", "LX_GEMM4", "LX_GEMM4_SK", "LX_GEMM4_FAULT", "LX_GEMM4_Q8")
+_GEMM_SWITCHES = ("LX_GEMM_BM", "LX_GEMM4", "LX_GEMM4_SK", "LX_GEMM4_FAULT")          # = what read_gemm_env() in csrc/gemm.hip caches
 
 
 @pytest.fixture(autouse=True)

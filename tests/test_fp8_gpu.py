@@ -188,7 +188,7 @@ def _dq(img8, scale):
     return img8.view(torch.float8_e4m3fn).float() / scale
 
 
-@pytest.mark.parametrize("bm", [256, 128, "g4"])
+@pytest.mark.parametrize("bm", [256, 128])
 def test_gemm_qkv_epilogue_e4m3_images(ops, monkeypatch, bm):
     """The byte images of the fused epilogue (q / k after RMSNorm + RoPE, V^T in the f8f6f4 operand order) against (a) an fp64
     restatement of block.py:43-99 rounded once to e4m3 and (b) the images lx_qkv_prep_fp8_segs makes from the bf16 projection
@@ -196,12 +196,7 @@ def test_gemm_qkv_epilogue_e4m3_images(ops, monkeypatch, bm):
     kernel puts them, and the bf16 outputs are NOT written."""
     from oracle.flux_modules import apply_rotary_emb, rope_tables
     from loongx_amd import _lib
-    if bm == "g4":                      # lx_gemm4_kernel's form of the same epilogue (16-row blocks, a wave's 128 columns = one head)
-        monkeypatch.delenv("LX_GEMM_BM", raising=False)
-        monkeypatch.setenv("LX_GEMM4", "2")
-        monkeypatch.setenv("LX_GEMM4_Q8", "1")             # (off by default: measured 0.2 % slower per image than the 8-wave plan)
-    else:
-        monkeypatch.setenv("LX_GEMM_BM", str(bm))
+    monkeypatch.setenv("LX_GEMM_BM", str(bm))          # (the 8-wave kernels own this epilogue; lx_gemm4_kernel's copy of it went in round 5)
     _lib.lib.lx_gemm_reload_env()
     B, H, K = 2, 2, 192
     D = H * 128

@@ -29,14 +29,30 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-PLANS = [256, 128, "pair", "g4"]
+PLANS = [256, 128, "g4"]
+# the 16-bit operand format of a launch: bf16 (default) or IEEE fp16 (LX_OPERANDS_F16: same layouts, v_mfma_f32_*_f16, fp16 16-bit stores)
+FMTS = ["bf16", "f16"]
+STORE_TOL = {"bf16": 4e-3, "f16": 5e-4}        # relative error of a 16-bit store: 8 vs 11 significand bits
+
+
+def opd(t, fmt):
+    """a bf16 test operand in the launch's format (bf16 -> fp16 is exact for these magnitudes)"""
+    return t.to(torch.float16) if fmt == "f16" else t
+
+
+def fkw(fmt, ovf=None):
+    return dict(f16=True, f16_ovf=ovf) if fmt == "f16" else {}
+
+
+def out16(fmt):
+    return torch.float16 if fmt == "f16" else torch.bfloat16
 
 
 _WS = []
 
 
 def _ws():
-    """The caller-owned workspace the split-K pair plan needs (lx_gemm_bf16_ws); one for this test module's stream."""
+    """The caller-owned workspace the split form of lx_gemm4_kernel needs (lx_gemm_bf16_ws); one for this test module's stream."""
     if not _WS:
         from loongx_amd import ops as o
         _WS.append(o.gemm_workspace(DEV))
@@ -50,39 +66,37 @@ def _restore_gemm_env():
     yield
     if torch.cuda.is_available():
         from loongx_amd import _lib
-        for k in ("LX_GEMM_BM", "LX_GEMM_PAIR", "LX_GEMM4", "LX_GEMM4_SK"):
+        for k in ("LX_GEMM_BM", "LX_GEMM4", "LX_GEMM4_SK"):
             os.environ.pop(k, None)
         _lib.lib.lx_gemm_reload_env()
 
 
 def _plan(monkeypatch, bm):
-    """Force one launch plan: all 256-row tiles, all 128-row tiles, or two workgroups per 256-row tile, each half of K
-    ("pair": lx_gemm_pair_kernel wherever the launch has <= 128 tiles and K >= 128). Returns the workspace to launch with."""
+    """Force one launch plan: all 256-row tiles, all 128-row tiles (8-wave kernels), or lx_gemm4_kernel. Returns the workspace to launch with."""
     from loongx_amd import _lib
-    if bm == "pair":
-        monkeypatch.delenv("LX_GEMM_BM", raising=False)
-        monkeypatch.setenv("LX_GEMM_PAIR", "2")
-    elif bm == "g4":                      # lx_gemm4_kernel (one wave per SIMD) wherever its epilogues allow, whatever the tile count
+    if bm == "g4":                      # lx_gemm4_kernel (one wave per SIMD) wherever its epilogues allow, whatever the tile count
         monkeypatch.delenv("LX_GEMM_BM", raising=False)
         monkeypatch.setenv("LX_GEMM4", "2")
     else:
         monkeypatch.setenv("LX_GEMM_BM", str(bm))
     _lib.lib.lx_gemm_reload_env()
-    return _ws() if bm == "pair" else None
+    return None
 
 
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("bm", PLANS)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (2560, 3072, 3072)])
-def test_gemm_store_bf16_bias(ops, M, N, K, bm, monkeypatch):
+def test_gemm_store_bf16_bias(ops, M, N, K, bm, fmt, monkeypatch):
     ws = _plan(monkeypatch, bm)
-    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
-    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    A = opd(rnd(M, K, seed=1, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16), fmt)
     bias = rnd(N, seed=3)
-    Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias)], ws)
+    Cc = torch.full((M, N), float("nan"), dtype=out16(fmt), device=DEV)
+    ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, **fkw(fmt, ovf))], ws)
     ref = A.float() @ W.float().T + bias
-    assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
-    assert torch.isfinite(Cc.float()).all()
+    assert relerr(Cc.float().cpu(), ref.cpu()) < STORE_TOL[fmt]
+    assert torch.isfinite(Cc.float()).all() and int(ovf) == 0
 
 
 def test_gemm_asymmetric_identity(ops):
@@ -95,38 +109,40 @@ def test_gemm_asymmetric_identity(ops):
     assert torch.equal(Cc, W.float().T)
 
 
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("bm", PLANS)
-def test_gemm_gelu_colstart_and_f32(ops, bm, monkeypatch):
+def test_gemm_gelu_colstart_and_f32(ops, bm, fmt, monkeypatch):
     ws = _plan(monkeypatch, bm)
     M, N, K = 520, 1024, 192
-    A = rnd(M, K, seed=4, dtype=torch.bfloat16)
-    W = rnd(N, K, seed=5, scale=0.1, dtype=torch.bfloat16)
+    A = opd(rnd(M, K, seed=4, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=5, scale=0.1, dtype=torch.bfloat16), fmt)
     bias = rnd(N, seed=6, scale=0.1)
-    Cc = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=512)], ws)
+    Cc = torch.empty(M, N, dtype=out16(fmt), device=DEV)
+    ops.gemm([ops.gemm_desc(A, W, Cc, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, gelu_col_start=512, **fkw(fmt))], ws)
     ref = A.float() @ W.float().T + bias
     ref[:, 512:] = torch.nn.functional.gelu(ref[:, 512:], approximate="tanh")
-    assert relerr(Cc.float().cpu(), ref.cpu()) < 4e-3
+    assert relerr(Cc.float().cpu(), ref.cpu()) < STORE_TOL[fmt]
     C32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm([ops.gemm_desc(A, W, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32)], ws)
+    ops.gemm([ops.gemm_desc(A, W, C32, bias=bias, epilogue=ops.LX_EPI_STORE_F32, **fkw(fmt))], ws)
     assert relerr(C32.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("bm", PLANS)
-def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
+def test_gemm_gate_resid_lora_grouped(ops, bm, fmt, monkeypatch):
     """Three-stream launch: text (own weights), image (base weights), condition (base + LoRA), gated residual."""
     ws = _plan(monkeypatch, bm)
     B, T, Nn, Cn, D, K, r = 2, 48, 80, 96, 512, 256, 4
-    Wt = rnd(D, K, seed=1, scale=0.05, dtype=torch.bfloat16)
-    Wi = rnd(D, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    Wt = opd(rnd(D, K, seed=1, scale=0.05, dtype=torch.bfloat16), fmt)
+    Wi = opd(rnd(D, K, seed=2, scale=0.05, dtype=torch.bfloat16), fmt)
     bt, bi = rnd(D, seed=3, scale=0.1), rnd(D, seed=4, scale=0.1)
-    At = rnd(B * T, K, seed=5, dtype=torch.bfloat16)
-    Ai = rnd(B * Nn, K, seed=6, dtype=torch.bfloat16)
-    Ac = rnd(B * Cn, K, seed=7, dtype=torch.bfloat16)
+    At = opd(rnd(B * T, K, seed=5, dtype=torch.bfloat16), fmt)
+    Ai = opd(rnd(B * Nn, K, seed=6, dtype=torch.bfloat16), fmt)
+    Ac = opd(rnd(B * Cn, K, seed=7, dtype=torch.bfloat16), fmt)
     X = rnd(B * (T + Nn + Cn), D, seed=8)
     X0 = X.clone()
     gate = rnd(3 * B, D, seed=9)                       # [text b0,b1 | image b0,b1 | cond b0,b1]
-    Ad = rnd(r, K, seed=10, scale=0.1, dtype=torch.bfloat16)
+    Ad = opd(rnd(r, K, seed=10, scale=0.1, dtype=torch.bfloat16), fmt)
     Bu = rnd(D, r, seed=11, scale=0.1)
     Tl = torch.empty(B * Cn, r, dtype=torch.float32, device=DEV)
     ops.lora_down(Ac, Ad, Tl)
@@ -134,10 +150,10 @@ def test_gemm_gate_resid_lora_grouped(ops, bm, monkeypatch):
     assert relerr(Tl.cpu(), tref.cpu()) < 1e-5
     Xt, Xi, Xc = X[: B * T], X[B * T: B * (T + Nn)], X[B * (T + Nn):]
     ops.gemm([
-        ops.gemm_desc(At, Wt, Xt, bias=bt, epilogue=ops.LX_EPI_RESID_F32, gate=gate[0:B], rows_per_batch=T),
-        ops.gemm_desc(Ai, Wi, Xi, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[B:2 * B], rows_per_batch=Nn),
+        ops.gemm_desc(At, Wt, Xt, bias=bt, epilogue=ops.LX_EPI_RESID_F32, gate=gate[0:B], rows_per_batch=T, **fkw(fmt)),
+        ops.gemm_desc(Ai, Wi, Xi, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[B:2 * B], rows_per_batch=Nn, **fkw(fmt)),
         ops.gemm_desc(Ac, Wi, Xc, bias=bi, epilogue=ops.LX_EPI_RESID_F32, gate=gate[2 * B:], rows_per_batch=Cn,
-                      lora_t=Tl, lora_up=Bu),
+                      lora_t=Tl, lora_up=Bu, **fkw(fmt)),
     ], ws)
     def gated(y, g, L):
         return y * g.repeat_interleave(L, dim=0)
@@ -206,8 +222,9 @@ def test_gemm_pretiled_weight(ops, bm, monkeypatch):
     assert relerr(C1.cpu(), (A.float() @ W.float().T + bias).cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("sk", [0, 1])
-def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
+def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk, fmt):
     """lx_gemm4_kernel (4 waves x 128x128, AGPR accumulators) on a two-problem launch with every plain-epilogue ingredient it has: gated
     fp32 residual + bias + LoRA (rank 4, two K-split slabs) on one problem, bf16 store + GELU on the other (its last tile row ragged);
     280 tiles = one full round + a 24-tile tail. sk = 1 (LX_GEMM4_SK): the tail's tiles by two workgroups each, half of K, meeting
@@ -218,22 +235,22 @@ def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
     ops.lib.lx_gemm_reload_env()
     ws = _ws()
     M1, M2, N, K, r = 768, 352, 256 * 56, 2048, 4          # 3 x 56 + 2 x 56 = 280 tiles (the second problem's last tile row is ragged)
-    A1 = rnd(M1, K, seed=1, dtype=torch.bfloat16); A2 = rnd(M2, K, seed=2, dtype=torch.bfloat16)
-    W = rnd(N, K, seed=3, scale=0.03, dtype=torch.bfloat16)
+    A1 = opd(rnd(M1, K, seed=1, dtype=torch.bfloat16), fmt); A2 = opd(rnd(M2, K, seed=2, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=3, scale=0.03, dtype=torch.bfloat16), fmt)
     Wt = ops.tile_weight(W.clone())
     bias = rnd(N, seed=4, scale=0.1)
     gate = rnd(3, N, seed=5)
     X0 = rnd(M1, N, seed=6)
-    Ad = rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16); Bu = rnd(N, r, seed=8, scale=0.1)
+    Ad = opd(rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16), fmt); Bu = rnd(N, r, seed=8, scale=0.1)
     Tl = torch.zeros(2, M1, 16, dtype=torch.float32, device=DEV)
     ops.lora_down(A1, Ad, Tl[0, :, :r], n_split=2, split_stride=Tl.stride(0))
 
     def run():
         X = X0.clone()
-        C2 = torch.zeros(M2, N, dtype=torch.bfloat16, device=DEV)
+        C2 = torch.zeros(M2, N, dtype=out16(fmt), device=DEV)
         ops.gemm([ops.gemm_desc(A1, Wt, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, rows_per_batch=256, lora_t=Tl[0, :, :r], lora_up=Bu,
-                                lora_nsplit=2, lora_split_stride=Tl.stride(0)),
-                  ops.gemm_desc(A2, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU)], ws)
+                                lora_nsplit=2, lora_split_stride=Tl.stride(0), **fkw(fmt)),
+                  ops.gemm_desc(A2, Wt, C2, bias=bias, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, **fkw(fmt))], ws)
         return X, C2
     X, C2 = run()
     t = A1.float() @ Ad.float().T
@@ -241,7 +258,7 @@ def test_gemm4_one_wave_per_simd_kernel(ops, monkeypatch, sk):
     ref1 = X0 + gate.repeat_interleave(256, 0)[:M1] * y
     ref2 = torch.nn.functional.gelu(A2.float() @ W.float().T + bias, approximate="tanh")
     assert relerr(X.cpu(), ref1.cpu()) < 2e-5
-    assert relerr(C2.float().cpu(), ref2.cpu()) < 4e-3
+    assert relerr(C2.float().cpu(), ref2.cpu()) < STORE_TOL[fmt]
     Xb, C2b = run()
     assert torch.equal(X, Xb) and torch.equal(C2, C2b)
     ops.gemm_workspace_status(ws)
@@ -284,33 +301,35 @@ def test_gemm_workspace_error_word_position(ops):
     assert not bool(ws[n - 64 * 4:].any())
 
 
-def test_gemm_pair_kernel_long_k(ops, monkeypatch):
-    """Two workgroups per tile on the single-block proj_out shape (120 tiles, K = 15360, gated fp32 residual + LoRA): against the
-    128-row-tile kernel on the same inputs, bit-identical from run to run, and again after HIP-graph capture + replays (each
-    flag is cleared by its reader, so replays need no reset)."""
+@pytest.mark.parametrize("fmt", FMTS)
+def test_gemm_split_form_long_k(ops, monkeypatch, fmt):
+    """Two workgroups per tile (lx_gemm4_kernel's split form, the default plan of a long-K launch of <= 128 tiles) on the single-block
+    proj_out shape (120 tiles, K = 15360, gated fp32 residual + LoRA): against the plans without a workspace on the same inputs,
+    bit-identical from run to run, and again after HIP-graph capture + replays (each flag is cleared by its reader, so replays need no
+    reset); two streams with their own workspaces run it concurrently."""
     monkeypatch.delenv("LX_GEMM_BM", raising=False)
     ops.lib.lx_gemm_reload_env()
     M, N, K, r = 2560, 3072, 15360, 4
-    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
-    W = rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16)
+    A = opd(rnd(M, K, seed=1, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16), fmt)
     bias = rnd(N, seed=3, scale=0.1)
     gate = rnd(1, N, seed=4)
     X0 = rnd(M, N, seed=5)
-    Ad = rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16)
+    Ad = opd(rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16), fmt)
     Bu = rnd(N, r, seed=8, scale=0.1)
     Tls = torch.zeros(4, M, 16, dtype=torch.float32, device=DEV)
     ops.lora_down(A, Ad, Tls[0][:, :r], n_split=4, split_stride=Tls.stride(0))
     out = {}
     X = torch.empty_like(X0)
     d = ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
-                      lora_split_stride=Tls.stride(0))
+                      lora_split_stride=Tls.stride(0), **fkw(fmt))
     ws = _ws()
     for mode in ("0", "2"):
         X.copy_(X0)
-        ops.gemm([d], ws if mode == "2" else None)          # default LX_GEMM_PAIR=1: the pair plan runs iff a workspace is given
+        ops.gemm([d], ws if mode == "2" else None)          # the split form runs iff a workspace is given
         torch.cuda.synchronize()
         out[mode] = X.clone()
-    ops.gemm_workspace_status(ws)                            # no pair workgroup timed out
+    ops.gemm_workspace_status(ws)                            # no split workgroup timed out
     t = Tls.sum(0)[:, :r]
     ref = X0 + gate * (A.float() @ W.float().T + bias + t @ Bu.T)
     assert relerr(out["2"].cpu(), ref.cpu()) < 2e-5
@@ -327,10 +346,10 @@ def test_gemm_pair_kernel_long_k(ops, monkeypatch):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(X, out["2"])
-    # two streams, each with its OWN workspace, may run the pair plan concurrently (the library keeps no scratch of its own)
+    # two streams, each with its OWN workspace, may run the split form concurrently (the library keeps no scratch of its own)
     ws2, X2 = ops.gemm_workspace(DEV), X0.clone()
     d2 = ops.gemm_desc(A, W, X2, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
-                       lora_split_stride=Tls.stride(0))
+                       lora_split_stride=Tls.stride(0), **fkw(fmt))
     s2 = torch.cuda.Stream()
     torch.cuda.synchronize()
     X.copy_(X0)
@@ -343,24 +362,25 @@ def test_gemm_pair_kernel_long_k(ops, monkeypatch):
     ops.gemm_workspace_status(ws); ops.gemm_workspace_status(ws2)
 
 
-def test_gemm_planner_mixed_tail(ops, monkeypatch):
+@pytest.mark.parametrize("fmt", FMTS)
+def test_gemm_planner_mixed_tail(ops, monkeypatch, fmt):
     """No LX_GEMM_BM override: 280 tiles of 256x256 -> the planner runs full rounds of 256-row tiles plus a 128-row-tile
     tail launch. Gate batch index, LoRA rows and residual must stay right across the split."""
     monkeypatch.delenv("LX_GEMM_BM", raising=False)
     ops.lib.lx_gemm_reload_env()
     M1, M2, N, K, r = 1536, 1024, 7168, 128, 4
-    A = rnd(M1 + M2, K, seed=1, dtype=torch.bfloat16)
-    W = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    A = opd(rnd(M1 + M2, K, seed=1, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16), fmt)
     bias = rnd(N, seed=3, scale=0.1)
     X = rnd(M1 + M2, N, seed=4)
     X0 = X.clone()
     g1, g2 = rnd(3, N, seed=5), rnd(4, N, seed=6)            # 3 batches of 512 rows, 4 batches of 256 rows
-    Ad = rnd(r, K, seed=7, scale=0.1, dtype=torch.bfloat16)
+    Ad = opd(rnd(r, K, seed=7, scale=0.1, dtype=torch.bfloat16), fmt)
     Bu = rnd(N, r, seed=8, scale=0.1)
     Tl = torch.empty(M2, r, dtype=torch.float32, device=DEV)
     ops.lora_down(A[M1:], Ad, Tl)
-    ops.gemm([ops.gemm_desc(A[:M1], W, X[:M1], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g1, rows_per_batch=512),
-              ops.gemm_desc(A[M1:], W, X[M1:], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g2, rows_per_batch=256, lora_t=Tl, lora_up=Bu)])
+    ops.gemm([ops.gemm_desc(A[:M1], W, X[:M1], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g1, rows_per_batch=512, **fkw(fmt)),
+              ops.gemm_desc(A[M1:], W, X[M1:], bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=g2, rows_per_batch=256, lora_t=Tl, lora_up=Bu, **fkw(fmt))])
     y = A.float() @ W.float().T + bias
     y[M1:] += (A[M1:].float() @ Ad.float().T) @ Bu.T
     ref = X0 + y * torch.cat([g1.repeat_interleave(512, 0), g2.repeat_interleave(256, 0)])
