@@ -270,6 +270,9 @@ typedef struct lx_attn_desc {
   int32_t n_qseg;        /* 0 / n_seg: every segment has queries. k < n_seg: only segments 0..k-1 do (keys and values of all n_seg segments
                           * are still attended to): the rows of the other segments of O are not written */
   int32_t flags;         /* LX_ATTN_* below (0 = the plain contract above) */
+  int32_t qseg_mask;     /* 0: the query segments are the first n_qseg (above). Otherwise bit s set = segment s has queries, any subset (n_qseg is then
+                          * ignored): the last single block of a forward needs the image rows' output only (transformer.py:243-252) -- its text and
+                          * condition rows serve keys and values, and their q columns are not even computed */
   int32_t* f16_ovf;      /* LX_ATTN_O_F16: device counter, += the number of waves that saturated an output value (NULL: not reported) */
 } lx_attn_desc;
 /* LX_ATTN_Q_LOG2: q already carries scale * log2(e) (e.g. folded into the norm_q weight handed to LX_EPI_QKV / lx_qkv_prep): the kernel

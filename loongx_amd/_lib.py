@@ -46,7 +46,7 @@ class AttnDesc(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("n_seg", C.c_int32),
                 ("seg_row0", C.c_int32 * 3), ("seg_len", C.c_int32 * 3), ("seg_vt0", C.c_int32 * 3),
                 ("bias", (C.c_float * 3) * 3), ("scale", C.c_float), ("n_qseg", C.c_int32), ("flags", C.c_int32),
-                ("f16_ovf", C.c_void_p)]
+                ("qseg_mask", C.c_int32), ("f16_ovf", C.c_void_p)]
 
 
 LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT, LX_ATTN_O_F16 = 1, 2, 4, 8

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const
   // ---- epilogue: O[q, d] = O^T / l ; lane holds d = db*32 + 8*(r>>2) + 4*lhi + (r&3) --------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
+  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
 #endif
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
+  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
+  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 #endif
   const float l_tot = __shfl(lacc[0], l31, 64);          // lanes 0-31 hold the sum of query l31
   const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  lx_store_o(args, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
+  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
 
 }  // namespace
@@ -1326,6 +1326,13 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 static int lx_attn_wide_store(const lx_attn_desc* d) {
   static const bool on = [] { const char* e = getenv("LX_ATTN_WIDE_STORE"); return e ? atoi(e) != 0 : true; }();
   return on && d->ldo % 8 == 0 && d->o_col % 8 == 0 && ((uintptr_t)d->O & 15) == 0;
+}
+
+// which segments have queries: qseg_mask when given, else the first n_qseg (0: all)
+static int lx_attn_qmask(const lx_attn_desc* d) {
+  if (d->qseg_mask != 0) return d->qseg_mask;
+  const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
+  return (1 << nq) - 1;
 }
 
 static thread_local int lx_attn_last = LX_ATTN_KERNEL_NONE;
@@ -1345,7 +1352,8 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   const int qblk = nw * 32;
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd: n_qseg=%d must be 0..n_seg", d->n_qseg);
-  const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
+  LX_CHECK_ARG(d->qseg_mask >= 0 && d->qseg_mask < (1 << d->n_seg), "lx_attn_fwd: qseg_mask=%d names a segment >= n_seg", d->qseg_mask);
+  const int qmask = lx_attn_qmask(d);
   AttnArgs a;
   a.d = *d;
   a.wide_store = lx_attn_wide_store(d);
@@ -1359,7 +1367,7 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
       LX_CHECK_ARG(d->seg_vt0[s] % 64 == 0, "lx_attn_fwd: seg_vt0 must be 64-aligned");
       bool any = false;
       for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
-      if (s >= nq) continue;                 // a segment without queries (n_qseg): keys / values only
+      if (!((qmask >> s) & 1)) continue;     // a segment without queries (n_qseg / qseg_mask): keys / values only
       LX_CHECK_ARG(any, "lx_attn_fwd: query segment %d is masked from every key segment", s);
       t += (d->seg_len[s] + qblk - 1) / qblk;
     }
@@ -1370,8 +1378,8 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT | LX_ATTN_O_F16)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
                "lx_attn_fwd: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
   bool any_bias = false;                       // a finite non-zero bias on a pair that is attended to
-  for (int s = 0; s < nq; ++s)
-    for (int k = 0; k < d->n_seg; ++k) any_bias |= d->bias[s][k] > -1e37f && d->bias[s][k] != 0.f;
+  for (int s = 0; s < d->n_seg; ++s)
+    for (int k = 0; k < d->n_seg; ++k) any_bias |= ((qmask >> s) & 1) && d->bias[s][k] > -1e37f && d->bias[s][k] != 0.f;
   static const bool nomax_ok = [] { const char* e = getenv("LX_ATTN_NOMAX"); return e ? atoi(e) != 0 : true; }();
   // lx_attn4_kernel (attn4.hip: one wave per SIMD, every K / V^T fragment feeds two MFMAs, persistent over the query tiles) serves the
   // bounded-score contract; its staging addresses a tile as buffer base + 32-bit byte offsets, so the K column block and the V^T image
@@ -1424,7 +1432,8 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG((d->flags & ~LX_ATTN_O_F16) == 0, "lx_attn_fwd_fp8: the only flag is LX_ATTN_O_F16 (the e4m3 kernels fold their own scales)");
   static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
-  const int nq = d->n_qseg > 0 ? d->n_qseg : d->n_seg;
+  LX_CHECK_ARG(d->qseg_mask >= 0 && d->qseg_mask < (1 << d->n_seg), "lx_attn_fwd_fp8: qseg_mask=%d names a segment >= n_seg", d->qseg_mask);
+  const int qmask = lx_attn_qmask(d);
   AttnArgs a;
   a.d = *d;
   a.wide_store = lx_attn_wide_store(d);
@@ -1437,7 +1446,7 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
       LX_CHECK_ARG(d->seg_vt0[s] % 64 == 0, "lx_attn_fwd_fp8: seg_vt0 must be 64-aligned");
       bool any = false;
       for (int k = 0; k < d->n_seg; ++k) any |= d->bias[s][k] > -1e37f;
-      if (s >= nq) continue;
+      if (!((qmask >> s) & 1)) continue;
       LX_CHECK_ARG(any, "lx_attn_fwd_fp8: query segment %d is masked from every key segment", s);
       t += (d->seg_len[s] + 255) / 256;
     }

@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
   const float b00 = D.bias[0][0], b01 = D.bias[0][1], b02 = D.bias[0][2], b10 = D.bias[1][0], b11 = D.bias[1][1], b12 = D.bias[1][2],
               b20 = D.bias[2][0], b21 = D.bias[2][1], b22 = D.bias[2][2];
   const int qs1 = args.qt_start[1], qs2 = args.qt_start[2];
+  // the output format / store shape and the overflow word, as register VALUES before the item loop (see lx_store_o: no kernel-argument
+  // load may appear inside that loop)
+  int o_mode = __builtin_amdgcn_readfirstlane(lx_o_mode(args));
+  uint32_t ovf_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)D.f16_ovf), ovf_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)D.f16_ovf >> 32));
+  asm volatile("" : "+s"(o_mode), "+s"(ovf_lo), "+s"(ovf_hi));
+  int* const o_ovf = (int*)(((uintptr_t)ovf_hi << 32) | (uintptr_t)ovf_lo);
   auto pick = [](int s, auto x0, auto x1, auto x2) { return s == 0 ? x0 : (s == 1 ? x1 : x2); };
   auto seg_len = [&](int s) { return pick(s, len0, len1, len2); };
   const int ldk = D.ldk, vt_ld = D.vt_ld, ldq = D.ldq;
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       const int q_in_seg = C.q_tile0 + wave * 64 + l31 + 32 * qb;
       const size_t q_row = (size_t)C.q_row0 + min(q_in_seg, C.q_len - 1);
-      lx_store_o(args, q_in_seg < C.q_len, (uint16_t*)D.O + q_row * D.ldo + D.o_col + C.h * DH, oacc[qb], inv, lhi);
+      lx_store_o(o_mode, o_ovf, q_in_seg < C.q_len, (uint16_t*)D.O + q_row * D.ldo + D.o_col + C.h * DH, oacc[qb], inv, lhi);
     }
     if (!more) break;
     C = decode(T0.w);

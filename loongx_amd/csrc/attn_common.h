@@ -35,46 +35,51 @@ struct AttnArgs {
 // wide: for each pair of groups (rq, rq+1) one v_permlane32_swap per dword hands the lower half-wave the upper half's group rq and
 // the upper half-wave the lower half's group rq+1: every lane then owns 16 contiguous bytes -> 8 dwordx4 stores per lane instead of
 // 16 dwordx2, same bytes, same addresses (the store tail of a row-per-lane epilogue is store-ISSUE bound: guide T21).
-// F16 (lx_attn_desc.flags & LX_ATTN_O_F16): O is the fp16 operand image of an LX_OPERANDS_F16 projection (to_out / proj_out), rounded to
-// nearest even and saturated; `mx` collects max |o| for the overflow report.
-template <bool F16>
-__device__ __forceinline__ void lx_store_o_fmt(uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi, bool wide, float& mx) {
-  if (wide) {
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; rq += 2) {
-        const uint32_t a0 = pack_op16x2<F16>(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, mx);
-        const uint32_t a1 = pack_op16x2<F16>(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, mx);
-        const uint32_t b0 = pack_op16x2<F16>(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv, mx);
-        const uint32_t b1 = pack_op16x2<F16>(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv, mx);
-        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        *(u32x4*)(row + db * 32 + 8 * (rq + lhi)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
-      }
-  } else {
-    uint16_t* op = row + 4 * lhi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 o;
-        o[0] = pack_op16x2<F16>(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, mx);
-        o[1] = pack_op16x2<F16>(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, mx);
-        *(u32x2*)(op + db * 32 + rq * 8) = o;
-      }
-  }
+// Output format (lx_attn_desc.flags & LX_ATTN_O_F16): bf16, or the fp16 operand image of an LX_OPERANDS_F16 projection (to_out / proj_out:
+// nearest even, saturated; `mx` collects max |o| for the overflow report). The format is a per-value SELECT, not a branch: the accumulators
+// are read at ONE place whatever the format. lx_attn4_kernel keeps O^T in AGPRs behind inline-asm MFMAs across its persistent item loop,
+// and a second read site in another branch made hipcc reconcile AGPR assignments at the join -- moves its hazard recogniser cannot order
+// against MFMAs it cannot see: the kernel turned nondeterministic (round 5). 64 extra conversions per row and item: not measurable.
+__device__ __forceinline__ uint32_t lx_pack_o(float lo, float hi, bool f16, float& mx) {
+  const uint32_t b = pack_bf16x2(lo, hi);
+  const uint32_t h = pack_f16x2_sat(lo, hi, mx);
+  return f16 ? h : b;
 }
 // (the swap inside exchanges data between the two half-waves of a row: both halves of a row must be valid or invalid together; `valid`
-//  guards the stores of rows past the segment, `args` names the output format and the overflow word)
-__device__ __forceinline__ void lx_store_o(const AttnArgs& args, bool valid, uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi) {
+//  guards the stores of rows past the segment.) `mode` = lx_o_mode(args): bit 0 wide stores, bit 1 fp16 output; `ovf` = the overflow
+//  word. Both are VALUES the kernel computes once, up front: no kernel-argument load inside lx_attn4_kernel's item loop.
+__device__ __forceinline__ int lx_o_mode(const AttnArgs& args) { return (args.wide_store != 0 ? 1 : 0) | ((args.d.flags & LX_ATTN_O_F16) ? 2 : 0); }
+__device__ __forceinline__ void lx_store_o(int mode, int* ovf, bool valid, uint16_t* row, const f32x16 (&oacc)[4], float inv, int lhi) {
   float mx = 0.f;
-  if (args.d.flags & LX_ATTN_O_F16) {
-    if (valid) lx_store_o_fmt<true>(row, oacc, inv, lhi, args.wide_store != 0, mx);
-    report_f16_overflow(mx, (int*)args.d.f16_ovf);
-  } else if (valid) {
-    lx_store_o_fmt<false>(row, oacc, inv, lhi, args.wide_store != 0, mx);
+  const bool f16 = (mode & 2) != 0;
+  if (valid) {
+    if (mode & 1) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; rq += 2) {
+          const uint32_t a0 = lx_pack_o(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, f16, mx);
+          const uint32_t a1 = lx_pack_o(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, f16, mx);
+          const uint32_t b0 = lx_pack_o(oacc[db][rq * 4 + 4] * inv, oacc[db][rq * 4 + 5] * inv, f16, mx);
+          const uint32_t b1 = lx_pack_o(oacc[db][rq * 4 + 6] * inv, oacc[db][rq * 4 + 7] * inv, f16, mx);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          *(u32x4*)(row + db * 32 + 8 * (rq + lhi)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+    } else {
+      uint16_t* op = row + 4 * lhi;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          u32x2 o;
+          o[0] = lx_pack_o(oacc[db][rq * 4 + 0] * inv, oacc[db][rq * 4 + 1] * inv, f16, mx);
+          o[1] = lx_pack_o(oacc[db][rq * 4 + 2] * inv, oacc[db][rq * 4 + 3] * inv, f16, mx);
+          *(u32x2*)(op + db * 32 + rq * 8) = o;
+        }
+    }
   }
+  if (f16) report_f16_overflow(mx, ovf);
 }
 
 }  // namespace

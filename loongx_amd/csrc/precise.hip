@@ -722,7 +722,7 @@ extern "C" int lx_qkv_prep_split_segs(const float* QKV, int ld, int q_col, int k
 extern "C" int lx_attn_fwd_split(const lx_attn_desc* d, int qk_lo_off, long long vt_lo_off, int o_lo_off, void* stream) {
   LX_CHECK_ARG(d && d->Q && d->K && d->VT && d->O, "lx_attn_fwd_split: NULL operand");
   LX_CHECK_ARG(d->n_seg >= 1 && d->n_seg <= 3, "lx_attn_fwd_split: n_seg=%d must be 1..3", d->n_seg);
-  LX_CHECK_ARG(d->B >= 1 && d->H >= 1 && d->n_qseg == 0, "lx_attn_fwd_split: bad B/H (n_qseg is not supported here)");
+  LX_CHECK_ARG(d->B >= 1 && d->H >= 1 && d->n_qseg == 0 && d->qseg_mask == 0, "lx_attn_fwd_split: bad B/H (n_qseg / qseg_mask are not supported here)");
   LX_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd_split: ldq/ldk %% 8, ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 8 == 0 && d->k_col % 8 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_split: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_lo_off % 8 == 0 && qk_lo_off >= d->H * 128 && vt_lo_off % 8 == 0 && vt_lo_off > 0 && o_lo_off % 4 == 0 && o_lo_off >= 0,

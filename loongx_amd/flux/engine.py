@@ -742,7 +742,9 @@ class DiTEngine:
             return False
         return not self.model_config.get("attn_fp8", False) or os.environ.get("LX_QKV_FUSED_FP8", "1") != "0"
 
-    def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False, layer: Optional[int] = None) -> None:
+    def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False, layer: Optional[int] = None, img_only: bool = False) -> None:
+        """img_only: only the image segment has queries (the last single block of a forward: the text / condition rows serve keys and values,
+        their q columns were not computed and hold whatever the previous layer left there)."""
         cfg = self.cfg
         D, H, B = cfg.inner_dim, cfg.num_attention_heads, self.B
         Y = self.Y
@@ -769,6 +771,8 @@ class DiTEngine:
         if not self.pair_plan:             # the batch-size-invariant plans: the attention kernel must not depend on the batch size either
             flags |= ops.ATTN_INVARIANT
         okw = dict(f16_ovf=self.f16_ovf) if self.f16 else {}      # O is the output projection's A operand: fp16 in the fp16 operand mode
+        if img_only:
+            okw["qseg_mask"] = 1 << [s for s, _ in streams].index("img")
         if self.f16:
             flags |= ops.ATTN_O_F16
         if self.model_config.get("attn_fp8", False):
@@ -784,7 +788,8 @@ class DiTEngine:
             # keys from the layer's key image, V^T from the layer's V^T image (the condition stream's part written by the first
             # forward of this conditioning); in a cond_skip forward only the text / image segments have queries
             ops.attn_fwd(Y, self.KC[layer], self.VTC[layer], Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0,
-                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=len(self._streams()) if self.cond_skip else 0, flags=flags, **okw)
+                         seg_len=seg_len, seg_vt0=seg_vt0, bias=bias, n_qseg=(len(self._streams()) if self.cond_skip else 0) if not img_only else 0,
+                         flags=flags, **okw)
             return
         if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
             ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
@@ -857,13 +862,13 @@ class DiTEngine:
                 join.record(side)
             self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=3,
                                cols=(0, 3 * D), ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None, lora=lora)
-            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j)
+            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
             main_s.wait_event(join)
         else:
             self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
                                lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None,
                                lora=ln_lora)
-            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j)
+            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)

@@ -340,16 +340,25 @@ ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16 = L.LX_ATTN_Q_LOG2, L.LX_A
 Q_LOG2_FACTOR = (1.0 / math.sqrt(128.0)) * 1.4426950408889634       # what LX_ATTN_Q_LOG2 expects q to carry already
 
 
-def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0, flags=0, f16_ovf=None) -> None:
-    """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values).
+def _q_rows(seg_len, n_qseg, qseg_mask):
+    if qseg_mask:
+        return sum(L_ for i, L_ in enumerate(seg_len) if (qseg_mask >> i) & 1)
+    return sum(seg_len[:n_qseg]) if n_qseg else sum(seg_len)
+
+
+def attn_fwd(Q, K, VT, O, *, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, n_qseg=0, flags=0, f16_ovf=None,
+             qseg_mask=0) -> None:
+    """n_qseg = k > 0: only the first k segments have queries (all segments still serve keys / values); qseg_mask != 0: exactly the
+    segments whose bit is set (any subset).
     flags: ATTN_Q_LOG2 [| ATTN_BOUNDED] (include/lx.h): q carries scale * log2 e; the caller bounds the scores -> no running max."""
     d = _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
     d.n_qseg = n_qseg
     d.flags = flags
+    d.qseg_mask = qseg_mask
     d.f16_ovf = _p(f16_ovf)               # (ATTN_O_F16: O is written as fp16, saturated; int32 device counter of clipping waves)
     if TIMER is not None:
         S = sum(seg_len)
-        Sq = sum(seg_len[:n_qseg]) if n_qseg else S
+        Sq = _q_rows(seg_len, n_qseg, qseg_mask)
         s, e = TIMER.bracket("attn", 4.0 * B * H * Sq * S * 128)
         s.record()
         check(lib.lx_attn_fwd(C.byref(d), _stream()), "lx_attn_fwd")
@@ -378,14 +387,14 @@ def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8,
                                    _stream()), "lx_qkv_prep_fp8_segs")
 
 
-def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, flags=0, f16_ovf=None) -> None:
-    """flags: 0 | ATTN_O_F16 (O written as fp16 for an fp16-operand output projection)"""
+def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, flags=0, f16_ovf=None, qseg_mask=0) -> None:
+    """flags: 0 | ATTN_O_F16 (O written as fp16 for an fp16-operand output projection); qseg_mask as in attn_fwd"""
     d = _attn_desc(Q8, K8, VT8, O, 0, 0, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
-    d.flags, d.f16_ovf = flags, _p(f16_ovf)
+    d.flags, d.f16_ovf, d.qseg_mask = flags, _p(f16_ovf), qseg_mask
     args = (C.byref(d), 1.0 / (FP8_Q_SCALE * FP8_K_SCALE), 1.0 / FP8_V_SCALE, _stream())
     if TIMER is not None:
         S = sum(seg_len)
-        s, e = TIMER.bracket("attn", 4.0 * B * H * S * S * 128)
+        s, e = TIMER.bracket("attn", 4.0 * B * H * _q_rows(seg_len, 0, qseg_mask) * S * 128)
         s.record()
         check(lib.lx_attn_fwd_fp8(*args), "lx_attn_fwd_fp8")
         e.record()

@@ -761,6 +761,34 @@ def test_attention_segments(ops, lens, mode):
     assert torch.equal(buf[:, : 2 * D], orig[:, : 2 * D])   # K and V columns untouched
 
 
+@pytest.mark.parametrize("mask", [0b010, 0b101, 0b100])
+def test_attention_query_segment_mask(ops, mask):
+    """lx_attn_desc.qseg_mask: any subset of the segments has queries (the last single block of a forward: image rows only). The rows of
+    the chosen segments equal the full launch's bit for bit; the other segments' O rows are not written."""
+    lens = (64, 128, 200)
+    B, H = 2, 3
+    D = H * 128
+    buf = _qkv_buffer(B, lens, H, seed=5)
+    row0, vt0, vt_len = _segments(B, lens)
+    VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=DEV)
+    for s_, Ls in enumerate(lens):
+        ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=row0[s_], n_rows=B * Ls, rows_per_batch=Ls, H=H, wq=None, wk=None,
+                     cos=None, sin=None, VT=VT, vt_pos0=vt0[s_])
+    kw = dict(q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=BIASES["cfactor"])
+    full = torch.full((buf.shape[0], D), 7.0, dtype=torch.bfloat16, device=DEV)
+    part = torch.full((buf.shape[0], D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(buf, buf, VT, full, **kw)
+    ops.attn_fwd(buf, buf, VT, part, qseg_mask=mask, **kw)
+    for s_, Ls in enumerate(lens):
+        rows = slice(row0[s_], row0[s_] + B * Ls)
+        if (mask >> s_) & 1:
+            assert torch.equal(part[rows], full[rows])
+        else:
+            assert bool((part[rows] == 7.0).all())
+    with pytest.raises(RuntimeError, match="qseg_mask"):
+        ops.attn_fwd(buf, buf, VT, part, qseg_mask=0b1000, **kw)
+
+
 def test_attention_single_segment_spike(ops):
     """One segment; a spiked key forces a large running-max jump mid-sequence (online-softmax rescale path)."""
     B, H, Ls = 1, 1, 320
