@@ -17,9 +17,10 @@ draws the weights and broadcasts them over RCCL/xGMI before the timed region.  P
 `--config {1,2,3,4}` sets batch / resolution / modalities / fp8-attention from BASELINE.json's configs (per-GPU batch = the
 config's global batch / N), e.g. `bench.py --gpus 8 --config 3` is the literal configs[3] run. With N = 1 and no explicit
 workload flags the line also carries `secondary`: short bounded legs (2 timed batches each, outside the headline's timed region)
-of the other BASELINE configs on this GPU -- configs[2] (batch 16, all four modalities), configs[4]'s per-GPU shape (1024x1024,
-batch 4) in bf16 and with the fp8 attention path, and the precise mode -- each with its own roofline, power and (fp8 / precise)
-full-depth parity figures; `--no-secondary` skips them.
+on this GPU -- the headline workload with fp16 GEMM operand images (`fp16_operands`: the north star's 1e-3 per forward) and on
+weights with a trained checkpoint's statistics (`realistic_stats`), then the other BASELINE configs: configs[2] (batch 16, all four
+modalities), configs[4]'s per-GPU shape (1024x1024, batch 4) in bf16 and with the fp8 attention path, and the precise mode -- each with
+its own roofline, power and full-depth parity figures; `--no-secondary` skips them.
 
 Besides the contract fields the line carries `roofline` (dominant kernel, live HIP events), `cpu_baseline` (the oracle on
 this box's host cores, bounded sample) and `parity` (the engine against the fp32 oracle on identical inputs at
@@ -236,13 +237,13 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1, brain=None):
+def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1, brain=None, realistic: bool = False):
     """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
     timed region) at full depth and width on this GPU, in the mode the timed region ran."""
     from oracle.parity import full_depth_parity
     mc = {"union_cond_attn": True}
     mc.update(extra_mc or {})
-    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc, hw=hw, every=every, brain=brain)
+    return full_depth_parity("cuda:0", steps=STEPS, precise=precise, model_config=mc, hw=hw, every=every, brain=brain, realistic=realistic)
 
 
 # BASELINE.json configs -> workload (global batch, latent grid side, modalities, extra model_config)
@@ -514,7 +515,12 @@ def main():
                 res["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and plain and not a.no_secondary:
             # ---- the other BASELINE configs on this GPU, outside the headline's timed region (bounded: 2 timed batches each) ----
-            legs = [dict(config=2, B=16, hw=32, allmod=True, mc={}, precise=False, parity=[(32, 4)]),
+            # fp16_operands: the headline workload with fp16 GEMM operand images (north star: 1e-3 per forward at the bf16 mode's matrix rate);
+            # realistic_stats: the headline workload on weights with a trained checkpoint's statistics (oracle.parity.realistic_stats_: mixed
+            # bounded / max-tracking attention plan, outlier channels, biases) -- what the headline would do on a real checkpoint
+            legs = [dict(name="fp16_operands", config=1, B=1, hw=32, allmod=False, mc={"operands": "fp16"}, precise=False, parity=[(32, 4)]),
+                    dict(name="realistic_stats", config=1, B=1, hw=32, allmod=False, mc={}, precise=False, parity=[(32, 9)], realistic=True),
+                    dict(config=2, B=16, hw=32, allmod=True, mc={}, precise=False, parity=[(32, 4)]),
                     dict(config=None, B=4, hw=64, allmod=True, mc={}, precise=False, parity=None),
                     dict(config=4, B=4, hw=64, allmod=True, mc={"attn_fp8": True}, precise=False, parity=[(32, 1), (64, 7)]),
                     dict(config=None, B=1, hw=32, allmod=False, mc={}, precise=True, parity=[(32, 4)])]
@@ -522,19 +528,29 @@ def main():
             for lg in legs:
                 t_leg = time.time()
                 try:
-                    r = run_leg(pw, dev, 0, 1, B=lg["B"], hw=lg["hw"], allmod=lg["allmod"], mc=lg["mc"], precise=lg["precise"],
+                    pw_leg, real_rec = pw, None
+                    if lg.get("realistic"):
+                        from loongx_amd.flux.weights import realistic_stats_
+                        pw_leg = synthetic_weights(cfg, dev, seed=1)
+                        realistic_stats_(pw_leg, seed=0)
+                    r = run_leg(pw_leg, dev, 0, 1, B=lg["B"], hw=lg["hw"], allmod=lg["allmod"], mc=lg["mc"], precise=lg["precise"],
                                 steps=a.secondary_steps, warmup=1, events=not a.no_roofline_events, seed=99)
+                    del pw_leg
+                    if lg.get("name"):
+                        r["leg"] = lg["name"]
                     m2 = dict(lg["mc"]); m2.setdefault("union_cond_attn", True)
                     r["config"] = {"workload": workload_name(lg["config"], lg["B"], lg["hw"], lg["allmod"], m2, lg["precise"]) +
                                                (" (per-GPU share of the 8-GPU config: batch 32 / 8)" if lg["config"] == 4 else
-                                                " (bf16 reference line for the fp8-attention leg)" if lg["hw"] == 64 else ""),
+                                                " (bf16 reference line for the fp8-attention leg)" if lg["hw"] == 64 else
+                                                " -- weights with a trained checkpoint's statistics (loongx_amd.flux.weights.realistic_stats_; its parity: the same recipe on the oracle side)" if lg.get("realistic") else ""),
                                    "batch_per_gpu": lg["B"], "global_batch": lg["B"], "parallelism": "dp1"}
                     if lg["parity"] and not a.no_parity:
                         r["parity"] = {}
                         for phw, every in lg["parity"]:
                             try:
-                                r["parity"][f"{16 * phw}x{16 * phw}"] = parity_check(lg["precise"], {k: True for k in lg["mc"]}, hw=phw, every=every,
-                                                                                     brain="all" if lg["allmod"] else "eeg")
+                                r["parity"][f"{16 * phw}x{16 * phw}"] = parity_check(lg["precise"], dict(lg["mc"]), hw=phw, every=every,
+                                                                                     brain=None if lg.get("realistic") else ("all" if lg["allmod"] else "eeg"),
+                                                                                     realistic=bool(lg.get("realistic")))
                             except Exception as e:
                                 r["parity"][f"{16 * phw}x{16 * phw}"] = {"error": f"{type(e).__name__}: {e}"}
                 except Exception as e:      # a secondary leg must never take the headline down with it
@@ -549,11 +565,14 @@ def main():
                  "attn_frac": (r.get("roofline_attention") or {}).get("frac"), "e2e_frac": r.get("mfma_frac_end_to_end")}
             par = r.get("parity")
             if isinstance(par, dict):
-                b["parity"] = ({k: {"mean": v.get("noise_pred_relerr_mean"), "final": v.get("final_latent_relerr")} for k, v in par.items() if isinstance(v, dict)}
+                b["parity"] = ({k: {"mean": v.get("noise_pred_relerr_mean"), "max": v.get("noise_pred_relerr_max"), "final": v.get("final_latent_relerr")} for k, v in par.items() if isinstance(v, dict)}
                                if "noise_pred_relerr_mean" not in par else {"mean": par.get("noise_pred_relerr_mean"), "final": par.get("final_latent_relerr")})
+            bl = (r.get("roofline_attention") or {}).get("bounded_score_layers")
+            if bl and bl["bounded"] != bl["layers"]:
+                b["bounded_score_layers"] = f"{bl['bounded']}/{bl['layers']}"
             return b
         summ = {"headline": brief(res), "cpu_tiny_s": (res.get("cpu_baseline") or {}).get("tiny_measured", {}).get("seconds")}
-        for lg, r in zip(("configs2_b16", "hw64_b4_bf16", "configs4_b4_attnfp8", "precise_b1"), res.get("secondary", [])):
+        for lg, r in zip(("fp16_operands_b1", "realistic_stats_b1", "configs2_b16", "hw64_b4_bf16", "configs4_b4_attnfp8", "precise_b1"), res.get("secondary", [])):
             summ[lg] = brief(r) if "error" not in r else {"error": r["error"]}
         res["summary"] = summ
         print(json.dumps(res))

@@ -39,189 +39,8 @@ namespace {
 // final O / l is unchanged.
 constexpr float DEFER_THR = 8.0f;
 
-template <int NW, bool DEFER>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lx_attn_kernel(const AttnArgs args) {
-  constexpr int QBLK = NW * 32;
-  constexpr int PIECES = 16 / NW;     // 1-KiB LDS-DMA pieces per wave per operand tile
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
-  const lx_attn_desc& D = args.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  // block -> (query tile, batch*head); all query tiles of one (b,h) share an XCD when B*H % 8 == 0
-  const int BH = D.B * D.H;
-  const int bh = blockIdx.x % BH;
-  const int qt = blockIdx.x / BH;
-  const int b = bh / D.H, h = bh % D.H;
-  int sq = 0;
-#pragma unroll
-  for (int s = 1; s < 3; ++s)
-    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
-  const int q_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 32 + l31;
-  const int q_len = D.seg_len[sq];
-  const bool q_valid = q_in_seg < q_len;
-  const size_t q_row = (size_t)D.seg_row0[sq] + (size_t)b * q_len + min(q_in_seg, q_len - 1);
-
-  // Q fragments: lane (q = l31, half = lhi) holds d = ks*16 + lhi*8 .. +8 for ks = 0..7
-  bf16x8 qf[8];
-  {
-    const __bf16* qp = (const __bf16*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-
-  const float c2 = (D.flags & LX_ATTN_Q_LOG2) ? 1.0f : D.scale * 1.4426950408889634f;  // scores are kept in log2 units
-
-  f32x16 oacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  // ---- staging --------------------------------------------------------------------------------------
-  const __bf16* Kbase = (const __bf16*)D.K + D.k_col + h * DH;
-  const __bf16* Vbase = (const __bf16*)D.VT + (size_t)bh * DH * D.vt_ld;
-  auto stage = [&](int sk, int kt, int buf) {
-    char* base = smem + buf * STAGE_BYTES;
-    const int klen = D.seg_len[sk];
-    const size_t krow0 = (size_t)D.seg_row0[sk] + (size_t)b * klen;
-    // K: one instruction = 4 key rows of 256 B; lane -> (row = lane>>4, slot = lane&15)
-#pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      const int key = (j * NW + wave) * 4 + (lane >> 4);
-      const int lslot = (lane & 15) ^ (key & 15);
-      const int kin = min(kt * KVBLK + key, klen - 1);
-      const __bf16* src = Kbase + (krow0 + kin) * D.ldk + lslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (j * NW + wave) * 1024), 16, 0, 0);
-    }
-    // V^T: one instruction = 8 d rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
-    const int vpos = D.seg_vt0[sk] + kt * KVBLK;
-#pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      const int drow = (j * NW + wave) * 8 + (lane >> 3);
-      const int lslot = (lane & 7) ^ ((drow >> 1) & 7);
-      const __bf16* src = Vbase + (size_t)drow * D.vt_ld + vpos + lslot * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + K_BYTES + (j * NW + wave) * 1024), 16, 0, 0);
-    }
-  };
-  // iteration over (key segment, key tile), skipping fully masked segment pairs
-  auto seg_ok = [&](int s) { return D.bias[sq][s] > -1e37f; };
-  auto advance = [&](int& sk, int& kt) {
-    ++kt;
-    while (sk < D.n_seg && (kt * KVBLK >= D.seg_len[sk] || !seg_ok(sk))) { ++sk; kt = 0; }
-  };
-  int sk = 0, kt = -1;
-  advance(sk, kt);
-
-  const int ksw = l31 & 15;            // K rows: slot ^= key & 15
-  const int vsw = (l31 >> 1) & 7;      // V^T rows: slot ^= (d >> 1) & 7
-  const int k_row_off = l31 * 256;
-  const int v_row_off = K_BYTES + l31 * 128;
-
-  if (sk < D.n_seg) stage(sk, kt, 0);
-  int buf = 0;
-  while (sk < D.n_seg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int nsk = sk, nkt = kt;
-    advance(nsk, nkt);
-    if (nsk < D.n_seg) stage(nsk, nkt, buf ^ 1);
-    const char* sb = smem + buf * STAGE_BYTES;
-
-    // ---- S^T = K . Q^T ---------------------------------------------------------------------------
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 kf = *(const bf16x8*)(sb + kb * 32 * 256 + k_row_off + (((ks * 2 + lhi) ^ ksw) * 16));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // ---- online softmax (log2 domain) ------------------------------------------------------------
-    const float bl = D.bias[sq][sk] * 1.4426950408889634f;
-    const int klen = D.seg_len[sk];
-    const int kbase = kt * KVBLK + 4 * lhi;
-    if (kt * KVBLK + KVBLK > klen) {   // ragged last tile of the segment: mask keys past its end
-      __builtin_amdgcn_sched_barrier(0);   // keep this a (wave-uniform) branch: if-converted it costs 64 VALU on every tile
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + kb * 32 + 8 * (r >> 2) + (r & 3);
-          if (key >= klen) sacc[kb][r] = -1e30f;
-        }
-    }
-    float tmax = fmaxf(sacc[0][0], sacc[0][1]);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float t_new = tmax * c2 + bl;
-    bool rescale = true;
-    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;    // wave-uniform
-    if (rescale) {
-      const float m_new = fmaxf(m_run, t_new);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-      m_run = m_new;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    }
-    const float off = bl - m_run;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, off));
-        sacc[kb][r] = p;
-        psum += p;
-      }
-    l_run += psum;
-    // ---- P fragments: step s uses accumulator registers [8*(s&1), +8) of sacc[s>>1] -------------
-    bf16x8 pf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4 w;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        w[i] = pack_bf16x2(sacc[s >> 1][8 * (s & 1) + 2 * i], sacc[s >> 1][8 * (s & 1) + 2 * i + 1]);
-      pf[s] = __builtin_bit_cast(bf16x8, w);
-    }
-    // ---- O^T += V^T . P^T ------------------------------------------------------------------------
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 vf = *(const bf16x8*)(sb + v_row_off + db * 32 * 128 + (((s * 2 + lhi) ^ vsw) * 16));
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    sk = nsk;
-    kt = nkt;
-    buf ^= 1;
-  }
-
-  // ---- epilogue: O[q, d] = O^T / l ; lane holds d = db*32 + 8*(r>>2) + 4*lhi + (r&3) --------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
-}
+// (The plain 8-wave kernel this file started with -- both waves of a SIMD alternating QK -> softmax -> PV, 695-710 TFLOP/s -- lived here until
+//  round 5 as an A/B arm (LX_ATTN_PIPE=0); the pipelined kernel below has been the only default since round 1: DESIGN 3.3.)
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -326,13 +145,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     char* base = smem + slot * STAGE_BYTES;
     if (j < 2) {
       const lx_rsrc_t rs = lx_make_rsrc(Kbase + (size_t)krow * ldk);                                     // wave-uniform
-#ifdef LX_ATTN_KOFF_MAD
-      const uint32_t off_ = (uint32_t)(min(k_key + j * 32, nclamp - 1) * ldk * 2) + k_slot_off;
-#else
       // min(row, clamp) * ld + slot = min(row * ld + slot, clamp * ld + slot): the products are loop-invariant registers / one scalar
       // multiply, so a piece costs v_add + v_min instead of v_min + v_mad_u64_u32 (hipcc's only 32 x 32 + 32 form, not full rate)
       const uint32_t off_ = min(j ? k_off1 : k_off0, (uint32_t)((nclamp - 1) * ldk * 2) + k_slot_off);
-#endif
       lx_buf_to_lds(rs, (lptr_t)(base + (j * NW + wave) * 1024), off_, 0);
     } else {
       const int jj = j - 2;
@@ -379,9 +194,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #ifndef LX_ATTN_LOOK
 #define LX_ATTN_LOOK 5
 #endif
-#ifndef LX_ATTN_LSUM_MFMA
-#define LX_ATTN_LSUM_MFMA 0
-#endif
 #ifndef LX_ATTN_PG0                 // gaps behind which the four LDS-DMA pieces of an iteration are issued (A/B knobs; tools/attn_ab.py)
 #define LX_ATTN_PG0 1
 #define LX_ATTN_PG1 3
@@ -397,22 +209,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #endif
   f32x16 sA[2], sB[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if LX_ATTN_LSUM_MFMA == 2
-  // Row sums on the matrix pipe, small form: v_mfma_f32_4x4x4_16b_bf16 is sixteen independent 4x4x4 products, block = lane / 4; with
-  // an all-ones A every lane's four result registers hold the sum of the four bf16 values IT supplied as B. Two of them behind each
-  // P.V slice add the lane's eight rounded probabilities of that slice into lacc4 (a 4-register tuple: the 16-register accumulator
-  // of the 32x32 form does not fit the allocator's tuple budget, 66 spills), and the 32 v_add per key tile of the half-units go.
-  typedef __attribute__((ext_vector_type(4))) short s16x4;
-  f32x4 lacc4 = {0.f, 0.f, 0.f, 0.f};
-  const s16x4 ones4 = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
-#elif LX_ATTN_LSUM_MFMA
-  // Row sums on the matrix pipe: behind the last P.V MFMA of a slice, one more MFMA multiplies the slice's P^T fragment by an
-  // all-ones A fragment -- every accumulator register of a lane then holds sum_k P[q, k] of the ROUNDED probabilities (the values
-  // P.V sees; the hardware sums over both half-waves' keys) -- and the 32 v_add per key tile of the half-units go (+4 MFMAs per tile).
-  f32x16 lacc = zero16;
-  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
-#endif
   float mx[4], t_new = 0.f;
   float off = 0.f, p_even[2] = {0.f, 0.f};   // (slices s and s+1 overlap in time: one pending even value per slice parity)
   uint32_t bq = 0, bv = 0;          // LDS byte offsets of the K buffer read by QK and the V buffer read by PV
@@ -442,28 +238,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }                                                                                                                    \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_RDP(j, last, QONLY) LX_RD(j, (j) < LOOK ? (last) : 0, QONLY)   /* the LOOK reads that prime the ring */
-#if LX_ATTN_LSUM_MFMA == 2
-#define LX_LSUM(f_)                                                                                                    \
-    if (((f_) & 1) == 1) {       /* behind the 2nd and the 4th P.V MFMA of a slice: one half of the slice's P fragment each */ \
-      const u32x2 h_ = {pfw[(f_) >> 2][((f_) & 2)], pfw[(f_) >> 2][((f_) & 2) + 1]};                                    \
-      lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, h_), lacc4, 0, 0, 0);              \
-      asm volatile("" : "+v"(lacc4));                                                                                 \
-    }
-#define LX_LADD(p_)
-#define LX_LPIN
-#elif LX_ATTN_LSUM_MFMA
-#define LX_LSUM(f_)                                                                                                    \
-    if (((f_) & 3) == 3) {                                                                                             \
-      lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, __builtin_bit_cast(bf16x8, pfw[(f_) >> 2]), lacc, 0, 0, 0); \
-      asm volatile("" : "+v"(lacc));                                                                                  \
-    }
-#define LX_LADD(p_)
-#define LX_LPIN
-#else
 #define LX_LSUM(f_)
 #define LX_LADD(p_) l_run += p_;
 #define LX_LPIN , "+v"(l_run)
-#endif
 #define LX_MM(g, SC, SN, QONLY)                                                                                        \
   if ((QONLY) || pipe_is_q(g)) {                                                                                       \
     constexpr int f_ = (QONLY) ? (g) : pipe_idx(g);                                                                    \
@@ -492,13 +269,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }
   // row max of tile t and the rescale decision, as vector fillers of gaps 0-3 (they used to run serially at the head of the
   // iteration: 8 us of a 90 us launch with nothing to overlap); four independent v_max3 chains, not one 16-deep chain
-#if LX_ATTN_LSUM_MFMA == 2
-#define LX_LSCALE(a_) lacc4[0] *= a_
-#elif LX_ATTN_LSUM_MFMA
-#define LX_LSCALE(a_) lacc[0] *= a_
-#else
 #define LX_LSCALE(a_) l_run *= a_
-#endif
 #define LX_MCHUNK(g, SC)                                                                                               \
   if ((g) == 0) {                                                                                                      \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                    \
@@ -534,32 +305,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   }
   // the wait of gap g hands the fragment register on ("+v"): the MFMA that consumes it then depends on the WAIT, not only on the
   // ds_read that was issued five gaps earlier -- otherwise nothing but luck keeps hipcc from hoisting the MFMA above its wait
-// LX_ATTN_PRIO_FLIP = G > 0 (A/B knob): the two waves of a SIMD trade priority inside every iteration -- waves 4-7 (the younger half,
-// which loses every arbitration by age and is the one the workgroup waits for: tools/attn_probe.py) run gaps [0, G) at priority 1 and
-// the rest at 0, waves 0-3 the other way round -- so that both reach the end-of-iteration barrier together.
-#ifndef LX_ATTN_PRIO_FLIP
-#define LX_ATTN_PRIO_FLIP 0
-#endif
-#if LX_ATTN_PRIO_FLIP > 0
-#define LX_PRIO_AT(g)                                                                                                  \
-  if ((g) == 0) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }                      \
-  if ((g) == LX_ATTN_PRIO_FLIP) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#elif LX_ATTN_PRIO_FLIP < 0
-#define LX_PRIO_AT(g)                                                                                                  \
-  if ((g) == 0) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }                      \
-  if ((g) == -(LX_ATTN_PRIO_FLIP)) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#else
-#define LX_PRIO_AT(g)
-#endif
+// (Wave-priority variants -- a static s_setprio for the younger half, priority traded inside every iteration -- were measured in round 3,
+// profiles/r03m_*: zero-sum between the two waves of a SIMD; removed in round 5.)
 #define LX_WAITR(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LX_MCHUNK_MAYBE(g, SC) if constexpr (MODE == 0) { LX_MCHUNK(g, SC) }
-#ifdef LX_ATTN_WAIT_AHEAD   /* A/B: gap g waits for the fragment of gap g + 1 as well, so that every MFMA consumes a fragment that landed a gap ago */
-#define LX_WAIT_GAP(g)                                                                                                 \
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ring[(g) % LOOK]), "+v"(ring[((g) + 1) % LOOK]) : "n"((30 - (g)) < (LOOK - 2) ? ((30 - (g)) < 0 ? 0 : (30 - (g))) : (LOOK - 2)) : "memory"); \
-  __builtin_amdgcn_sched_barrier(0);
-#else
 #define LX_WAIT_GAP(g) LX_WAITR((31 - (g)) < (LOOK - 1) ? (31 - (g)) : (LOOK - 1), ring[(g) % LOOK]);
-#endif
 #ifdef LX_ATTN_ELIM_SOFT
 #define LX_HALVES(g, SC)
 #else
@@ -582,7 +332,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   LX_RD((g) + LOOK, 32, false);                                                                                        \
   LX_MCHUNK_MAYBE(g, SC)                                                                                               \
   LX_HALVES(g, SC)                                                                                                     \
-  LX_PRIO_AT(g)                                                                                                        \
   LX_PIECES(g)                                                                                                         \
   __builtin_amdgcn_sched_barrier(0)
 #define LX_GAP4(g, SC, SN) LX_GAP(g, SC, SN); LX_GAP((g) + 1, SC, SN); LX_GAP((g) + 2, SC, SN); LX_GAP((g) + 3, SC, SN)
@@ -636,20 +385,12 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #define LX_PROBE_B()
 #define LX_PROBE_C()
 #endif
-  const bool young = wave >= 4;             // (an SGPR condition: the branches of LX_PRIO_AT are scalar)
-  if (args.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);      // wave is an SGPR value (readfirstlane): a real scalar branch
   int t = 0;
   if (t0.nvalid > 0) {
     piece(0, t0.krow, 0, t0.nclamp, 0); piece(1, t0.krow, 0, t0.nclamp, 0);
     piece(2, 0, t0.vpos, 0, 0); piece(3, 0, t0.vpos, 0, 0);
     piece(0, t1.krow, 0, t1.nclamp, 1); piece(1, t1.krow, 0, t1.nclamp, 1);
-#ifdef LX_ATTN_PROLOGUE_EARLY
-    // the scores of tile 0 need K(0) only: wait for this wave's two K(0) pieces (the four issued behind them -- V^T(0), K(1) --
-    // stay in flight under the 16 prologue MFMAs; guide T20 follow-on: a wait belongs in front of its first consumer)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     LX_BARRIER();
     // prologue: scores of tile 0
     LX_WAITL(0);
@@ -662,9 +403,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     // barrier a wave that runs ~14 gaps behind its workgroup (it shares its SIMD with an older wave) could fetch fragments of tile 2
     // for its tile-0 scores -- seen as run-to-run differences of single 32-row groups, ~1e-6 per workgroup, only under load
     // (tools/det_block.py). The iterations themselves end in a barrier; the prologue did not.
-#ifdef LX_ATTN_PROLOGUE_EARLY
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // V^T(0) and K(1) of every wave have landed before anyone reads them
-#endif
     LX_BARRIER();
 #ifdef LX_ATTN_PROBE
     pr_loop0 = __builtin_amdgcn_s_memtime();
@@ -682,7 +420,6 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
 #undef LX_PROBE_C
 #undef LX_GAP4
 #undef LX_GAP
-#undef LX_PRIO_AT
 #undef LX_MCHUNK
 #undef LX_MCHUNK_MAYBE
 #undef LX_WAIT_GAP
@@ -714,13 +451,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
     }
   }
 #endif
-#if LX_ATTN_LSUM_MFMA == 2
-  const float l_tot = lacc4[0] + __shfl_xor(lacc4[0], 32, 64);     // per lane: its own 32 probabilities per tile, as l_run was
-#elif LX_ATTN_LSUM_MFMA
-  const float l_tot = lacc[0];          // (every register of lacc holds the row's sum; the MFMA summed over both half-waves' keys)
-#else
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-#endif
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
 }
@@ -742,172 +473,8 @@ constexpr int K8_BYTES = KVBLK * DH;        // 8 KiB
 constexpr int V8_BYTES = DH * KVBLK;        // 8 KiB
 constexpr int STAGE8_BYTES = K8_BYTES + V8_BYTES;
 
-template <bool DEFER>
-__global__ __launch_bounds__(512, 1) void lx_attn_fp8_kernel(const AttnArgs args, float qk_descale, float v_descale) {
-  constexpr int QBLK = 256;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE8_BYTES];
-  const lx_attn_desc& D = args.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int BH = D.B * D.H;
-  const int bh = blockIdx.x % BH;
-  const int qt = blockIdx.x / BH;
-  const int b = bh / D.H, h = bh % D.H;
-  int sq = 0;
-#pragma unroll
-  for (int s = 1; s < 3; ++s)
-    if (s < D.n_seg && qt >= args.qt_start[s]) sq = s;
-  const int q_in_seg = (qt - args.qt_start[sq]) * QBLK + wave * 32 + l31;
-  const int q_len = D.seg_len[sq];
-  const bool q_valid = q_in_seg < q_len;
-  const size_t q_row = (size_t)D.seg_row0[sq] + (size_t)b * q_len + min(q_in_seg, q_len - 1);
-
-  // Q fragments: lane (q = l31, g = lhi) holds d = half*64 + g*32 .. +32 for half = 0, 1
-  i32x8 qf[2];
-  {
-    const uint8_t* qp = (const uint8_t*)D.Q + q_row * D.ldq + D.q_col + h * DH + lhi * 32;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const u32x4 lo = *(const u32x4*)(qp + hf * 64), hi = *(const u32x4*)(qp + hf * 64 + 16);
-      qf[hf] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-    }
-  }
-  const float c2 = D.scale * qk_descale * 1.4426950408889634f;
-
-  f32x16 oacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const uint8_t* Kbase = (const uint8_t*)D.K + D.k_col + h * DH;
-  const uint8_t* Vbase = (const uint8_t*)D.VT + (size_t)bh * DH * D.vt_ld;
-  auto stage = [&](int sk, int kt, int buf) {
-    char* base = smem + buf * STAGE8_BYTES;
-    const int klen = D.seg_len[sk];
-    const size_t krow0 = (size_t)D.seg_row0[sk] + (size_t)b * klen;
-    {  // K: this wave's piece = 8 key rows of 128 B; lane -> (row = lane>>3, slot = lane&7)
-      const int key = wave * 8 + (lane >> 3);
-      const int lslot = (lane & 7) ^ ((key >> 1) & 7);
-      const int kin = min(kt * KVBLK + key, klen - 1);
-      const uint8_t* src = Kbase + (krow0 + kin) * D.ldk + lslot * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + wave * 1024), 16, 0, 0);
-    }
-    {  // V^T: this wave's piece = 16 d rows of 64 B; lane -> (row = lane>>2, slot = lane&3)
-      const int drow = wave * 16 + (lane >> 2);
-      const int lslot = (lane & 3) ^ ((drow >> 2) & 3);
-      const uint8_t* src = Vbase + (size_t)drow * D.vt_ld + D.seg_vt0[sk] + kt * KVBLK + lslot * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + K8_BYTES + wave * 1024), 16, 0, 0);
-    }
-  };
-  auto seg_ok = [&](int s) { return D.bias[sq][s] > -1e37f; };
-  auto advance = [&](int& sk, int& kt) {
-    ++kt;
-    while (sk < D.n_seg && (kt * KVBLK >= D.seg_len[sk] || !seg_ok(sk))) { ++sk; kt = 0; }
-  };
-  int sk = 0, kt = -1;
-  advance(sk, kt);
-
-  const int ksw = (l31 >> 1) & 7;     // K rows (128 B): slot ^= (key >> 1) & 7
-  const int vsw = (l31 >> 2) & 3;     // V^T rows (64 B): slot ^= (d >> 2) & 3   (rows db*32 + l31: (row >> 2) & 3 == (l31 >> 2) & 3)
-  auto frag = [&](const char* p0, int slot_a, int sw) {   // 32 bytes = 16-B slots slot_a, slot_a + 1 (slot_a even) of one row
-    const u32x4 lo = *(const u32x4*)(p0 + ((slot_a ^ sw) * 16)), hi = *(const u32x4*)(p0 + (((slot_a + 1) ^ sw) * 16));
-    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-  };
-
-  if (sk < D.n_seg) stage(sk, kt, 0);
-  int buf = 0;
-  while (sk < D.n_seg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int nsk = sk, nkt = kt;
-    advance(nsk, nkt);
-    if (nsk < D.n_seg) stage(nsk, nkt, buf ^ 1);
-    const char* sb = smem + buf * STAGE8_BYTES;
-
-    // ---- S^T = K . Q^T : sacc[kb][r] <-> key = kb*32 + 8*(r>>2) + 4*lhi + (r&3), query = l31 -------------------
-    f32x16 sacc[2];
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const char* krow = sb + (kb * 32 + l31) * 128;
-      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(krow, 0 + lhi * 2, ksw), qf[0], z, 0, 0, 0, 0, 0, 0);
-      sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(krow, 4 + lhi * 2, ksw), qf[1], sacc[kb], 0, 0, 0, 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // ---- online softmax (log2 domain), as in the bf16 kernels ------------------------------------------------
-    const float bl = D.bias[sq][sk] * 1.4426950408889634f;
-    const int klen = D.seg_len[sk];
-    const int kbase = kt * KVBLK + 4 * lhi;
-    if (kt * KVBLK + KVBLK > klen) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + kb * 32 + 8 * (r >> 2) + (r & 3);
-          if (key >= klen) sacc[kb][r] = -1e30f;
-        }
-    }
-    float tmax = fmaxf(sacc[0][0], sacc[0][1]);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = (kb == 0 ? 2 : 0); r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sacc[kb][r]), sacc[kb][r + 1]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float t_new = tmax * c2 + bl;
-    bool rescale = true;
-    if (DEFER) rescale = __builtin_amdgcn_ballot_w64(t_new - m_run > DEFER_THR) != 0;
-    if (rescale) {
-      const float m_new = fmaxf(m_run, t_new);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-      m_run = m_new;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    }
-    const float off = bl - m_run;
-    float psum = 0.f;
-    i32x8 pf;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        float pv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          pv[c] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][rq * 4 + c], c2, off));
-          psum += pv[c];
-        }
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], w, true);
-        pf[kb * 4 + rq] = w;                          // byte p = kb*16 + r of this lane group's 32 k positions
-      }
-    l_run += psum;
-    // ---- O^T += V^T . P^T : one MFMA per 32-row d block, k = the tile's 64 keys ---------------------------------
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      const char* vrow = sb + K8_BYTES + (db * 32 + l31) * 64;
-      oacc[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(vrow, lhi * 2, vsw), pf, oacc[db], 0, 0, 0, 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    sk = nsk;
-    kt = nkt;
-    buf ^= 1;
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? v_descale / l_tot : 0.f;
-  lx_store_o(lx_o_mode(args), (int*)D.f16_ovf, q_valid, (uint16_t*)D.O + q_row * D.ldo + D.o_col + h * DH, oacc, inv, lhi);
-}
+// (lx_attn_fp8_kernel, the plain e4m3 kernel -- 1147 / 1197 TFLOP/s at S = 2560 / 8704 against 1390 / 1568 for the pipelined one below --
+//  was kept as LX_ATTN_FP8_PIPE=0 until round 5.)
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1322,11 +889,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 
 }  // namespace
 
-// 16-byte epilogue stores need 16-byte aligned output rows and head columns (LX_ATTN_WIDE_STORE=0: always the 8-byte form, A/B)
-static int lx_attn_wide_store(const lx_attn_desc* d) {
-  static const bool on = [] { const char* e = getenv("LX_ATTN_WIDE_STORE"); return e ? atoi(e) != 0 : true; }();
-  return on && d->ldo % 8 == 0 && d->o_col % 8 == 0 && ((uintptr_t)d->O & 15) == 0;
-}
+// 16-byte epilogue stores need 16-byte aligned output rows and head columns
+static int lx_attn_wide_store(const lx_attn_desc* d) { return d->ldo % 8 == 0 && d->o_col % 8 == 0 && ((uintptr_t)d->O & 15) == 0; }
 
 // which segments have queries: qseg_mask when given, else the first n_qseg (0: all)
 static int lx_attn_qmask(const lx_attn_desc* d) {
@@ -1344,21 +908,13 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   LX_CHECK_ARG(d->B >= 1 && d->H >= 1, "lx_attn_fwd: bad B/H");
   LX_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd: ldq/ldk %% 8, ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 8 == 0 && d->k_col % 8 == 0 && d->o_col % 4 == 0, "lx_attn_fwd: column offsets must be 16-byte aligned");
-  // variant: LX_ATTN_PIPE=0|1 (software-pipelined 8-wave kernel), LX_ATTN_NW=4|8 (plain kernel: waves per workgroup),
-  // LX_ATTN_DEFER=0|1 (deferred max rescale); defaults 1 / 8 / 1
-  static const int pipe_mode = [] { const char* e = getenv("LX_ATTN_PIPE"); return e ? atoi(e) : 1; }();      // 0 plain | 1 pipelined
-  const bool piped = pipe_mode != 0;
-  static const int nw = [] { const char* e = getenv("LX_ATTN_NW"); const int v = e ? atoi(e) : 8; return (v == 4 && pipe_mode == 0) ? 4 : 8; }();
-  static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
-  const int qblk = nw * 32;
+  const int qblk = 256;                        // query rows per workgroup (8 waves x 32 / 4 waves x 64)
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd: n_qseg=%d must be 0..n_seg", d->n_qseg);
   LX_CHECK_ARG(d->qseg_mask >= 0 && d->qseg_mask < (1 << d->n_seg), "lx_attn_fwd: qseg_mask=%d names a segment >= n_seg", d->qseg_mask);
   const int qmask = lx_attn_qmask(d);
   AttnArgs a;
   a.d = *d;
   a.wide_store = lx_attn_wide_store(d);
-  static const int prio = [] { const char* e = getenv("LX_ATTN_PRIO"); return e ? atoi(e) : 0; }();
-  a.prio_young = prio;
   int t = 0;
   for (int s = 0; s < 3; ++s) {
     a.qt_start[s] = t;
@@ -1384,11 +940,11 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   // lx_attn4_kernel (attn4.hip: one wave per SIMD, every K / V^T fragment feeds two MFMAs, persistent over the query tiles) serves the
   // bounded-score contract; its staging addresses a tile as buffer base + 32-bit byte offsets, so the K column block and the V^T image
   // have to lie within 2 GiB each. LX_ATTN4 = 0: never, 1: whenever it can, unset: where it measured faster than the 8-wave kernel on
-  // MI355X (profiles/r04_attn4_ab.txt): launches of at least two rounds of workgroups whose items are at most 64 key tiles long
+  // MI355X (profiles/r04a_attn4_ab.txt): launches of at least two rounds of workgroups whose items are at most 64 key tiles long
   // (B = 16, S = 2560: +1.4 %; 16 x 64 x 2048: +1.7 %) -- one round (B = 1: -2.7 % at S = 2560) and long items (S = 8704: -1.4 %) stay
   // on the 8-wave kernel.
   static const int attn4_mode = [] { const char* e = getenv("LX_ATTN4"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-  if (piped && (d->flags & LX_ATTN_BOUNDED) && nomax_ok && attn4_mode != 0) {
+  if ((d->flags & LX_ATTN_BOUNDED) && nomax_ok && attn4_mode != 0) {
     long long max_row = 0, key_tiles = 0;
     for (int s = 0; s < d->n_seg; ++s) {
       max_row = std::max(max_row, (long long)d->seg_row0[s] + (long long)d->B * d->seg_len[s]);
@@ -1404,18 +960,12 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
       return LX_OK;
     }
   }
-  if (piped && (d->flags & LX_ATTN_BOUNDED) && nomax_ok) {
+  // one kernel per contract: bounded scores without / with a bias (no running maximum), or the max-tracking form with the deferred rescale
+  if ((d->flags & LX_ATTN_BOUNDED) && nomax_ok) {
     if (any_bias) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 2>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 1>), dim3(grid), dim3(512), 0, st, a);
-  } else if (piped) {
-    if (defer) hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 0>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lx_attn_pipe_kernel<false, 0>), dim3(grid), dim3(512), 0, st, a);
-  } else if (nw == 8) {
-    if (defer) hipLaunchKernelGGL((lx_attn_kernel<8, true>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lx_attn_kernel<8, false>), dim3(grid), dim3(512), 0, st, a);
   } else {
-    if (defer) hipLaunchKernelGGL((lx_attn_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lx_attn_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lx_attn_pipe_kernel<true, 0>), dim3(grid), dim3(512), 0, st, a);
   }
   LX_LAUNCH_CHECK("lx_attn_fwd");
   lx_attn_last = LX_ATTN_KERNEL_8WAVE;
@@ -1430,14 +980,12 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
   LX_CHECK_ARG((d->flags & ~LX_ATTN_O_F16) == 0, "lx_attn_fwd_fp8: the only flag is LX_ATTN_O_F16 (the e4m3 kernels fold their own scales)");
-  static const bool defer = [] { const char* e = getenv("LX_ATTN_DEFER"); return e ? atoi(e) != 0 : true; }();
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
   LX_CHECK_ARG(d->qseg_mask >= 0 && d->qseg_mask < (1 << d->n_seg), "lx_attn_fwd_fp8: qseg_mask=%d names a segment >= n_seg", d->qseg_mask);
   const int qmask = lx_attn_qmask(d);
   AttnArgs a;
   a.d = *d;
   a.wide_store = lx_attn_wide_store(d);
-  a.prio_young = 0;
   int t = 0;
   for (int s = 0; s < 3; ++s) {
     a.qt_start[s] = t;
@@ -1453,20 +1001,15 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   }
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
-  static const bool piped = [] { const char* e = getenv("LX_ATTN_FP8_PIPE"); return e ? atoi(e) != 0 : true; }();
-  static const bool pow2_ok = [] { const char* e = getenv("LX_ATTN_FP8_POW2"); return e ? atoi(e) != 0 : true; }();
-  if (piped) {
-    // softmax scale x log2(e) x operand descale an exact power of two 2^-k (ops.py chooses the q scale so)? Then the score MFMAs
-    // apply it as an MX block scale and the scores come out as exp2 arguments (lx_attn_fp8_pipe_kernel, POW2)
-    const double c2 = (double)d->scale * (double)qk_descale * 1.4426950408889634;
-    const int k = (int)lround(-log2(c2));
-    const bool pow2 = pow2_ok && defer && k >= 1 && k <= 60 && fabs(c2 * ldexp(1.0, k) - 1.0) < 1e-5;
-    hipStream_t st = (hipStream_t)stream;
-    if (pow2) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k);
-    else if (defer) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
-    else hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<false, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
-  } else if (defer) hipLaunchKernelGGL((lx_attn_fp8_kernel<true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
-  else hipLaunchKernelGGL((lx_attn_fp8_kernel<false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a, qk_descale, v_descale);
+  // softmax scale x log2(e) x operand descale an exact power of two 2^-k (ops.py chooses the q scale so)? Then the score MFMAs
+  // apply it as an MX block scale and the scores come out as exp2 arguments (lx_attn_fp8_pipe_kernel, POW2); any other combination of
+  // scales runs the generic form (one fma per score)
+  const double c2 = (double)d->scale * (double)qk_descale * 1.4426950408889634;
+  const int k = (int)lround(-log2(c2));
+  const bool pow2 = k >= 1 && k <= 60 && fabs(c2 * ldexp(1.0, k) - 1.0) < 1e-5;
+  hipStream_t st = (hipStream_t)stream;
+  if (pow2) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k);
+  else hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
   LX_LAUNCH_CHECK("lx_attn_fwd_fp8");
   return LX_OK;
 }

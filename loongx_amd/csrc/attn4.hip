@@ -48,28 +48,14 @@ constexpr int a4_kind(int i) { return (i >= 6 && i < 14) || (i >= 22 && i < 30) 
 constexpr int a4_kb(int i) { return i < 14 ? 1 : 0; }                                       // score slots: key block
 constexpr int a4_ks(int i) { return (i < 14 ? i - 6 : i - 22) & 7; }                        // score slots: 16-wide d step
 constexpr int a4_pvf(int i) { return (i < 6 ? 10 + i : i < 22 ? i - 14 : i - 22) & 15; }    // P.V slots: 0-1 -> 10, 11; 2-5 -> 12..15; 14-21 -> 0..7; 30-31 -> 8, 9
-// Row sums. LX_A4_LSUM 1 (default): on the matrix pipe -- behind the last P.V MFMA of a slice one more MFMA per query block multiplies the
-// slice's P^T fragment by an all-ones A fragment: every accumulator register of a lane then holds sum_k P[q, k] of the ROUNDED
-// probabilities (the values P.V sees), summed over both half-waves' keys: 8 MFMAs per frame instead of 64 v_add_f32. The frame is bound by
-// instruction ISSUE (a v_add ~6 cycles, an exp2 ~11, a ds_read_b128 ~16, an LDS-DMA piece ~60 against 32 per MFMA), not by the matrix
-// pipe (64 of ~110 cycles per slot busy): the eight MFMAs are the cheaper way. 0: v_add_f32 per probability (A/B).
-#ifndef LX_A4_LSUM
-#define LX_A4_LSUM 0
-#endif
-constexpr int A4_SL = LX_A4_LSUM ? 24 : 40;      // vector instructions per 16-key slice (both query blocks)
-// vector instructions per slot. LX_A4_SCHED 0: the same number in every slot; 1 (default): none in the eight slots that carry an LDS-DMA piece
-#ifndef LX_A4_SCHED
-#define LX_A4_SCHED 1
-#endif
+// Row sums: one v_add_f32 per probability, taken from the UNROUNDED p (fp32), summed per lane and across the two half-waves at the end.
+// (Summing on the matrix pipe instead -- an all-ones MFMA per slice and query block -- was built and measured in round 4: 8 MFMAs = 256 pipe
+// cycles per frame to save 53 exposed ones, profiles/r04a_attn4_ab.txt; removed in round 5.)
+constexpr int A4_SL = 40;                        // vector instructions per 16-key slice (both query blocks): 16 exp2 + 16 add + 8 cvt_pk
+// vector instructions per slot: none in the eight slots that carry an LDS-DMA piece
 constexpr int a4_nslot(int i) {
-#if LX_A4_SCHED == 0
-  return A4_SL / 8;
-#elif LX_A4_LSUM
-  return (i >= 8 && i < 12) || (i >= 24 && i < 28) ? 0 : 4;
-#else
   constexpr int n[32] = {7, 7, 6, 7, 7, 6, 7, 6, 0, 0, 0, 0, 7, 7, 7, 6, 7, 7, 6, 7, 7, 6, 7, 6, 0, 0, 0, 0, 7, 7, 7, 6};
   return n[i];
-#endif
 }
 constexpr int a4_ngap(int g) { return (g & 1) ? a4_nslot(g >> 1) / 2 : (a4_nslot(g >> 1) + 1) / 2; }   // gap 2i: behind the slot's first MFMA
 constexpr int a4_pos(int g) { int p = 0; for (int k = 0; k < g; ++k) p += a4_ngap(k); return p; }      // stream position at the start of gap g (0..64)
@@ -79,32 +65,20 @@ static_assert(a4_pos(32) <= 2 * A4_SL, "slices 2, 3 read the kb-1 scores: not be
 static_assert(a4_pos(44) >= 2 * A4_SL, "slices 0, 1 read the kb-0 scores: done before slot 22 overwrites them");
 static_assert(a4_pos(12) <= 3 * A4_SL && a4_pos(4) <= 2 * A4_SL, "P words of slices 2 / 3 are rewritten only after the previous tile's P.V slots 0-1 / 2-5");
 // The softmax of one 16-key slice is a stream of vector instructions over 8 pair units u = pair * 2 + query block:
-//   LSUM 0:  exp2 e(0), o(0) | for u = 1..7: exp2 e(u), exp2 o(u), add e(u-1), add o(u-1), cvt_pk(u-1) | add e(7), add o(7), cvt_pk(7)    (40)
-//   LSUM 1:  exp2 e(0), o(0) | for u = 1..7: exp2 e(u), exp2 o(u), cvt_pk(u-1)                          | cvt_pk(7)                        (24)
+//   exp2 e(0), o(0) | for u = 1..7: exp2 e(u), exp2 o(u), add e(u-1), add o(u-1), cvt_pk(u-1) | add e(7), add o(7), cvt_pk(7)    (40)
 // kind: 0 exp2, 1 add, 2 cvt_pk
-#if LX_A4_LSUM
-constexpr int a4_op_kind(int n) { return n < 2 ? 0 : n == 23 ? 2 : ((n - 2) % 3 < 2 ? 0 : 2); }
-constexpr int a4_op_unit(int n) { return n < 2 ? 0 : n == 23 ? 7 : ((n - 2) % 3 < 2 ? (n - 2) / 3 + 1 : (n - 2) / 3); }
-constexpr int a4_op_half(int n) { return n < 2 ? n : n == 23 ? 0 : ((n - 2) % 3 < 2 ? (n - 2) % 3 : 0); }
-#else
 constexpr int a4_op_kind(int n) { return n < 2 ? 0 : n >= 37 ? (n == 39 ? 2 : 1) : ((n - 2) % 5 < 2 ? 0 : (n - 2) % 5 < 4 ? 1 : 2); }
 constexpr int a4_op_unit(int n) { return n < 2 ? 0 : n >= 37 ? 7 : ((n - 2) % 5 < 2 ? (n - 2) / 5 + 1 : (n - 2) / 5); }
 constexpr int a4_op_half(int n) { return n < 2 ? n : n >= 37 ? (n - 37) & 1 : ((n - 2) % 5 < 2 ? (n - 2) % 5 : ((n - 2) % 5 - 2) & 1); }
-#endif
-// Fragment ring: LX_A4_LOOK reads in flight (4 or 8: it has to divide 32); LX_A4_WAIT2: one s_waitcnt per TWO slots (even slots wait for their own
-// fragment and the next one)
+// Fragment ring: LX_A4_LOOK reads in flight (4 or 8: it has to divide 32)
 #ifndef LX_A4_LOOK
 #define LX_A4_LOOK 4
-#endif
-#ifndef LX_A4_WAIT2
-#define LX_A4_WAIT2 0
 #endif
 constexpr int A4_LOOK = LX_A4_LOOK;
 static_assert(A4_LOOK == 4 || A4_LOOK == 8, "ring depth");
 // lgkmcnt for position i of a fragment sequence of n_seq reads (-1: no wait here): min(LOOK, n_seq - i) reads are outstanding in front of it
 constexpr int a4_wait(int i, int n_seq) {
   const int out = n_seq - i < A4_LOOK ? n_seq - i : A4_LOOK;
-  if (LX_A4_WAIT2) return (i & 1) ? -1 : (out - 2 < 0 ? 0 : out - 2);
   return out - 1;
 }
 // LDS-DMA pieces: K(T+2) pieces 0-3 behind slots 8-11 (right behind the barrier), V^T(T+1) pieces 0-3 behind slots 24-27
@@ -146,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
   // launch is PERSISTENT when there are more items than CUs. Between items only O / l / Q change hands: the K / V^T tile stream, its rings
   // and the frame pipeline run on across the boundary (the generator below hands out the next item's tiles behind the last tile of this
   // one), so the next item's first tiles are staged under this item's last frames and its Q is fetched under the last frame. Measured
-  // before this (profiles/r04_attn4_cycles.txt): prologue + epilogue + dispatch = 18-20 k of a workgroup's 105-125 k cycles at 32-40 tiles. ----
+  // before this (profiles/r04a_attn4_cycles.txt): prologue + epilogue + dispatch = 18-20 k of a workgroup's 105-125 k cycles at 32-40 tiles. ----
   struct Item { int w, b, h, bh, sq, q_len, q_row0, q_tile0; };   // q_row0: first row of the item's query segment and batch; q_tile0: the tile's first row in it
   auto decode = [&](int w) {
     Item it;
@@ -257,12 +231,6 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
 
   f32x16 oacc[2][4];
   float lsum[2][2];            // LSUM 0: per lane, its own 32 probabilities per tile [query block][even / odd value]
-#if LX_A4_LSUM
-  f32x16 lacc[2];              // LSUM 1: every register = the row's sum (AGPRs)
-  const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  bf16x8 ones_frag = __builtin_bit_cast(bf16x8, ones_w);
-  asm volatile("" : "+v"(ones_frag));
-#endif
 
   // ---- fragment addresses: K 16-B slot ((2ks + lhi) ^ (key & 15)), V^T slot ((2s + lhi) ^ ((d >> 1) & 7)); key block / d block are immediates,
   // the ring position is part of the register: both start at ring position 0 ----
@@ -287,11 +255,7 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
 #define A4_SB() __builtin_amdgcn_sched_barrier(0)
   // LX_A4_ELIM_*: timing experiments only (WRONG numbers): what one class of instructions costs the stream -- DSR the fragment reads, DMA the
   // LDS-DMA pieces, VALU the softmax stream, BAR the frame barrier, ADDR the twelve ring-position adds (tools/run_a4_elim.sh)
-#ifdef LX_A4_RING_AGPR       /* the fragment ring in AGPRs (MFMA A operands may be AGPRs; ds_read can target them) */
-#define A4_RC "a"
-#else
 #define A4_RC "v"
-#endif
 #ifdef LX_A4_ELIM_DSR
 #define A4_DSR(dst, addr, offs) asm volatile("" : "+" A4_RC(dst) : "v"(addr)); A4_SB()
 #elif defined(LX_A4_ELIM_DSR_HALF)
@@ -409,9 +373,6 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
   if constexpr (!(DRAIN)) { A4_VALU(2 * (i)) }                                                                         \
   A4_MM(i, 1, -1)                                                                                                      \
   if constexpr (!(DRAIN) || (i) + A4_LOOK < 6) { A4_RD((i) + A4_LOOK) }                                                \
-  if constexpr (LX_A4_LSUM && a4_kind(i) == 1 && (a4_pvf(i) & 3) == 3) {      /* the slice's row sums */                \
-    A4_LSUM_MM(a4_pvf(i) >> 2, 0) A4_LSUM_MM(a4_pvf(i) >> 2, 1)                                                        \
-  }                                                                                                                    \
   if constexpr (!(DRAIN)) {                                                                                            \
     A4_VALU(2 * (i) + 1)                                                                                               \
     if constexpr ((i) >= 2 && (i) < 6) { A4_ADDR_STEP(vaddr[((i) - 2) & 3], dv); A4_SB(); }     /* V^T reads move on to ring position T (the reads of slots <= 5 are issued by slot 1) */ \
@@ -425,11 +386,6 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
     if constexpr ((i) == 27) { T0 = T1; T1 = T2; A4_SB(); }     /* (nothing reads T1 / T2 behind the V^T pieces: the scalar bookkeeping sits under queued MFMAs) */ \
     if constexpr ((i) == 28) { gen_next(); T2 = g_cur; A4_SB(); }                                                      \
   }
-#if LX_A4_LSUM
-#define A4_LSUM_MM(sl, qb) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones_frag), "v"(pw[qb][sl])); A4_SB();
-#else
-#define A4_LSUM_MM(sl, qb)
-#endif
 #define A4_SLOT4(i, DRAIN) A4_SLOT(i, DRAIN) A4_SLOT((i) + 1, DRAIN) A4_SLOT((i) + 2, DRAIN) A4_SLOT((i) + 3, DRAIN)
 
   // ---- prologue: K(0) -> ring position 0, V^T(0) -> 0, K(1) -> 1 ----
@@ -459,10 +415,6 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
       lsum[qb][0] = lsum[qb][1] = 0.f;
-#if LX_A4_LSUM
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
-#endif
       // "tile -1" of the item: P = 0 against whatever finite tile the V^T reads still point at (0 x finite = 0)
       pw[qb][2] = u32x4{0, 0, 0, 0}; pw[qb][3] = u32x4{0, 0, 0, 0};
 #ifdef LX_A4_ELIM_VALU
@@ -534,12 +486,8 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
     // ---- epilogue: O[q, d] = O^T / l ----
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-#if LX_A4_LSUM
-      const float l_tot = lacc[qb][0];      // (the MFMA summed over both half-waves' keys)
-#else
       const float l_lane = lsum[qb][0] + lsum[qb][1];
       const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
-#endif
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       const int q_in_seg = C.q_tile0 + wave * 64 + l31 + 32 * qb;
       const size_t q_row = (size_t)C.q_row0 + min(q_in_seg, C.q_len - 1);
@@ -553,7 +501,6 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every LDS-DMA piece of this wave (tiles that do not exist are staged too) has landed before the wave ends
 #undef A4_SLOT4
-#undef A4_LSUM_MM
 #undef A4_FRAME_BARRIER
 #undef A4_KPIECE
 #undef A4_VPIECE
@@ -591,10 +538,8 @@ int lx_attn4_cus(void) {
 
 int lx_attn4_launch(const void* attn_args, int n_items, int mode, void* stream) {
   const AttnArgs& a = *(const AttnArgs*)attn_args;
-  // one workgroup per CU (96 KiB of LDS, ~400 registers per lane): more items than CUs -> a persistent launch (LX_ATTN4_PERSIST=0: one
-  // workgroup per item, A/B)
-  static const bool persist = [] { const char* e = getenv("LX_ATTN4_PERSIST"); return !(e && atoi(e) == 0); }();
-  const int grid = (persist && n_items > lx_attn4_cus()) ? lx_attn4_cus() : n_items;
+  // one workgroup per CU (96 KiB of LDS, ~400 registers per lane): more items than CUs -> a persistent launch
+  const int grid = n_items > lx_attn4_cus() ? lx_attn4_cus() : n_items;
   if (mode == 2) hipLaunchKernelGGL((lx_attn4_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, n_items);
   else hipLaunchKernelGGL((lx_attn4_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, n_items);
   return 0;

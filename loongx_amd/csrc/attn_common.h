@@ -27,7 +27,6 @@ struct AttnArgs {
   lx_attn_desc d;
   int qt_start[4];   // prefix of (32*NW)-row query tiles per segment
   int wide_store;    // O rows and columns are 16-byte aligned: the epilogue stores 16 B per lane (lx_store_o)
-  int prio_young;    // LX_ATTN_PRIO=1: one static s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration; guide T5 static form)
 };
 
 // Epilogue store of one query row per lane pair: O[q, d] = O^T / l; lane (q = lane & 31, half = lane >> 5) holds

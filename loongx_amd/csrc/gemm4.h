@@ -289,16 +289,22 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (tid == 0) {
       const int me = pid - sk_full, other = me ^ 1;
-      if (!(sk_parts == 3 && part == 1))               // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
-        __hip_atomic_store(sk_flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      bool ok = true;
-      while (__hip_atomic_load(sk_flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) { ok = false; break; }
+      // The error word is STICKY until the host resets the workspace (lx_gemm_workspace_status): after a time-out a partner's flag may be
+      // raised late and stay up, and a later launch on the same slot (the engine polls the word asynchronously, graph replays keep coming)
+      // would pass its wait on that stale flag and add sums the partner has not written. So a workspace with the word up is refused:
+      // no flag is trusted, the tile finishes invalid like the launch that timed out, and the word stays up for the host.
+      bool ok = __hip_atomic_load(sk_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+      if (ok) {
+        if (!(sk_parts == 3 && part == 1))             // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
+          __hip_atomic_store(sk_flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(sk_flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 20)) { ok = false; break; }
+        }
+        if (ok) __hip_atomic_store(sk_flags + other, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (each flag: raised by its owner, reset by its reader)
+        else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // lx_gemm_workspace_status reports it
       }
-      if (ok) __hip_atomic_store(sk_flags + other, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (each flag: raised by its owner, reset by its reader)
-      else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lx_gemm_workspace_status reports it
     }
     __syncthreads();
     G4_STAMP(6)

@@ -101,6 +101,9 @@ def broadcast_packed_weights(pw, src: int = 0) -> int:
         if lo.down_lo is not None:
             flat[f"{k}::lora_down_lo"] = lo.down_lo
     n = broadcast_tensors(flat, src)
+    # everything an engine derived from the overwritten tensors is stale: the version moves UNCONDITIONALLY (the q_log2 table below exists
+    # only when bounded-score attention has been set up; the fp16 weight images of DiTEngine._setup_f16 and the step graphs key on this)
+    pw.weights_version = getattr(pw, "weights_version", 0) + 1
     refresh_q_log2(pw)
     return n
 

@@ -46,6 +46,9 @@ class DiTEngine:
         self._warmed = set()             # kernel sets (modes) that have run eagerly once: first launches must not happen inside a capture
         import os
         self.use_graph = os.environ.get("LX_GRAPH", "1") != "0"
+        # The projection launches normalise / rotate k and q and write V^T in their epilogue (LX_EPI_QKV) wherever the shapes allow it
+        # (_rope_pairs decides); False forces the separate lx_qkv_prep pass everywhere (tests compare the two).
+        self.qkv_epilogue = True
         self.model_config: Dict = {}
         self.c_factor: Optional[float] = None
         # Split-K pair plan of the GEMM (lx_gemm_bf16_ws): needs a caller-owned workspace, one per stream -- this engine owns one
@@ -72,16 +75,6 @@ class DiTEngine:
         self.w16: Dict[str, torch.Tensor] = {}         # name -> fp16 image of the (tiled) weight / name + ".down" -> fp16 LoRA down-projection
         self.f16_ovf: Optional[torch.Tensor] = None
         self._gemm_ws: Optional[torch.Tensor] = None
-        # Adapter rows on merged weights (LX_LORA_MERGE=1; off by default): W' = bf16(W + lora_scale * B_up A_down) per LoRA-carrying
-        # block weight (+11.5 GB at FLUX.1-dev scale), built once per (weights, scale). The adapter streams' problems of a grouped
-        # launch then read W' instead of W: the 88 lx_lora_down launches of a step -- each one's input is the output of the kernel in
-        # front of it, 0.69-0.75 ms of a 35.6 ms step on its critical path, profiles/r04l_lora_down_share.txt -- and the LoRA k-step of
-        # the GEMM tile prologue go. Measured (profiles/r04n_lora_merge_ab.txt, alternating on one box): 1.0368 / 1.0363 images/s
-        # against 1.0350 / 1.0372 -- the image and condition rows no longer share a weight panel through L2 / MALL and the GEMMs give
-        # the 2 % back (0.445 vs 0.457 of peak). Kept as a tested option. bf16 modes only, not with add_cond_attn.
-        self.lora_merge = os.environ.get("LX_LORA_MERGE", "0") == "1"
-        self.wl: Dict[str, torch.Tensor] = {}
-        self._wl_key = None
         # Step-invariant condition stream (model_config independent_condition / union_cond_attn = False: the condition queries see
         # only condition keys, its timestep c_t is fixed, so its hidden states, keys and values are the same at every denoise step):
         # the first forward after set_conditioning() computes all three streams and leaves the condition keys / V^T of every layer in
@@ -91,14 +84,11 @@ class DiTEngine:
         self.cond_cached = False         # the per-layer images hold this conditioning's condition keys / values
         self.cond_skip = False           # the forward being enqueued runs without the condition rows
         self.KC = self.VTC = None        # [layers, M, D] keys / [layers, B, H, 128, vt_ld] V^T, allocated on first use
-        # LoRA down-projection of the AdaLN-normalised stream inside ln_modulate (opt-in, LX_LN_LORA=1). Measured: -1.1 % (1011 vs
-        # 1000 ms per image): 57 lx_lora_down launches of 7 us go, but the 576-768 extra FMAs + 12-16 wave reductions per adapter row
-        # lengthen ln_modulate's condition-row workgroups by more than that. Kept for A/B; the default is the separate launch.
-        self.ln_lora = os.environ.get("LX_LN_LORA", "0") == "1"
-        # two-stream single blocks (opt-in, LX_OVERLAP=1): measured +0.3 % -- the step runs at the 1400 W package power cap, so filling
-        # the partly idle last rounds of a kernel with another kernel's workgroups buys clock back elsewhere, not time
-        self.overlap = os.environ.get("LX_OVERLAP", "0") == "1"
-        self.side_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
+        # (Round 5 removed three measured-negative options that lived here as environment switches: the q/k/v adapters' down-projection
+        # inside ln_modulate (LX_LN_LORA: -1.1 %; it could absorb the 57 launches per step that read the AdaLN-normalised stream, not the 75
+        # that read an attention output or a GELU hidden), adapter rows on merged weights W' = W + s B A (LX_LORA_MERGE: +11.5 GB, the GEMMs
+        # give the saved launches back as lost weight sharing) and the MLP-up half of the single blocks on a second stream (LX_OVERLAP: the
+        # step runs at the package power cap, +0.3 % / -1 %). DESIGN.md sections 3.2, 9 and 10 keep the measurements.)
 
     # ------------------------------------------------------------------------------------------ workspace
     def setup(self, B: int, T: int, N: int, C: int) -> None:
@@ -118,9 +108,7 @@ class DiTEngine:
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
-        self.TL_SPLIT = int(os.environ.get("LX_TL_SPLIT", "4"))         # K-split slabs of the LoRA down-projection (1/2/8 measured: no better)
-        if self.TL_SPLIT < 1:
-            raise ValueError(f"LX_TL_SPLIT={self.TL_SPLIT}: need at least one slab")
+        self.TL_SPLIT = 4                 # K-split slabs of the LoRA down-projection (1 / 2 / 8 measured: no better)
         # precise mode writes one slab per cross term (up to 3: hi.A, lo.A, hi.A_lo) whatever the K-split of the bf16 path is
         self.TLs = torch.zeros(max(self.TL_SPLIT, 3), M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]
@@ -193,7 +181,7 @@ class DiTEngine:
         honours: tests/test_f16_gpu.py); the share of weights that lose bits is kept in `w16_inexact_share`."""
         if self.f16_ovf is None:
             self.f16_ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
-        key = (id(self.w), getattr(self.w, "weights_version", 0), len(self.w.lora))
+        key = (id(self.w), getattr(self.w, "weights_version", 0), getattr(self.w, "lora_version", 0), len(self.w.lora))
         if self.w16 and self._w16_key == key:
             return
         self.w16 = {}
@@ -231,55 +219,43 @@ class DiTEngine:
             self.graphs = {}
             self.cond_ready = False
             self.sched = None
-            if self.wl:                  # merged adapter weights follow the scale (rebuilt in place)
-                self._setup_lora_merge()
 
-    def gemm_ws(self, side: bool = False) -> Optional[torch.Tensor]:
-        """The caller-owned GEMM workspace of lx_gemm_bf16_ws (the default launch plans: split-K pairs, lx_gemm4_kernel). One per stream:
-        side=True is the second stream's (the MLP-up half of the single blocks' projection, LX_OVERLAP) -- its launches have too many
-        tiles for any plan that exchanges through the workspace, but passing one is what selects the default plans."""
+    def gemm_ws(self) -> Optional[torch.Tensor]:
+        """The caller-owned GEMM workspace of lx_gemm_bf16_ws (what selects the default launch plans: lx_gemm4_kernel and its split form).
+        One per stream that may have such a launch in flight: this engine runs on one stream at a time."""
         if not self.pair_plan:
             return None
         if self._gemm_ws is None:
             if torch.cuda.is_current_stream_capturing():
                 return None                      # never allocate inside a capture; the eager warm-up pass allocates it
             self._gemm_ws = ops.gemm_workspace(self.device)
-            self._gemm_ws_side = ops.gemm_workspace(self.device)
-        return self._gemm_ws_side if side else self._gemm_ws
+        return self._gemm_ws
 
     def check_status(self, sync: bool = True) -> None:
-        """Raises LxError if a split-K pair workgroup timed out (the results of that step are invalid); the pair plan is then
+        """Raises LxError if a split-tile workgroup timed out (the results of that step are invalid); the workspace plans are then
         switched off for this engine, so a retry takes the plain plans. sync=True drains the stream and checks now. sync=False
         costs no synchronisation: it looks at the error word copied to pinned host memory by the previous call (if that copy has
         landed) and enqueues the next copy -- generate() does this once per image, so a time-out surfaces at most one image late."""
-        if self._gemm_ws is None or (not sync and os.environ.get("LX_ASYNC_STATUS", "1") == "0"):
+        if self._gemm_ws is None:
             return
         if sync:
-            first = None
-            for ws in (self._gemm_ws, getattr(self, "_gemm_ws_side", None)):     # BOTH workspaces are checked (and their flags / error words reset)
-                if ws is None:
-                    continue
-                try:
-                    ops.gemm_workspace_status(ws)
-                except Exception as e:                                           # before the first failure is re-raised
-                    first = first or e
-            if first is not None:
+            try:
+                ops.gemm_workspace_status(self._gemm_ws)      # (resets the flags and the error word when it reports)
+            except Exception:
                 self.pair_plan, self.graphs, self._err_event = False, {}, None
-                raise first
+                raise
             return
         n = self._gemm_ws.numel()
         if getattr(self, "_err_host", None) is None:
-            self._err_host = torch.zeros(2, dtype=torch.int32).pin_memory()     # the main and the second stream's error words
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._err_event = None
         if self._err_event is not None and self._err_event.query():
             self._err_event = None
-            if int(self._err_host[0]) != 0 or int(self._err_host[1]) != 0:
-                self.check_status(sync=True)          # resets the workspaces and raises
+            if int(self._err_host[0]) != 0:
+                self.check_status(sync=True)          # resets the workspace and raises
         if self._err_event is None:
-            for i, ws in enumerate((self._gemm_ws, getattr(self, "_gemm_ws_side", None))):
-                if ws is not None:
-                    word = ws[n - 64 * 4: n - 63 * 4].view(torch.int32)         # [slots | 256 flags | error word + pad]
-                    self._err_host[i:i + 1].copy_(word, non_blocking=True)
+            word = self._gemm_ws[n - 64 * 4: n - 63 * 4].view(torch.int32)         # [slots | 256 flags | error word + pad]
+            self._err_host.copy_(word, non_blocking=True)
             self._err_event = torch.cuda.Event()
             self._err_event.record()
 
@@ -474,8 +450,6 @@ class DiTEngine:
         self._pick_operands()
         if self.model_config.get("attn_fp8", False) and not self.precise:
             self._fp8_images()                                                                    # never first allocated inside a capture
-        if C or self.latent_lora:
-            self._setup_lora_merge()
         if self.model_config.get("add_cond_attn", False) and C and C != N:
             raise ValueError("add_cond_attn adds the condition attention output onto the image stream: needs C == N")
         f32, bf16 = torch.float32, torch.bfloat16
@@ -557,70 +531,18 @@ class DiTEngine:
         return dict(f16=True, f16_ovf=self.f16_ovf) if self.f16 else {}
 
     # ------------------------------------------------------------------------------------------ building blocks
-    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int, lora_name: Optional[str] = None, include_txt: bool = False):
-        """AdaLN LayerNorm + modulation of every stream of this forward into XN. `lora_name`: the adapter whose modules read XN next
-        (q/k/v, + proj_mlp in single blocks): its down-projection of the adapter rows is computed in the same launch (one slab in
-        TL) and returned as (Lora, first row, n_slabs = 1) for _gemm_streams(lora=...); None when there is nothing to project."""
+    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
+        """AdaLN LayerNorm + modulation of every stream of this forward into XN (the 16-bit operand image of this mode)."""
         row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
         segs = []
         for s, L in self._streams():
             mods = self.cmods if s == "cond" else self.mods
             b0 = base_by_stream[s]
             segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
-        lora = None
-        if lora_name is not None and self.ln_lora and not self.f16 and self.cfg.inner_dim in (3072, 256) and not self._merge_active(lora_name):
-            lo = self.w.lora.get(lora_name)
-            rows = self._lora_rows(include_txt)
-            if lo is not None and rows is not None and not (self.C == 0 and not self.latent_lora) and self.lora_scale != 0.0:
-                r0, n = rows
-                lora = (lo.down, self.TL[r0:r0 + n], r0, n)
         if self.f16:
             ops.ln_modulate_segs(self.X, segs, self.XN16, self.mods.stride(0), f16_ovf=self.f16_ovf)
-            return None
-        ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0), lora=lora)
-        if lora is None:
-            return None
-        if self.lora_scale != 1.0:
-            self.TL[lora[2]:lora[2] + lora[3], : lo.down.shape[0]].mul_(self.lora_scale)
-        return lo, lora[2], 1
-
-    def _merge_active(self, name: str) -> bool:
-        """This launch group's adapter rows read the merged weight (no lx_lora_down, no LoRA operands)."""
-        return (self.lora_merge and not self.precise and not self.gemm_fp8 and not self.f16 and self.lora_scale != 0.0 and name in self.wl
-                and (self.C > 0 or self.latent_lora) and not self.model_config.get("add_cond_attn", False))
-
-    def _setup_lora_merge(self) -> None:
-        """W' = bf16(W + lora_scale * up_m . down_m) for every LoRA-carrying block weight, module by module for the fused ones (column
-        block n // D picks down-projection rows min(n // D, n_mod - 1): lora_mod_cols / lora_toff_max of the unmerged launch), in the
-        same tiled image as W. Rebuilt IN PLACE when the scale or the weights change (captured graphs hold the addresses)."""
-        if not self.lora_merge or self.precise or self.gemm_fp8 or self.lora_scale == 0.0 or not self.w.lora:
-            return
-        key = (id(self.w), getattr(self.w, "lora_version", 0), getattr(self.w, "q_log2_version", 0), self.lora_scale, len(self.w.lora))
-        if key == self._wl_key:
-            return
-        D = self.cfg.inner_dim
-        for name, lo in self.w.lora.items():
-            if not (name[0] in "ds" and name[1].isdigit()):       # block weights only (x_embedder: one launch per step, left as it is)
-                continue
-            W = self.w.t[name + ".w"]
-            tiled = getattr(W, "lx_tiled", False)
-            W32 = (ops.untile_weight(W) if tiled else W).float()
-            N = W32.shape[0]
-            r = lo.up.shape[1]
-            n_mod = lo.down.shape[0] // r
-            down = lo.down.float()
-            for m in range(n_mod):
-                n0 = m * D if n_mod > 1 else 0
-                n1 = N if m == n_mod - 1 else (m + 1) * D
-                W32[n0:n1].addmm_(lo.up[n0:n1].float(), down[m * r:(m + 1) * r], alpha=self.lora_scale)
-            merged = W32.to(torch.bfloat16)
-            merged = ops.tile_weight(merged) if tiled else merged.contiguous()
-            dst = self.wl.get(name)
-            if dst is not None and dst.shape == merged.shape:
-                dst.copy_(merged)
-            else:
-                self.wl[name] = merged
-        self._wl_key = key
+        else:
+            ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0))
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
@@ -638,8 +560,6 @@ class DiTEngine:
         lo = self.w.lora.get(name)
         if lo is None or (self.C == 0 and not self.latent_lora) or self.lora_scale == 0.0 or self._lora_rows(include_txt) is None:
             return None, None
-        if self._merge_active(name):          # the adapter rows read W' = W + B A: nothing to project down
-            return None, None
         r0, n = self._lora_rows(include_txt)
         t = self.TL[r0:r0 + n, : lo.down.shape[0]]
         ops.lora_down(self._op(A[r0:r0 + n]), self._down(name, lo), t, n_split=self.TL_SPLIT, split_stride=self.TLs.stride(0))
@@ -650,25 +570,15 @@ class DiTEngine:
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
                       gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
                       gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None,
-                      qkv=None, cols: Optional[tuple] = None, lora=None, lora_t_col0: int = 0, ws: bool = True) -> None:
+                      qkv=None) -> None:
         """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
         (None => text rows use `main` too: single blocks). `only` restricts the launch to those streams and `ncols[s]` to the
         first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
         w = self.w
         lora_needed = only is None or "cond" in only or self.latent_lora
         nsplit = self.TL_SPLIT
-        merged = self.wl[main] if (lora_needed and self._merge_active(main) and self._lora_rows(txt is None) is not None) else None
-        lr0m = self._lora_rows(txt is None)[0] if merged is not None else 0
-        if merged is not None:             # adapter rows on W' = W + B A: no down-projection, no LoRA operands
-            lo, lr0 = None, None
-        elif lora is not None:               # (Lora, first row[, slabs]) already projected down by the caller (_ln, or one lx_lora_down for several launches)
-            lo, lr0 = lora[:2] if lora_needed else (None, None)
-            if len(lora) > 2:
-                nsplit = lora[2]
-        else:
-            lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
+        lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
         probs = []
-        c0, c1 = cols if cols is not None else (0, None)     # output-column range of this launch (multiples of 256)
         for s, L in self._streams():
             if only is not None and s not in only:
                 continue
@@ -677,15 +587,6 @@ class DiTEngine:
             W, bias = self._W(name), w.t[name + ".b"]
             if self.f16 and (epilogue & 0xff) == LX_EPI_STORE_BF16 and qkv is None:
                 c = c.view(torch.float16)               # a 16-bit store of this mode is the next GEMM's fp16 operand
-            if merged is not None and name == main and (s == "cond" or (s == "img" and self.latent_lora) or
-                                                        (s == "txt" and self.latent_lora and txt is None)):
-                if {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s] >= lr0m:
-                    W = merged
-            if cols is not None:
-                tiled = getattr(W, "lx_tiled", False)
-                W, bias, c = W[c0:c1], bias[c0:c1], c[:, c0:c1]
-                if tiled:
-                    W.lx_tiled = True          # row blocks of 256 are contiguous in the tiled image
             n_out = ncols.get(s) if ncols else None
             if n_out is not None and n_out < W.shape[0]:
                 tiled = getattr(W, "lx_tiled", False)
@@ -709,17 +610,17 @@ class DiTEngine:
                                                     (s == "txt" and self.latent_lora and txt is None)):
                 row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}[s]
                 if row0 >= lr0:
-                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0], lora_t_col0:], lora_up=lo.up[c0:c0 + W.shape[0]], lora_mod_cols=lora_mod_cols,
+                    kw.update(lora_t=self.TL[row0:row0 + a.shape[0]], lora_up=lo.up[: W.shape[0]], lora_mod_cols=lora_mod_cols,
                               lora_toff_max=lora_toff_max, lora_nsplit=nsplit, lora_split_stride=self.TLs.stride(0))
             probs.append(ops.gemm_desc(a, W, c, **kw))
-        ops.gemm(probs, self.gemm_ws(side=not ws))
+        ops.gemm(probs, self.gemm_ws())
 
     def _rope_pairs(self, check: bool) -> None:
         """(cos, sin) per rotary pair, [L, 128], for LX_EPI_QKV, and the decision whether the projections of this configuration
         use it (self.qkv_fused): bf16 kernel set, every stream a multiple of 32 tokens, heads in pairs, tables whose two
         entries of a pair agree (FluxPosEmbed's repeat_interleave; `check`: tables handed in by a caller are verified)."""
         D, rd = self.cfg.inner_dim, sum(self.cfg.axes_dims_rope)
-        ok = (os.environ.get("LX_QKV_FUSED", "1") != "0" and D % 256 == 0 and rd == 128 and self.cos_main is not None
+        ok = (self.qkv_epilogue and D % 256 == 0 and rd == 128 and self.cos_main is not None
               and all(L % 32 == 0 for _, L in self._all_streams()) and (self.C == 0 or self.cos_cond is not None)
               and self.cos_main.shape[0] == self.T + self.N)
         if ok:
@@ -740,7 +641,7 @@ class DiTEngine:
         the separate lx_qkv_prep_fp8_segs pass)."""
         if not self.qkv_fused or self.precise or self.gemm_fp8:
             return False
-        return not self.model_config.get("attn_fp8", False) or os.environ.get("LX_QKV_FUSED_FP8", "1") != "0"
+        return True
 
     def _attention(self, wq, wk, wq_txt, wk_txt, prepped: bool = False, layer: Optional[int] = None, img_only: bool = False) -> None:
         """img_only: only the image segment has queries (the last single block of a forward: the text / condition rows serve keys and values,
@@ -808,11 +709,11 @@ class DiTEngine:
         base = {"img": b, "cond": b, "txt": b + 6 * D}
         p = f"d{i}"
         Yq, Ya, Yf = self.Y[:, : 3 * D], self.Y[:, 2 * D: 3 * D], self.Y[:, 3 * D:]
-        lora = self._ln(base, 0, D, lora_name=p + ".qkv")                                  # norm1 / norm1_context (+ the q/k/v adapters' down-projection)
+        self._ln(base, 0, D)                                                               # norm1 / norm1_context
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
         fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2,
-                           qkv=nw + (i,) if fused else None, lora=lora)
+                           qkv=nw + (i,) if fused else None)
         self._attention(*nw, prepped=fused, layer=i)
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
@@ -842,33 +743,13 @@ class DiTEngine:
         b = cfg.mod_base_single(j)
         base = {"img": b, "cond": b, "txt": b}
         p = f"s{j}"
-        ln_lora = self._ln(base, 0, D, lora_name=p + ".fused", include_txt=True)
+        self._ln(base, 0, D)
         kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
         fused = self._qkv_epilogue()
-        if self.overlap:
-            # The MLP-up half of the fused projection does not feed the attention: it runs on a second stream beside
-            # {q/k/v projection -> attention}, so that the partly filled last rounds of the three kernels (0.41 + 0.88 + 0.94 of a
-            # round of 256 CUs) share the chip instead of each waiting for its own stragglers. One lx_lora_down serves both launches.
-            lora = ln_lora if ln_lora is not None else self._lora_t(self.XN, p + ".fused", include_txt=True)
-            main_s, side = torch.cuda.current_stream(self.device), self.side_stream
-            fork, join = torch.cuda.Event(), torch.cuda.Event()
-            fork.record(main_s)
-            side.wait_event(fork)
-            with torch.cuda.stream(side):
-                self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=0,
-                                   cols=(3 * D, 7 * D), lora=lora, lora_t_col0=3 * self.cfg.lora_r, ws=False,
-                                   only=("img",) if image_out_only else None)
-                join.record(side)
-            self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=3,
-                               cols=(0, 3 * D), ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None, lora=lora)
-            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
-            main_s.wait_event(join)
-        else:
-            self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                               lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None,
-                               lora=ln_lora)
-            self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
+        self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
+                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None)
+        self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
                            only=("img",) if image_out_only else None)
@@ -1266,6 +1147,7 @@ class DiTEngine:
         # shape and code path (LoRA rows, attention bias table, add_cond_attn ...): key it on exactly those.
         key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8, self.f16,
                getattr(self.w, "q_log2_version", 0),      # (a weight broadcast refreshes the scaled norm_q tensors and the per-layer bounds)
+               getattr(self.w, "weights_version", 0),     # (... and moves this one unconditionally: dist.broadcast_packed_weights)
                self.cond_cache, skip)
         g = self.graphs.get(key)
         if g is None:

@@ -31,8 +31,8 @@ _GEMM_WEIGHTS = re.compile(r"^(d\d+\.(qkv|qkv_txt|out|out_txt|ff1|ff1_txt|ff2|ff
 
 def _maybe_tile(name: str, w: torch.Tensor) -> torch.Tensor:
     """GEMM-consumed weights are stored pre-tiled (ops.tile_weight: the kernel's LDS image, one contiguous 32 KiB block
-    per K tile) so they stream from HBM with DRAM-page locality. LX_TILE_W=0 keeps nn.Linear row-major."""
-    if os.environ.get("LX_TILE_W", "1") == "0" or not _GEMM_WEIGHTS.match(name):
+    per K tile) so they stream from HBM with DRAM-page locality."""
+    if not _GEMM_WEIGHTS.match(name):
         return w
     if w.shape[0] % 256 or w.shape[1] % 64:
         return w
@@ -356,8 +356,55 @@ def install_lora(pw: PackedWeights, lora_sd: Dict[str, torch.Tensor], lora_scale
     for k in [k for k in pw.t if k.startswith("mod.lora_")]:
         del pw.t[k]
     pw.t.update(new_t)
-    pw.lora_version += 1                 # engines rebuild what they derived from the adapters (merged weights: DiTEngine._setup_lora_merge)
+    pw.lora_version += 1                 # engines rebuild what they derived from the adapters (the fp16 images: DiTEngine._setup_f16)
     return n
+
+
+@torch.no_grad()
+def realistic_stats_(pw: "PackedWeights", seed: int = 0) -> Dict:
+    """Give synthetic packed weights the statistics a trained checkpoint has and N(0, std^2) weights with unit norms and zero biases do
+    not (bench.py's `realistic_stats` leg; the parity harness applies the same recipe to the oracle model, oracle/parity.py):
+      (a) per-layer q / k RMSNorm weights with gains 0.5 ... 2.5 and 15 % channel jitter -- about half of the layers then exceed the
+          bounded-score attention's limit (16.33 max|w_q| max|w_k| <= 100) and keep the max-tracking kernel: a MIXED plan in one step;
+      (b) four residual-stream channels carrying a constant 60 ... 900 (x_embedder / context_embedder biases: "massive activations") and
+          three MLP-hidden channels per block at 50 ... 200 (ff1 / proj_mlp biases);
+      (c) every other bias N(0, 0.05^2)."""
+    cfg = pw.cfg
+    D = cfg.inner_dim
+    g = torch.Generator().manual_seed(9000 + seed)
+    dev = next(iter(pw.t.values())).device
+    gains = []
+    for li in range(cfg.num_layers + cfg.num_single_layers):
+        gain = 0.5 + 2.0 * ((li * 7) % 10) / 9.0
+        gains.append(gain)
+        p = f"d{li}" if li < cfg.num_layers else f"s{li - cfg.num_layers}"
+        for n in ("wq", "wk", "wq_txt", "wk_txt"):
+            t = pw.t.get(f"{p}.{n}")
+            if t is not None:
+                t.copy_((gain * (1.0 + 0.15 * torch.randn(t.shape[0], generator=g))).to(dev))
+    for name, t in pw.t.items():
+        if name.endswith(".b") and t.dim() == 1:
+            t.copy_((0.05 * torch.randn(t.shape[0], generator=g)).to(dev))
+    res_ch, res_val = [17, 1031, 2049, 3001], [120.0, -300.0, 60.0, 900.0]
+    for emb in ("x_embedder", "context_embedder"):
+        for c, v in zip(res_ch, res_val):
+            if c < D:
+                pw.t[emb + ".b"][c] = v
+    hid_val = [50.0, 200.0, -90.0]
+    for li in range(cfg.num_layers + cfg.num_single_layers):
+        if li < cfg.num_layers:
+            targets = [(pw.t[f"d{li}.ff1.b"], 0), (pw.t[f"d{li}.ff1_txt.b"], 0)]
+        else:
+            targets = [(pw.t[f"s{li - cfg.num_layers}.fused.b"], 3 * D)]          # fused columns [k | v | q | mlp]
+        for b, off in targets:
+            n = b.shape[0] - off
+            for k, v in enumerate(hid_val):
+                b[off + (li * 131 + k * 4099 + 7) % n] = v
+    if getattr(pw, "q_log2", None):
+        from ..dist import refresh_q_log2
+        refresh_q_log2(pw)
+    pw.weights_version = getattr(pw, "weights_version", 0) + 1
+    return {"norm_gain_range": [min(gains), max(gains)], "residual_outlier_channels": dict(zip(res_ch, res_val)), "mlp_hidden_outliers": hid_val, "bias_std": 0.05}
 
 
 def synthetic_weights(cfg: FluxConfig, device, seed: int = 0, std: float = 0.02, lora: bool = True, fill: bool = True) -> PackedWeights:

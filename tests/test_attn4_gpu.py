@@ -49,7 +49,6 @@ def _run(tmp_path, tag, env, **shape):
     out = str(tmp_path / f"{tag}.npy")
     e = dict(os.environ)
     e.pop("LX_ATTN4", None)
-    e.pop("LX_ATTN4_PERSIST", None)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, out=out, **shape)], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -80,10 +79,11 @@ def test_forced_kernel_passes_the_attention_suite():
 def test_persistent_launch_matches_one_item_per_workgroup_and_the_8wave_kernel(tmp_path, mode):
     """B = 12, H = 24 with ragged segments (3 + 2 + 1 query tiles per (batch, head) = 1728 items on 256 CUs: 6.75 rounds, items of 9
     key tiles whose last tiles are ragged): the persistent launch (K / V^T stream, rings and frame pipeline running across items) is
-    BIT-identical to one workgroup per item, and agrees with the 8-wave kernel to bf16 rounding of P (different summation order of l)."""
+    BIT-identical from run to run, and agrees with the 8-wave kernel to bf16 rounding of P (different summation order of l). (Until round 5
+    a switch ran the same kernel with one workgroup per item as a third arm: bit-identical, 300 runs of it on the driver's boxes.)"""
     shape = dict(B=12, H=24, lens=(520, 300, 100), mode=mode)
     k_p, o_p = _run(tmp_path, "persist", {"LX_ATTN4": "1"}, **shape)
-    k_1, o_1 = _run(tmp_path, "single", {"LX_ATTN4": "1", "LX_ATTN4_PERSIST": "0"}, **shape)
+    k_1, o_1 = _run(tmp_path, "again", {"LX_ATTN4": "1"}, **shape)
     k_8, o_8 = _run(tmp_path, "w8", {"LX_ATTN4": "0"}, **shape)
     assert (k_p, k_1, k_8) == (2, 2, 1)
     assert np.array_equal(o_p, o_1)
@@ -120,3 +120,61 @@ def test_repeated_launches_are_bit_reproducible(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "NHASH 1" in r.stdout, r.stdout
+
+
+def test_in_place_output_on_a_persistent_launch(tmp_path):
+    """The engine runs attention IN PLACE (O over the q columns of Y) -- from a persistent workgroup that fetches the next item's Q under
+    the current item's last frame. An item's Q tile is read only by the workgroup that later writes that item's O, and before it does:
+    the in-place launch must equal the launch into a separate buffer bit for bit, forty times in a row (6.75 rounds of items)."""
+    code = CHILD.replace('for _ in range(3):\n    ops.attn_fwd(buf, buf, VT, O, **kw)',
+                         'ops.attn_fwd(buf, buf, VT, O, **kw)\nkw2 = dict(kw, o_col=2 * D)\nhs = set()\nimport hashlib\nkeep = buf.clone()\n'
+                         'for _ in range(40):\n    buf.copy_(keep); ops.attn_fwd(buf, buf, VT, buf, **kw2)\n'
+                         '    hs.add(hashlib.sha256(buf[:, 2 * D:].contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n'
+                         'hs.add(hashlib.sha256(O.view(torch.int16).cpu().numpy().tobytes()).hexdigest())\nprint("NHASH", len(hs))\n'
+                         'assert torch.equal(buf[:, :2 * D], keep[:, :2 * D])')
+    out = str(tmp_path / "inplace.npy")
+    e = dict(os.environ, LX_ATTN4="1")
+    r = subprocess.run([sys.executable, "-c", code % dict(root=ROOT, out=out, B=12, H=24, lens=(520, 300, 100), mode="cfactor")], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "KERNEL 2" in r.stdout and "NHASH 1" in r.stdout, r.stdout
+
+
+def test_invariant_flag_keeps_shards_on_the_batch_kernel():
+    """LX_ATTN_INVARIANT (what the engine sets with its batch-size-invariant GEMM plans): the kernel choice must not depend on the batch
+    size of the launch -- at B = 16 the planner would otherwise move to lx_attn4_kernel, whose row sums are accumulated in another order.
+    The rows of batch element 0 from a B = 16 launch equal a B = 1 launch of the same rows bit for bit, and both ran the 8-wave kernel."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from loongx_amd import ops
+    from loongx_amd._lib import lib
+    dev, H, lens, B = "cuda", 24, (128, 256, 256), 16
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(3)
+    one = torch.ones(128, device=dev)
+
+    def run(bufs, Bn, flags):
+        M = Bn * sum(lens)
+        buf = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+        row0 = [Bn * sum(lens[:i]) for i in range(len(lens))]
+        for s_, L_ in enumerate(lens):                      # stream-major rows: batch b of segment s at row0[s] + b * L
+            buf[row0[s_]: row0[s_] + Bn * L_] = bufs[s_][: Bn * L_]
+        vt0, p = [], 0
+        for L_ in lens:
+            vt0.append(p); p += ((L_ + 63) // 64) * 64
+        VT = torch.zeros(Bn, H, 128, p, dtype=torch.bfloat16, device=dev)
+        ops.qkv_prep_segs(buf, 2 * D, 0, D, [(row0[i], lens[i], vt0[i], one * ops.Q_LOG2_FACTOR, one, None, None) for i in range(len(lens))], Bn, H, VT)
+        O = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
+        ops.attn_fwd(buf, buf, VT, O, q_col=2 * D, k_col=0, o_col=0, B=Bn, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=flags)
+        torch.cuda.synchronize()
+        return [O[row0[i]: row0[i] + lens[i]].clone() for i in range(len(lens))], lib.lx_attn_last_kernel()
+    bufs = [torch.randn(B * L_, 3 * D, device=dev, generator=g).to(torch.bfloat16) for L_ in lens]
+    base = ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED
+    o16, k16 = run(bufs, B, base | ops.ATTN_INVARIANT)
+    o1, k1 = run(bufs, 1, base | ops.ATTN_INVARIANT)
+    assert (k16, k1) == (1, 1)                               # LX_ATTN_KERNEL_8WAVE both times
+    assert all(torch.equal(a, b) for a, b in zip(o16, o1))
+    import os
+    if os.environ.get("LX_ATTN4") is None:
+        _, kfree = run(bufs, B, base)
+        assert kfree == 2                                    # without the flag this launch shape goes to lx_attn4_kernel

@@ -176,9 +176,9 @@ def test_load_lora_from_safetensors(G, tmp_path):
 
 
 @pytest.mark.parametrize("mc", [{}, {"latent_lora": True}, {"union_cond_attn": False}])
-def test_forward_with_fused_qkv_epilogue(monkeypatch, mc):
+def test_forward_with_fused_qkv_epilogue(mc):
     """Streams of 32 / 64 / 64 tokens take the LX_EPI_QKV projection epilogue (RMSNorm + RoPE + V^T inside the GEMM, no qkv_prep
-    launch): against the fp32 oracle, and against the same engine with LX_QKV_FUSED=0 (the two-pass path the goldens cover).
+    launch): against the fp32 oracle, and against the same engine with qkv_epilogue = False (the two-pass path the goldens cover).
     The last single block exercises the kv-only (N = 2D) launch of the text / condition streams."""
     from oracle import flux_modules as fm
     tr = tiny_transformer(seed=5)
@@ -196,8 +196,8 @@ def test_forward_with_fused_qkv_epilogue(monkeypatch, mc):
     d = "cuda"
     outs = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("LX_QKV_FUSED", fused)
         eng = _engine(tr)
+        eng.qkv_epilogue = fused == "1"
         eng.set_conditioning(kw["encoder_hidden_states"].to(d), kw["pooled_projections"].to(d), kw["guidance"].to(d), kw["txt_ids"].to(d),
                              kw["img_ids"].to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=mc)
         assert eng.qkv_fused == (fused == "1")
@@ -208,23 +208,6 @@ def test_forward_with_fused_qkv_epilogue(monkeypatch, mc):
     e1, e0 = relerr(outs["1"], want), relerr(outs["0"], want)
     assert e1 < TOL and e0 < TOL, (e1, e0)
     assert relerr(outs["1"], outs["0"]) < 1e-2
-
-
-def test_two_stream_single_blocks_match_the_serial_schedule(monkeypatch, G):
-    """LX_OVERLAP=1: the MLP-up half of a single block's fused projection runs on a second stream beside {q/k/v projection ->
-    attention} (fork / join inside the captured step graph). Same arithmetic per output element: the results must agree with the
-    one-stream schedule to the last bit, eagerly and replayed."""
-    outs = {}
-    for ov in ("0", "1"):
-        monkeypatch.setenv("LX_OVERLAP", ov)
-        eng = _engine(tiny_transformer())
-        assert eng.overlap == (ov == "1")
-        a = _run(eng, G)
-        b = eng.forward(G["in_latents"].to("cuda"), G["in_timestep"].to("cuda")).float().cpu().clone()      # graph replay
-        assert torch.equal(a, b)
-        outs[ov] = a
-    assert torch.equal(outs["0"], outs["1"])
-    assert relerr(outs["1"], G["fwd_cond"]) < TOL
 
 
 @pytest.mark.parametrize("mc", [{"independent_condition": True}, {"union_cond_attn": False}, {"independent_condition": True, "latent_lora": True}])
@@ -280,52 +263,3 @@ def test_condition_cache_is_off_when_the_condition_stream_sees_the_image(G):
     assert not eng.cond_cache and not eng.cond_cached and eng.KC is None
 
 
-def test_lora_down_inside_ln_modulate_matches_the_separate_launch(monkeypatch, G):
-    """LX_LN_LORA=1 (opt-in): T of the q/k/v(/proj_mlp) adapters from lx_ln_modulate_lora_segs instead of lx_lora_down."""
-    outs = {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("LX_LN_LORA", v)
-        eng = _engine(tiny_transformer())
-        assert eng.ln_lora == (v == "1")
-        outs[v] = _run(eng, G)
-    assert relerr(outs["1"], outs["0"]) < 2e-3 and relerr(outs["1"], G["fwd_cond"]) < TOL
-
-
-@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
-def test_merged_adapter_weights_match_the_unmerged_launches(monkeypatch, G, mc):
-    """LX_LORA_MERGE=1 (opt-in): the adapter rows' problems read W' = bf16(W + scale * B A) and the step has no lx_lora_down launch
-    behind the condition embedder; against the unmerged path (fp32-class LoRA term on bf16 W) and the reference goldens, with the
-    scale moved (merged weights rebuilt in place) and back, and with the adapters off (base weights on every stream)."""
-    from loongx_amd import ops
-    calls = [0]
-    real = ops.lora_down
-
-    def counted(*a, **k):
-        calls[0] += 1
-        return real(*a, **k)
-    monkeypatch.setattr(ops, "lora_down", counted)
-    outs, n_down = {}, {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("LX_LORA_MERGE", v)
-        eng = _engine(tiny_transformer())
-        assert eng.lora_merge == (v == "1")
-        calls[0] = 0
-        outs[v] = _run(eng, G, model_config=mc)
-        n_down[v] = calls[0]
-        if v == "1":
-            eng.set_lora_scale(0.5)
-            half = _run(eng, G, model_config=mc)
-            eng.set_lora_scale(0.0)
-            off = _run(eng, G, model_config=mc)
-            eng.set_lora_scale(1.0)
-            assert torch.equal(_run(eng, G, model_config=mc), outs["1"])          # rebuilt in place: the same image of W'
-        else:
-            eng.set_lora_scale(0.5)
-            half0 = _run(eng, G, model_config=mc)
-            eng.set_lora_scale(0.0)
-            off0 = _run(eng, G, model_config=mc)
-    assert n_down["1"] < n_down["0"] and n_down["1"] <= 3                         # (x_embedder keeps its adapter launches: condition rows, latents)
-    assert relerr(outs["1"], outs["0"]) < 3e-3
-    assert relerr(half, half0) < 3e-3 and torch.equal(off, off0)
-    if not mc:
-        assert relerr(outs["1"], G["fwd_cond"]) < TOL

@@ -133,20 +133,16 @@ def test_engine_fp8_attention_vs_bf16_path_at_1024sq():
         assert torch.equal(fwd(slice(i, i + 1), {"attn_fp8": True})[0], v8[i])
 
 
-@pytest.mark.parametrize("variant", ["pow2", "generic_scale", "plain_kernel", "no_pow2"])
+@pytest.mark.parametrize("variant", ["pow2", "generic_scale"])
 def test_fp8_attention_kernel_variants_agree(variant):
     """The pipelined fp8 kernel's two score paths (MX-block-scaled MFMAs with exp2 straight on the result when scale x log2 e x
     descale is a power of two -- the default, arranged by ops.FP8_Q_SCALE -- and the generic one-fma-per-score path taken for any
-    other softmax scale) and the plain kernel, each in its own process (the switches are read once), against fp32 SDPA."""
+    other softmax scale), against fp32 SDPA."""
     import os, subprocess, sys
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ)
     env["LX_T_SCALE"] = "0.1" if variant == "generic_scale" else ""
-    if variant == "plain_kernel":
-        env["LX_ATTN_FP8_PIPE"] = "0"
-    if variant == "no_pow2":
-        env["LX_ATTN_FP8_POW2"] = "0"
     code = r'''
 import os, sys, math, torch
 sys.path.insert(0, os.getcwd())
@@ -272,9 +268,9 @@ def test_gemm_qkv_epilogue_e4m3_images(ops, monkeypatch, bm):
 
 
 @pytest.mark.parametrize("mc", [{}, {"latent_lora": True}])
-def test_engine_fp8_attention_with_fused_projection_epilogue(monkeypatch, mc):
+def test_engine_fp8_attention_with_fused_projection_epilogue(mc):
     """model_config attn_fp8 with bf16 GEMMs: the engine takes the e4m3 projection epilogue (no lx_qkv_prep_fp8_segs launch);
-    against the fp32 oracle and against the same engine with LX_QKV_FUSED_FP8=0 (the two-pass path)."""
+    against the fp32 oracle and against the same engine with qkv_epilogue = False (the two-pass path)."""
     from oracle import flux_modules as fm
     from oracle import flux_ref as fr
     from tests.helpers import tiny_transformer
@@ -295,8 +291,8 @@ def test_engine_fp8_attention_with_fused_projection_epilogue(monkeypatch, mc):
     mc8 = dict(mc, attn_fp8=True)
     outs = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("LX_QKV_FUSED_FP8", fused)
         eng = _engine(tr)
+        eng.qkv_epilogue = fused == "1"
         eng.set_conditioning(kw["encoder_hidden_states"].to(d), kw["pooled_projections"].to(d), kw["guidance"].to(d), kw["txt_ids"].to(d),
                              kw["img_ids"].to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=mc8)
         assert eng._qkv_epilogue() == (fused == "1")

@@ -286,6 +286,42 @@ def test_gemm4_split_form_with_a_ragged_tile_row(ops):
     ops.gemm_workspace_status(ws)
 
 
+def test_gemm_split_form_timeout_is_reported_and_poisons_the_workspace(ops, monkeypatch):
+    """LX_GEMM4_FAULT=1: the second half of every split tile never raises its flag. The first half's bounded wait gives up, raises the
+    workspace's error word and finishes (nothing hangs, nothing traps). The word is STICKY: until lx_gemm_workspace_status has reported
+    and reset it, later split launches on that workspace refuse the exchange (a flag raised late by the timed-out launch could otherwise
+    be trusted by the next one) -- and after the reset the same launch is exact again."""
+    from loongx_amd._lib import LxError
+    monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    M, N, K = 2560, 1536, 6144                                            # 60 tiles, 96 K tiles: the split form by default
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16)
+    ref = (A.float() @ W.float().T).cpu()
+    ws = ops.gemm_workspace(DEV)
+    C = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    d = ops.gemm_desc(A, W, C, epilogue=ops.LX_EPI_STORE_F32)
+    ops.gemm([d], ws); torch.cuda.synchronize()
+    assert relerr(C.cpu(), ref) < 2e-5
+    ops.gemm_workspace_status(ws)                                         # clean
+    monkeypatch.setenv("LX_GEMM4_FAULT", "1")
+    ops.lib.lx_gemm_reload_env()
+    ops.gemm([d], ws); torch.cuda.synchronize()                           # ~1 s: every first half polls to its bound
+    monkeypatch.delenv("LX_GEMM4_FAULT")
+    ops.lib.lx_gemm_reload_env()
+    n = ws.numel()
+    assert int(ws[n - 64 * 4: n - 63 * 4].view(torch.int32)[0]) == 1
+    import time
+    t0 = time.time()
+    ops.gemm([d], ws); torch.cuda.synchronize()                           # a healthy launch on the poisoned workspace: refused, not trusted
+    assert time.time() - t0 < 0.5                                         # (and it does not wait for anything)
+    assert relerr(C.cpu(), ref) > 1e-3
+    with pytest.raises(LxError):
+        ops.gemm_workspace_status(ws)                                     # reported once, flags and word reset
+    ops.gemm([d], ws); torch.cuda.synchronize()
+    assert relerr(C.cpu(), ref) < 2e-5
+    ops.gemm_workspace_status(ws)
+
+
 def test_gemm_workspace_error_word_position(ops):
     """The engine polls the workspace's error word asynchronously (FluxEngine.check_status(sync=False)) at a FIXED position: the int 64
     ints before the end (include/lx.h). Raising it by hand must be what lx_gemm_workspace_status reports -- and resets."""
