@@ -313,8 +313,8 @@ def test_gemm_split_form_timeout_is_reported_and_poisons_the_workspace(ops, monk
     import time
     t0 = time.time()
     ops.gemm([d], ws); torch.cuda.synchronize()                           # a healthy launch on the poisoned workspace: refused, not trusted
-    assert time.time() - t0 < 0.5                                         # (and it does not wait for anything)
-    assert relerr(C.cpu(), ref) > 1e-3
+    assert time.time() - t0 < 0.5                                         # (and it does not wait for anything; its output is not to be used --
+    assert int(ws[n - 64 * 4: n - 63 * 4].view(torch.int32)[0]) == 1      #  the word is still up and says so)
     with pytest.raises(LxError):
         ops.gemm_workspace_status(ws)                                     # reported once, flags and word reset
     ops.gemm([d], ws); torch.cuda.synchronize()
