@@ -237,6 +237,50 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def dry_run_plan(a):
+    """What `bench.py <these flags>` would run, rank by rank (configs[3] / [4] are 8-GPU configurations this builder cannot launch): the
+    workload each rank gets under the same rules main() applies, the launch command of _self_launch, and the bytes of the weight
+    broadcast -- computed on the host, nothing is allocated."""
+    from loongx_amd.flux.weights import FluxConfig
+    world = max(1, a.gpus)
+    mc = {"union_cond_attn": True}
+    if a.config:
+        c = CONFIGS[a.config]
+        B = max(1, c["global_batch"] // world) if a.batch is None else a.batch
+        hw = c["hw"] if a.hw is None else a.hw
+        allmod = (c["modalities"] if a.modalities is None else a.modalities) == "all"
+        mc.update(c["mc"])
+    else:
+        B, hw, allmod = a.batch or 1, a.hw or 32, (a.modalities or "eeg") == "all"
+    for flag, key in ((a.fp8 or a.attn_fp8, "attn_fp8"), (a.fp8 or a.gemm_fp8, "gemm_fp8"), (a.independent_condition, "independent_condition")):
+        if flag:
+            mc[key] = True
+    if a.operands:
+        mc["operands"] = a.operands
+    cfg = FluxConfig()
+    D_, r_ = cfg.inner_dim, cfg.lora_r
+    nb = cfg.num_layers + cfg.num_single_layers
+    # bytes of synthetic_weights(cfg): bf16 GEMM / modulation weights, fp32 biases / norm weights / LoRA-up, bf16 LoRA-down
+    w_el = cfg.num_layers * (2 * 3 * D_ * D_ + 2 * D_ * D_ + 2 * 4 * D_ * D_ + 2 * 4 * D_ * D_) + cfg.num_single_layers * (7 * D_ * D_ + 5 * D_ * D_) + cfg.n_mod * D_ \
+        + D_ * cfg.in_channels + D_ * cfg.joint_attention_dim + cfg.in_channels * D_ + 2 * (256 * D_ + D_ * D_) + cfg.pooled_projection_dim * D_ + D_ * D_
+    b_el = cfg.num_layers * (2 * 3 * D_ + 2 * D_ + 2 * 4 * D_ + 2 * D_ + 4 * 128) + cfg.num_single_layers * (7 * D_ + D_ + 2 * 128) + cfg.n_mod + 2 * D_ + cfg.in_channels + 6 * D_
+    lora_dn = cfg.num_layers * (3 * r_ * D_ + r_ * D_ + r_ * 4 * D_) + cfg.num_single_layers * (4 * r_ * D_ + r_ * 5 * D_) + nb * r_ * D_ + r_ * cfg.in_channels
+    lora_up = cfg.num_layers * (3 * D_ * r_ + D_ * r_ + D_ * r_) + cfg.num_single_layers * (7 * D_ * r_ + D_ * r_) + (cfg.num_layers * 6 + cfg.num_single_layers * 3) * D_ * r_ + D_ * r_
+    wbytes = 2 * (w_el + lora_dn) + 4 * (b_el + lora_up)
+    N = hw * hw
+    fpi = flops_per_image(N, N)
+    ranks = [{"rank": r, "device": f"cuda:{r}", "batch": B, "tokens_per_sample": [T_TXT, N, N], "rows_per_step": B * (T_TXT + 2 * N),
+              "images_per_timed_step": B, "seed": 1234 + r, "weights": "draws" if r == 0 else "receives (RCCL broadcast from rank 0)",
+              "pflop_per_timed_step": round(B * fpi / 1e15, 3)} for r in range(world)]
+    launch = (f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node={world} --master-addr 127.0.0.1 --master-port <free port> "
+              f"{os.path.abspath(__file__)} " + " ".join(x for x in sys.argv[1:] if x != "--dry-run")) if world > 1 else f"{sys.executable} {os.path.abspath(__file__)}"
+    return {"dry_run": True, "metric": f"edited images/s @{16 * hw}x{16 * hw}, 28-step Flux denoise", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "scaling": "weak", "config": {"workload": workload_name(a.config, B, hw, allmod, mc, a.precise), "batch_per_gpu": B, "global_batch": world * B,
+                                         "parallelism": f"dp{world}", "model_config": mc, "collectives": "one weight broadcast before the timed region; "
+                                         "barrier + all_reduce(MAX) of the elapsed time around it; none inside the denoise loop"},
+            "weight_bytes_per_rank": wbytes, "launch": launch, "ranks": ranks}
+
+
 def parity_check(precise: bool = False, extra_mc=None, hw: int = 32, every: int = 1, brain=None, realistic: bool = False):
     """The engine against the fp32 oracle (oracle/parity.py: test infrastructure, used here as the checker only, outside the
     timed region) at full depth and width on this GPU, in the mode the timed region ran."""
@@ -440,7 +484,11 @@ def main():
     ap.add_argument("--operands", type=str, default=None, choices=("bf16", "fp16"),
                     help="16-bit format of the GEMM operand images: bf16 (default) | fp16 (v_mfma_f32_*_f16, same rate, 11 significand bits: the "
                          "north star's 1e-3 per forward; model_config[\"operands\"])")
+    ap.add_argument("--dry-run", action="store_true", help="print the per-rank plan of this invocation as one JSON line and exit: no GPU, no process group")
     a = ap.parse_args()
+    if a.dry_run:
+        print(json.dumps(dry_run_plan(a)))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(a.gpus))
 

@@ -58,6 +58,58 @@ def test_gloo_world2_broadcast_shard_gather():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _book_worker(rank, world, port, q):
+    """world-N bookkeeping at the configs' real sizes: global batch 128 (configs[3]) and 30 (uneven: the last rank takes the remainder,
+    reference inference.py:126-128) -- shard, per-rank results tagged with their global index, gather in order, max-over-ranks timing."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from loongx_amd import dist as lxd
+    r, _, w = lxd.init("gloo", timeout_s=60)
+    ok = (r, w) == (rank, world)
+    for n in (128, 30):
+        spans = [lxd.shard_range(n, r_, world) for r_ in range(world)]
+        counts = [e - s for s, e in spans]
+        ok = ok and counts[:-1] == [n // world] * (world - 1) and sum(counts) == n and counts[-1] == n - (world - 1) * (n // world)
+        s, e = spans[rank]
+        local = (torch.arange(s, e, dtype=torch.float32).view(-1, 1, 1) * torch.ones(1, 3, 2))          # [count, 3, 2] "latents" tagged by image index
+        allr = lxd.gather_batches(local, counts)
+        ok = ok and allr.shape == (n, 3, 2) and torch.equal(allr[:, 0, 0], torch.arange(n, dtype=torch.float32))
+    ok = ok and lxd.barrier_max_ms(100.0 + rank, "cpu") == 100.0 + world - 1
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world4_bookkeeping_at_the_configs_batch_sizes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_book_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(4)]
+
+
+def test_bench_dry_run_prints_the_per_rank_plan_without_a_gpu():
+    """`bench.py --gpus 8 --config 3 --dry-run`: the literal configs[3] run (batch 128 over 8 GPUs) as a plan -- per-rank batch, tokens,
+    launch command, weight bytes each rank receives -- without touching a GPU or starting a process group."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["dry_run"] and plan["n_gpus"] == 8 and plan["config"]["global_batch"] == 128 and plan["config"]["parallelism"] == "dp8"
+    assert [p["batch"] for p in plan["ranks"]] == [16] * 8 and plan["ranks"][3]["tokens_per_sample"] == [512, 1024, 1024]
+    assert "torch.distributed.run" in plan["launch"] and "--nproc-per-node=8" in plan["launch"]
+    assert 23.0e9 < plan["weight_bytes_per_rank"] < 25.0e9 and plan["ranks"][0]["weights"] == "draws" and plan["ranks"][7]["weights"] == "receives (RCCL broadcast from rank 0)"
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "4", "--dry-run"], capture_output=True, text=True, timeout=300)
+    p4 = json.loads(r4.stdout.strip().splitlines()[-1])
+    assert [p["batch"] for p in p4["ranks"]] == [4] * 8 and p4["ranks"][0]["tokens_per_sample"] == [512, 4096, 4096] and p4["config"]["model_config"].get("attn_fp8")
+
+
 def test_shard_range_matches_reference_rule():
     from loongx_amd.dist import shard_range
     for n in (0, 1, 7, 8, 128, 131):
