@@ -7,7 +7,7 @@
 // kernel K[h,l]; here the same operator runs as a linear recurrence in modal form,
 //     y[l] = Re sum_n w_n s_n[l] + D u[l],   s_n[l] = lam_n s_n[l-1] + u[l],
 // evaluated by a WAVEFRONT PREFIX SCAN: the 64 lanes of a wave each own L/64 consecutive time steps of one
-// (batch, channel) sequence, run the recurrence locally, exchange chunk carries with a 6-step Kogge-Stone
+// (batch, channel) sequence (read with coalesced loads and handed to the lanes through LDS: seq_to_lanes), run the recurrence locally, exchange chunk carries with a 6-step Kogge-Stone
 // scan over the wave (multiplier lam^(L/64), squared each step), and replay with the carry-in.  HiPPO-LegS
 // modes cancel by up to ~1e10 at n=64 (oracle/s4.py::diagonalize), so the state and the output accumulator
 // are fp64 -- MI355X runs vector fp64 at half the fp32 rate, and the op is tiny next to the DiT.
@@ -16,25 +16,63 @@
 
 namespace {
 
+// A sequence's samples reach the lanes through LDS: the workgroup reads its NT * CH consecutive floats with lane-CONTIGUOUS loads (one
+// 256-B run per wave and instruction; 16 B per lane when CH % 4 == 0), and every lane then takes the CH consecutive samples it owns from
+// LDS (rows of CH + 1 floats: conflict-free). Until round 5 a lane loaded its own chunk straight from HBM -- 16 B per lane at a CH * 4-byte
+// stride, i.e. 64 different 256-B-apart addresses per load instruction. Results are the same bits; the output goes back the same way.
+template <int CH, int NT>
+__device__ __forceinline__ void seq_to_lanes(const float* __restrict__ src, float* __restrict__ lds, float (&uf)[CH], int tid) {
+  if constexpr (CH % 4 == 0) {
+#pragma unroll
+    for (int it = 0; it < CH / 4; ++it) {
+      const int i = (it * NT + tid) * 4;               // float index in the sequence: lanes on consecutive 16-byte pieces
+      const f32x4 v = *(const f32x4*)(src + i);
+      float* d = lds + (i / CH) * (CH + 1) + (i % CH);
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      const int i = it * NT + tid;
+      lds[(i / CH) * (CH + 1) + (i % CH)] = src[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CH; ++j) uf[j] = lds[tid * (CH + 1) + j];
+  __syncthreads();
+}
+template <int CH, int NT>
+__device__ __forceinline__ void lanes_to_seq(float* __restrict__ dst, float* __restrict__ lds, const float (&yf)[CH], int tid) {
+#pragma unroll
+  for (int j = 0; j < CH; ++j) lds[tid * (CH + 1) + j] = yf[j];
+  __syncthreads();
+  if constexpr (CH % 4 == 0) {
+#pragma unroll
+    for (int it = 0; it < CH / 4; ++it) {
+      const int i = (it * NT + tid) * 4;
+      const float* d = lds + (i / CH) * (CH + 1) + (i % CH);
+      *(f32x4*)(dst + i) = f32x4{d[0], d[1], d[2], d[3]};
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      const int i = it * NT + tid;
+      dst[i] = lds[(i / CH) * (CH + 1) + (i % CH)];
+    }
+  }
+}
+
 template <int CH>
 __global__ __launch_bounds__(64) void s4_scan_kernel(const float* __restrict__ u, const double* __restrict__ lam,
                                                      const double* __restrict__ w, const float* __restrict__ Dskip,
                                                      float* __restrict__ y, int H, int L, int N) {
+  __shared__ float stage[64 * (CH + 1)];
   const int bh = blockIdx.x;
   const int h = bh % H;
   const int lane = threadIdx.x;
-  const float* up = u + (size_t)bh * L + lane * CH;
   float uf[CH];
-  if constexpr (CH % 4 == 0) {
-#pragma unroll
-    for (int j = 0; j < CH; j += 4) {
-      const f32x4 v = *(const f32x4*)(up + j);
-      uf[j] = v[0]; uf[j + 1] = v[1]; uf[j + 2] = v[2]; uf[j + 3] = v[3];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) uf[j] = up[j];
-  }
+  seq_to_lanes<CH, 64>(u + (size_t)bh * L, stage, uf, lane);
   double yacc[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) yacc[j] = 0.0;
@@ -78,9 +116,10 @@ __global__ __launch_bounds__(64) void s4_scan_kernel(const float* __restrict__ u
     }
   }
   const double dk = (double)Dskip[h];
-  float* yp = y + (size_t)bh * L + lane * CH;
+  float yf[CH];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) yp[j] = (float)(yacc[j] + dk * (double)uf[j]);
+  for (int j = 0; j < CH; ++j) yf[j] = (float)(yacc[j] + dk * (double)uf[j]);
+  lanes_to_seq<CH, 64>(y + (size_t)bh * L, stage, yf, lane);
 }
 
 // The same scan with NW waves per sequence (block = NW x 64 lanes, lane g owns time steps [g*CH, (g+1)*CH)): a [B, H] = [1, 64]
@@ -93,21 +132,12 @@ __global__ __launch_bounds__(64 * NW) void s4_scan_mw_kernel(const float* __rest
                                                            const double* __restrict__ w, const float* __restrict__ Dskip,
                                                            float* __restrict__ y, int H, int L, int N) {
   __shared__ double tot[2][NW][2];
+  __shared__ float stage[64 * NW * (CH + 1)];
   const int bh = blockIdx.x, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = wave * 64 + lane;
-  const float* up = u + (size_t)bh * L + g * CH;
   float uf[CH];
-  if constexpr (CH % 4 == 0) {
-#pragma unroll
-    for (int j = 0; j < CH; j += 4) {
-      const f32x4 v = *(const f32x4*)(up + j);
-      uf[j] = v[0]; uf[j + 1] = v[1]; uf[j + 2] = v[2]; uf[j + 3] = v[3];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) uf[j] = up[j];
-  }
+  seq_to_lanes<CH, 64 * NW>(u + (size_t)bh * L, stage, uf, g);
   double yacc[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) yacc[j] = 0.0;
@@ -164,9 +194,10 @@ __global__ __launch_bounds__(64 * NW) void s4_scan_mw_kernel(const float* __rest
     }
   }
   const double dk = (double)Dskip[h];
-  float* yp = y + (size_t)bh * L + g * CH;
+  float yf[CH];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) yp[j] = (float)(yacc[j] + dk * (double)uf[j]);
+  for (int j = 0; j < CH; ++j) yf[j] = (float)(yacc[j] + dk * (double)uf[j]);
+  lanes_to_seq<CH, 64 * NW>(y + (size_t)bh * L, stage, yf, g);
 }
 
 // direct causal convolution: block per (b,h); K and u staged in LDS
@@ -478,7 +509,116 @@ __global__ __launch_bounds__(256) void chan_gemm_f32_kernel(const float* __restr
   }
 }
 
+// ---- the same operator on the bf16 matrix pipe, fp32-class: Y = epi(W . X + bias) with every operand a bf16 PAIR -------------------
+// x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 significand bits), W likewise, and W . X evaluated as W_hi X_lo + W_lo X_hi +
+// W_hi X_hi on v_mfma_f32_32x32x16_bf16 into one fp32 accumulation (the dropped W_lo X_lo term is 2^-18 relative): three MFMAs of 16-deep k
+// where the exact-fp32 form needs eight of 2-deep k -- 16 / 3 of its rate (precise.hip's trick). The DUAN gate's two 1x1
+// convolutions are 17.2 GFLOP of this per batch-16 call and were the reason `duan_norm_prompt` ran at 0.8 TB/s of its algorithmic bytes
+// (fp32-matrix-bound at 157 TFLOP/s peak, not HBM-bound: round 4). Layout: a 64 (n) x 64 (l) tile per 4 waves as above, K in chunks of 64;
+// the split happens ONCE per element at staging time -- W rows as they are, X transposed on the way into LDS (thread = one position l,
+// 16 channels k: lane-contiguous 4-byte global loads, then 16 consecutive k of its l as two 16-byte LDS stores per image) so that both
+// MFMA operands are one ds_read_b128 per lane (rows of 72 bf16 = 144 B: the 16 lanes of a read phase hit 64 distinct banks).
+constexpr int CS_KC = 64, CS_LD = 72;
+__global__ __launch_bounds__(256) void chan_gemm_split_kernel(const float* __restrict__ X, long x_bstride, int ldx, const float* __restrict__ W, int ldw,
+                                                              const float* __restrict__ bias, float* __restrict__ Y, long y_bstride, int ldy,
+                                                              int N, int K, int L, int epi, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) uint16_t Wh[64 * CS_LD], Wl[64 * CS_LD], Xh[64 * CS_LD], Xl[64 * CS_LD];
+  const int b = blockIdx.z, n0 = blockIdx.y * 64, l0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave >> 1, wl = wave & 1;
+  const float* Xb = X + (size_t)b * x_bstride;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // staging roles: W: thread -> (row n = tid / 4, 16 consecutive k); X: thread -> (position l = tid % 64, 16 consecutive k)
+  const int wn_s = tid >> 2, wk_s = (tid & 3) * 16;
+  const int xl_s = tid & 63, xk_s = (tid >> 6) * 16;
+  const bool w_ok = n0 + wn_s < N, x_ok = l0 + xl_s < L;
+  float wr[16], xr[16];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (w_ok && k0 + wk_s + 4 * q < K) v = *(const f32x4*)(W + (size_t)(n0 + wn_s) * ldw + k0 + wk_s + 4 * q);     // (K % 4 == 0)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wr[4 * q + c] = v[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xr[j] = (x_ok && k0 + xk_s + j < K) ? Xb[(size_t)(k0 + xk_s + j) * ldx + l0 + xl_s] : 0.f;
+  };
+  auto split_store = [&](const float (&v)[16], uint16_t* dh, uint16_t* dl) {
+    u32x4 h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint16_t a = f32_to_bf16(v[2 * q]), c = f32_to_bf16(v[2 * q + 1]);
+      h[q >> 2][q & 3] = (uint32_t)a | ((uint32_t)c << 16);
+      l[q >> 2][q & 3] = pack_bf16x2(v[2 * q] - bf16_to_f32(a), v[2 * q + 1] - bf16_to_f32(c));
+    }
+    *(u32x4*)dh = h[0]; *(u32x4*)(dh + 8) = h[1];
+    *(u32x4*)dl = l[0]; *(u32x4*)(dl + 8) = l[1];
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += CS_KC) {
+    __syncthreads();                                   // the previous chunk's fragments have been read
+    split_store(wr, Wh + wn_s * CS_LD + wk_s, Wl + wn_s * CS_LD + wk_s);
+    split_store(xr, Xh + xl_s * CS_LD + xk_s, Xl + xl_s * CS_LD + xk_s);
+    __syncthreads();
+    if (k0 + CS_KC < K) fetch(k0 + CS_KC);             // the next chunk's loads fly under this chunk's MFMAs
+    const int ao = (wn * 32 + l31) * CS_LD + hi * 8, bo = (wl * 32 + l31) * CS_LD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < CS_KC / 16; ++ks) {
+      const bf16x8 ah = *(const bf16x8*)(Wh + ao + ks * 16), al = *(const bf16x8*)(Wl + ao + ks * 16);
+      const bf16x8 bh = *(const bf16x8*)(Xh + bo + ks * 16), bl = *(const bf16x8*)(Xl + bo + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);       // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  // acc[r]: n = n0 + wn*32 + 8*(r/4) + 4*hi + r%4 ; l = l0 + wl*32 + l31   (the layout of chan_gemm_f32_kernel: same epilogues)
+  const int l = l0 + wl * 32 + l31;
+  float* Yb = Y ? Y + (size_t)b * y_bstride : nullptr;
+  if (epi == 3) {
+    __syncthreads();
+    float* red = (float*)Xh;                           // 64 n x 2 halves of partial sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nl = wn * 32 + 8 * (r >> 2) + 4 * hi + (r & 3), n = n0 + nl;
+      float v = 0.f;
+      if (n < N && l < L) v = 1.0f / (1.0f + __expf(-(acc[r] + (bias ? bias[n] : 0.f))));
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (l31 == 0) red[nl * 2 + wl] = v;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) part[((size_t)b * gridDim.x + blockIdx.x) * N + n0 + tid] = red[tid * 2] + red[tid * 2 + 1];
+    return;
+  }
+  if (l >= L) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+    if (n >= N) continue;
+    float v = acc[r] + (bias ? bias[n] : 0.f);
+    float* yp = Yb + (size_t)n * ldy + l;
+    if (epi == 1) v += *yp;
+    else if (epi == 2) v = v > 0.f ? v : 0.f;
+    *yp = v;
+  }
+}
+
 }  // namespace
+
+// internal (dgf.hip): the split-bf16 form of lx_chan_gemm_f32, same arguments and epilogues, relative error ~2^-16 instead of exact fp32 products
+int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride, int ldy,
+                       int B, int N, int K, int L, int epilogue, float* part, void* stream) {
+  LX_CHECK_ARG(X && W && B > 0 && N > 0 && K > 0 && L > 0, "lx_chan_gemm_split: bad arguments");
+  LX_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && (epilogue == 3 ? part != nullptr : Y != nullptr), "lx_chan_gemm_split: epilogue 0..3 (3 needs part, the others Y)");
+  LX_CHECK_ARG(K % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, "lx_chan_gemm_split: K, ldw must be multiples of 4, W 16-byte aligned");
+  hipLaunchKernelGGL(chan_gemm_split_kernel, dim3((L + 63) / 64, (N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, W, ldw, bias, Y,
+                     y_bstride, ldy, N, K, L, epilogue, part);
+  LX_LAUNCH_CHECK("lx_chan_gemm_split");
+  return LX_OK;
+}
 
 extern "C" int lx_chan_gemm_f32(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride,
                                 int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream) {

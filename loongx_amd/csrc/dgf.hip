@@ -7,6 +7,9 @@
 //   5 mask    per b: rank-count top-k over channels, zero the dropped rows
 #include "common.h"
 
+int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride, int ldy,
+                       int B, int N, int K, int L, int epilogue, float* part, void* stream);       // cs3.hip
+
 namespace {
 
 __device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads
@@ -77,17 +80,20 @@ __global__ __launch_bounds__(256) void duan_gate_kernel(const float* __restrict_
   }
 }
 
-// One workgroup per (64 channels, b) -- 8 x B workgroups instead of B (16 workgroups ran this for 53 us at batch 16). Every workgroup
-// recomputes what all channels share (layer statistics in fp64, the hidden layer of the gamma / beta MLP: waves over hidden units,
-// lanes over channels, so the weight rows are read coalesced); the per-channel sums keep their order (gate mean over tiles, MLP rows
-// over hidden units), so the affine is bit-identical to the one-workgroup form.
+// One workgroup per (64 channels, b). Every workgroup recomputes what all channels share (layer statistics in fp64, the hidden layer of
+// the gamma / beta MLP). Round 5: every dot product is a WAVE's -- lanes along the contraction, coalesced weight rows straight from
+// global memory, all loads of a row in flight at once, one shuffle reduction -- and the gate's mean over the L / 64 position tiles is
+// summed by four groups of lanes in parallel. The earlier form walked each contraction on one lane (64-128 dependent steps, and 64
+// dependent global loads for the tile sums): 152 us per call at C = 512, L = 4096 on 128 workgroups, the largest kernel of the DUAN.
+// Sums are in a fixed order (tree per wave, then ascending): deterministic, batch-independent.
 __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gpart,
                                                         const float* __restrict__ mw1, const float* __restrict__ mb1,
                                                         const float* __restrict__ mw2, const float* __restrict__ mb2,
                                                         float* __restrict__ coef, int C, int L, int Hd, int ntile, float eps) {
   __shared__ float hid2[128];
   __shared__ float mc[1024];
-  __shared__ float wt[128 * 65];          // (>= 64 * 129)
+  __shared__ float gb[2][64];              // gamma / beta of this workgroup's 64 channels
+  __shared__ float gsum[4][64];
   __shared__ double dred[8];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* st = stats + (size_t)b * C * 4;
@@ -108,44 +114,62 @@ __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict_
   __syncthreads();
   const double var_l = (dred[4] + dred[5] + dred[6] + dred[7]) / (double)C;
   const float mul = (float)mu_l, sig_l = sqrtf((float)var_l + eps);
-  // gamma/beta MLP on the pooled condition: hidden unit hd = relu(b1 + sum over channels IN CHANNEL ORDER) -- one lane walks the
-  // channels of its hidden unit (the order of the reference's matmul row is not defined; this keeps the order of the earlier kernel)
-  // (weight rows go through LDS in 64-column chunks: read coalesced, then each lane walks ITS row -- stride 65: conflict-free)
+  // gamma / beta MLP, layer 1: hidden unit hd = relu(b1 + W1[hd, :] . pooled condition); wave w takes hd = w, w + 4, ...
+  // (four rows x up to 16 column chunks = 64 loads of a lane in flight together: the kernel is a chain of memory round trips otherwise)
+  for (int i0 = 0; wave + 4 * i0 < Hd; i0 += 4) {
+    float v[4][16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hd = wave + 4 * (i0 + u);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[u][q] = (hd < Hd && lane + 64 * q < C) ? mw1[(size_t)hd * C + lane + 64 * q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hd = wave + 4 * (i0 + u);
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a = fmaf(v[u][q], lane + 64 * q < C ? mc[lane + 64 * q] : 0.f, a);
+      a = wave_sum(a);
+      if (lane == 0 && hd < Hd) { a += mb1[hd]; hid2[hd] = a > 0.f ? a : 0.f; }
+    }
+  }
+  __syncthreads();
+  // layer 2: rows [0, C) = gamma, [C, 2C) = beta; the 128 rows of this workgroup's 64 channels, 32 per wave, lanes along the hidden units
+  for (int i0 = 0; i0 < 32; i0 += 16) {               // rows r = wave + 4 i: sixteen rows x two hidden-unit chunks in flight
+    float v[16][2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = wave + 4 * (i0 + u), half = r >> 6, cr = blockIdx.x * 64 + (r & 63);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) v[u][q] = (cr < C && lane + 64 * q < Hd) ? mw2[(size_t)(half * C + cr) * Hd + lane + 64 * q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = wave + 4 * (i0 + u), half = r >> 6, cr = blockIdx.x * 64 + (r & 63);
+      float a = fmaf(v[u][1], lane + 64 < Hd ? hid2[lane + 64] : 0.f, v[u][0] * (lane < Hd ? hid2[lane] : 0.f));
+      a = wave_sum(a);
+      if (lane == 0) gb[half][r & 63] = cr < C ? a + mb2[half * C + cr] : 0.f;
+    }
+  }
+  // the gate's mean over L: group q = wave sums its quarter of the tiles for channel `lane` (coalesced rows of gpart), then q = 0..3 in order
+  const int ch = blockIdx.x * 64 + lane;
   {
-    float a = tid < Hd ? mb1[tid] : 0.f;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      __syncthreads();
-      for (int e = tid; e < Hd * 64; e += 256) {
-        const int hd = e >> 6, cc = e & 63;
-        wt[hd * 65 + cc] = c0 + cc < C ? mw1[(size_t)hd * C + c0 + cc] : 0.f;
-      }
-      __syncthreads();
-      if (tid < Hd) {
-        const int n = min(64, C - c0);
-        for (int cc = 0; cc < n; ++cc) a = fmaf(wt[tid * 65 + cc], mc[c0 + cc], a);
-      }
-    }
-    if (tid < Hd) hid2[tid] = a > 0.f ? a : 0.f;
-  }
-  const int ch = blockIdx.x * 64 + tid;
-  float gam = 0.f, bet = 0.f;
-  for (int half = 0; half < 2; ++half) {              // gamma rows [0, C), beta rows [C, 2C) of the second MLP layer: 64 rows x Hd at a time
-    __syncthreads();
-    for (int e = tid; e < 64 * Hd; e += 256) {
-      const int r = e / Hd, hd = e - r * Hd, cr = blockIdx.x * 64 + r;
-      wt[r * 129 + hd] = cr < C ? mw2[(size_t)(half * C + cr) * Hd + hd] : 0.f;
-    }
-    __syncthreads();
-    if (tid < 64 && ch < C) {
-      float a = mb2[half * C + ch];
-      for (int hd = 0; hd < Hd; ++hd) a = fmaf(wt[tid * 129 + hd], hid2[hd], a);
-      if (half == 0) gam = a; else bet = a;
-    }
-  }
-  if (tid < 64 && ch < C) {
+    const int per = (ntile + 3) / 4, t0 = wave * per, t1 = min(ntile, t0 + per);
     float g = 0.f;
-    for (int t = 0; t < ntile; ++t) g += gpart[((size_t)b * ntile + t) * C + ch];
-    g /= (float)L;
+    for (int tb = t0; tb < t1; tb += 16) {             // sixteen tiles' rows in flight, added in ascending tile order
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (ch < C && tb + u < t1) ? gpart[((size_t)b * ntile + tb + u) * C + ch] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g += v[u];
+    }
+    gsum[wave][lane] = g;
+  }
+  __syncthreads();
+  if (tid < 64 && ch < C) {
+    const float g = (((gsum[0][tid] + gsum[1][tid]) + gsum[2][tid]) + gsum[3][tid]) / (float)L;
+    const float gam = gb[0][tid], bet = gb[1][tid];
     const float mu = g * st[ch * 4] + (1.f - g) * mul;
     const float sig = g * sqrtf(st[ch * 4 + 1] + eps) + (1.f - g) * sig_l;
     const float A = (1.f + gam) / sig;
@@ -217,12 +241,17 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(duan_stats_kernel, dim3(C, B), dim3(256), 0, s, x, c, stats, C, L);
   if (C % 4 == 0 && Hd % 4 == 0 && L % 4 == 0) {
-    // the two 1x1 convolutions of the gate as channel-major fp32 GEMMs on the f32 MFMA (cs3.hip, lx_chan_gemm_f32):
-    // hid = relu(W1 c + b1);  gpart[b][tile][ch] = sum over the tile's positions of sigmoid(W2 hid + b2)
+    // the two 1x1 convolutions of the gate as channel-major GEMMs on the bf16 matrix pipe, every operand a split-bf16 pair (cs3.hip,
+    // lx_chan_gemm_split): hid = relu(W1 c + b1);  gpart[b][tile][ch] = sum over the tile's positions of sigmoid(W2 hid + b2)
     float* hid = (float*)(((uintptr_t)(imp + (size_t)B * C) + 255) & ~(uintptr_t)255);
-    int rc = lx_chan_gemm_f32(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
+    // (2^-16 per product at 16/3 of the exact-fp32 MFMA's rate; the gate feeds a mean over L of sigmoids: the kept-channel sets of the
+    //  goldens and of the full-size case are unchanged. Rounds 2-4 ran two exact-fp32 lx_chan_gemm_f32 launches here: 2 x 150 us, now
+    //  2 x 84 us. A FUSED form -- one workgroup per 128 positions, the hidden layer kept in LDS as bf16 pairs, W1 / W2 staged per
+    //  workgroup -- was built and measured in round 5: 195-242 us per call; its 384 MFMAs per wave are 6 us of a ~100-us workgroup, the
+    //  rest is staging 512 KB of weights and 32 KB of c per workgroup with one workgroup per CU. Not kept.)
+    int rc = lx_chan_gemm_split(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
     if (rc != LX_OK) return rc;
-    rc = lx_chan_gemm_f32(hid, (long)Hd * L, L, gw2, Hd, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
+    rc = lx_chan_gemm_split(hid, (long)Hd * L, L, gw2, Hd, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
     if (rc != LX_OK) return rc;
   } else {
     hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
