@@ -144,16 +144,26 @@ def cpu_baseline(max_threads: int):
                                         "512 text + 256 image + 256 condition tokens, 4 steps, fp32, batch 1"}}
 
 
+GEMM_SOURCES = ("gemm.hip", "gemm_common.h", "gemm8.h", "gemm4.h", "gemm4.hip", "gemm_f16.hip", "gemm4_f16.hip", "gemm_modes.hip", "gemm4_split.hip")
+
+
+def gemm_sources_sha16() -> str:
+    """One hash over every source file the GEMM kernels and their planner are built from (round 5 split gemm.hip into these)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        h.update(open(os.path.join(ROOT, "loongx_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _gemm_traffic_mb(key="b1_hw32"):
     """HBM-side bytes per GEMM launch cannot be observed from inside the process: they come from separate rocprofv3 --pmc passes
     of this workload, summarised by tools/pmc_traffic.py into profiles/pmc_traffic.json together with the hash of the kernel
     source they were measured on. A summary of a different gemm.hip is stale: report null rather than a number that no longer
     describes the kernel."""
-    import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
-        if rec.get("gemm_hip_sha16") != sha:
+        if rec.get("gemm_hip_sha16") != gemm_sources_sha16():       # (key name kept from the one-file days)
             return None, None
         w = rec.get("workloads", {}).get(key)       # per workload: b1_hw32 (headline), b16_hw32 (configs[2]), b4_hw64 (configs[4]'s per-GPU shape), b1_hw32_precise
         if w is not None:
@@ -413,13 +423,11 @@ def run_leg(pw, dev, rank, world, *, B, hw, allmod, mc, precise, steps, warmup, 
         gm, at = s.get("gemm"), s.get("attn")
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         to_image = STEPS / len(ROOFLINE_STEPS)      # bracketed steps -> all steps of one batch
-        traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}" + ("_precise" if precise else ""))
+        traffic, traffic_src = _gemm_traffic_mb(f"b{B}_hw{hw}" + ("_precise" if precise else "_f16" if f16 else ""))
         gname = ("lx_gemm_fp8_kernel (e4m3 32x32x64 f8f6f4 MFMA, fused epilogues)" if gemm_fp8 else
                  "lx_gemm4_kernel<true> / lx_gemm_split_kernel (split-bf16 operands on the bf16 MFMA, 2 K-segments per product: achieved counts ALGORITHMIC flops, the MFMAs do 2x)" if precise else
                  "lx_gemm_* (fp16 MFMA operands: v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fused epilogues; launch-weighted over the 8-wave kernels and lx_gemm4_kernel)" if f16 else
                  "lx_gemm_* (bf16 MFMA, fused epilogues; launch-weighted over the 8-wave 32x32x16 kernels and lx_gemm4_kernel, the one-wave-per-SIMD 16x16x32 form)")
-        if f16:
-            traffic, traffic_src = None, None          # (same bytes by construction -- 16-bit images of the same shapes -- but the committed PMC passes are of the bf16 kernels)
         if gemm_fp8:
             traffic, traffic_src = None, None          # the committed PMC passes are of the bf16 / split-bf16 kernels (the fp8-attention mode runs the bf16 GEMMs)
         res["roofline"] = {"bound": "mfma", "kernel": gname, "achieved": round(ach, 1),

@@ -43,10 +43,22 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   f32x4 v[NCH];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
-    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  for (int i = 0; i < NCH; ++i) v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+  // the modulation rows do not depend on the statistics: their loads go out with the row's (one memory round trip instead of two: the
+  // kernel has 2.5 workgroups per CU at S = 2560 and is bound by its own latency chain, 11.1 us per launch in the step, 76 launches)
+  const int b = rin / rows_per_batch;
+  const float* sh = shift + (size_t)b * mod_ld;
+  const float* sc = scale + (size_t)b * mod_ld;
+  f32x4 av[RQ > 0 ? 1 : NCH], bv[RQ > 0 ? 1 : NCH];
+  if constexpr (RQ == 0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      av[i] = *(const f32x4*)(sc + (i * 64 + lane) * 4);
+      bv[i] = *(const f32x4*)(sh + (i * 64 + lane) * 4);
+    }
   }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
@@ -57,9 +69,6 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
       q += d * d;
     }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-  const int b = rin / rows_per_batch;
-  const float* sh = shift + (size_t)b * mod_ld;
-  const float* sc = scale + (size_t)b * mod_ld;
   uint16_t* yr = Y + (size_t)row * ldy;
   const bool with_lora = RQ > 0 && row >= lo.row0 && row < lo.row0 + lo.rows;      // wave-uniform
   float t[RQ > 0 ? 4 * RQ : 1];
@@ -69,8 +78,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int col = (i * 64 + lane) * 4;
-    const f32x4 a = *(const f32x4*)(sc + col);
-    const f32x4 bsh = *(const f32x4*)(sh + col);
+    f32x4 a, bsh;
+    if constexpr (RQ == 0) { a = av[i]; bsh = bv[i]; }
+    else { a = *(const f32x4*)(sc + col); bsh = *(const f32x4*)(sh + col); }
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mean) * rstd * (1.0f + a[c]) + bsh[c];

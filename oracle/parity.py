@@ -83,7 +83,8 @@ def realistic_stats_(tr, seed: int = 0) -> Dict:
 
 
 def build_pair(device, num_layers: int = 19, num_single_layers: int = 38, heads: int = 24, seed: int = 0, std: float = 0.02,
-               bf16_exact_base: bool = True, joint_dim: int = 4096, pooled_dim: int = 768, precise: bool = False, realistic: bool = False):
+               bf16_exact_base: bool = True, joint_dim: int = 4096, pooled_dim: int = 768, precise: bool = False, realistic: bool = False,
+               engine: bool = True):
     """-> (oracle FluxTransformer2DModel on `device`, LxFluxTransformer packed from ITS state dict).
     realistic: realistic_stats_() on top of the synthetic weights (mixed bounded / max-tracking attention plan, outlier channels, biases)."""
     from loongx_amd.flux.transformer import LxFluxTransformer
@@ -105,11 +106,89 @@ def build_pair(device, num_layers: int = 19, num_single_layers: int = 38, heads:
     if realistic:
         realistic_stats_(tr, seed)
     tr.eval()
+    if not engine:
+        return tr, None
+    return tr, engine_for(tr, device, num_layers, num_single_layers, heads=heads, joint_dim=joint_dim, pooled_dim=pooled_dim, precise=precise)
+
+
+def engine_for(tr, device, num_layers: int = 19, num_single_layers: int = 38, heads: int = 24, joint_dim: int = 4096, pooled_dim: int = 768,
+               precise: bool = False):
+    """The product's transformer packed from the oracle model's state dict (identical weights on both sides)."""
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
     cfg = FluxConfig(num_layers=num_layers, num_single_layers=num_single_layers, num_attention_heads=heads, in_channels=64,
                      joint_attention_dim=joint_dim, pooled_projection_dim=pooled_dim, guidance_embeds=True)
     kw = dict(precise=True) if precise else {}
-    lx = LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, device, **kw)
-    return tr, lx
+    return LxFluxTransformer.from_state_dict(tr.state_dict(), cfg, device, **kw)
+
+
+# The oracle side of a parity run depends on the weights recipe, the shapes and the oracle-relevant model_config -- not on the engine's
+# arithmetic mode. The 13 full-depth parity tests (and bench.py's seven parity legs) share five such combinations: the oracle model and its
+# 28-step trajectory are built once per combination and per process (the fp32 model stays resident: 48 GB of the 288), only the engine side
+# is rebuilt per mode. clear_cache() drops everything.
+_ORACLE_MODELS: Dict = {}
+_TRAJECTORIES: Dict = {}
+_ENGINE_ONLY_KEYS = ("operands", "attn_fp8", "gemm_fp8", "precise")
+
+
+def clear_cache() -> None:
+    _ORACLE_MODELS.clear()
+    _TRAJECTORIES.clear()
+    torch.cuda.empty_cache()
+
+
+def _oracle_model(device, num_layers, num_single_layers, seed, realistic):
+    key = (str(device), num_layers, num_single_layers, seed, bool(realistic))
+    if key not in _ORACLE_MODELS:
+        tr, _ = build_pair(device, num_layers, num_single_layers, seed=seed, realistic=realistic, engine=False)
+        _ORACLE_MODELS[key] = tr
+    return _ORACLE_MODELS[key]
+
+
+@torch.no_grad()
+def _oracle_trajectory(dev, tr, steps, hw, n_txt, seed, brain, omc):
+    """Inputs + the oracle's own denoise trajectory: latents and noise prediction of every step, and the final latents."""
+    N = hw * hw
+    g = torch.Generator(device=dev).manual_seed(4321 + seed)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    lat0, cond, pe, pooled = r(1, N, 64), r(1, N, 64), r(1, n_txt, 4096) * 0.1, r(1, 768)
+    ent = {"lat0": lat0, "cond": cond, "pe_text": pe, "pooled_text": pooled, "signals": {}, "ref_cs3_sd": None}
+    if brain is not None:
+        from . import cs3 as ocs3
+        if brain not in ("eeg", "all"):
+            raise ValueError("brain must be None, 'eeg' or 'all'")
+        torch.manual_seed(seed)
+        ref_cs3 = ocs3.CS3DGF(seed=seed).eval()
+        signals = {"eeg": r(1, 4, 4096)}
+        if brain == "all":
+            signals.update(fnirs=r(1, 6, 512), ppg=r(1, 4, 256), motion=r(1, 6, 128))
+        cpu = {k: v.float().cpu() for k, v in signals.items()}
+        rpe, rpool = ref_cs3.brain_embeds(pe.float().cpu(), pooled.float().cpu(), cpu.get("eeg"), cpu.get("fnirs"), cpu.get("ppg"), cpu.get("motion"),
+                                          fuse_flag=brain == "all", per_stream=True)
+        pe, pooled = rpe.to(dev), rpool.to(dev)                 # what the ORACLE's DiT is conditioned on
+        ent.update(signals=signals, ref_cs3_sd=ref_cs3.state_dict())
+    ids = fm.prepare_latent_image_ids(hw, hw).to(dev)
+    cids = ids.clone()
+    cids[:, 2] -= hw
+    txt_ids = torch.zeros(n_txt, 3, device=dev)
+    guidance = torch.full((1,), 3.5, device=dev)
+    sch = fm.FlowMatchEulerDiscreteScheduler()
+    sig = np.linspace(1.0, 1 / steps, steps)
+    mu = fm.calculate_shift(N, sch.config.base_image_seq_len, sch.config.max_image_seq_len, sch.config.base_shift, sch.config.max_shift)
+    timesteps, _ = fm.retrieve_timesteps(sch, steps, dev, None, sig, mu=mu)
+    lat = lat0.clone()
+    lats, wants, tss = [], [], []
+    torch.cuda.synchronize(dev); t1 = time.time()
+    for i, t in enumerate(timesteps):
+        ts = t.expand(1).to(lat.dtype) / 1000
+        want = fr.tranformer_forward(tr, cond, cids, None, omc, hidden_states=lat, encoder_hidden_states=pe, pooled_projections=pooled, timestep=ts,
+                                     img_ids=ids, txt_ids=txt_ids, guidance=guidance)[0]
+        lats.append(lat.clone()); wants.append(want.clone()); tss.append(ts)
+        lat = sch.step(want, t, lat)[0]
+    torch.cuda.synchronize(dev)
+    ent.update(pe=pe, pooled=pooled, ids=ids, cids=cids, txt_ids=txt_ids, guidance=guidance, lats=lats, wants=wants, tss=tss, final=lat,
+               oracle_s_per_forward=(time.time() - t1) / len(timesteps))
+    return ent
 
 
 @torch.no_grad()
@@ -130,56 +209,34 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
     from loongx_amd.flux.transformer import tranformer_forward
     dev = torch.device(device)
     t0 = time.time()
-    tr, lx = build_pair(dev, num_layers, num_single_layers, seed=seed, precise=precise, realistic=realistic)
     mc = dict(model_config or {"union_cond_attn": True})
+    omc = {k: v for k, v in mc.items() if k not in _ENGINE_ONLY_KEYS}
+    tr = _oracle_model(dev, num_layers, num_single_layers, seed, realistic)
+    tk = (str(dev), num_layers, num_single_layers, seed, bool(realistic), hw, n_txt, steps, brain, tuple(sorted(omc.items())))
+    cached = tk in _TRAJECTORIES
+    if not cached:
+        _TRAJECTORIES[tk] = _oracle_trajectory(dev, tr, steps, hw, n_txt, seed, brain, omc)
+    T = _TRAJECTORIES[tk]
+    lx = engine_for(tr, dev, num_layers, num_single_layers, precise=precise)
     N = hw * hw
-    g = torch.Generator(device=dev).manual_seed(4321 + seed)
-    r = lambda *s: torch.randn(*s, device=dev, generator=g)
-    lat0, cond, pe, pooled = r(1, N, 64), r(1, N, 64), r(1, n_txt, 4096) * 0.1, r(1, 768)
-    signals, model, brain_rec = {}, None, {}
-    pe_text, pooled_text = pe, pooled
+    lat0, cond, pe, pooled, pe_text, pooled_text, signals = T["lat0"], T["cond"], T["pe"], T["pooled"], T["pe_text"], T["pooled_text"], T["signals"]
+    ids, cids, txt_ids, guidance = T["ids"], T["cids"], T["txt_ids"], T["guidance"]
+    model, brain_rec = None, {}
     if brain is not None:
         from loongx_amd.flux.pipeline import LxFluxPipeline as _Pipe
         from loongx_amd.train.model import OminiModel
-        from . import cs3 as ocs3
-        if brain not in ("eeg", "all"):
-            raise ValueError("brain must be None, 'eeg' or 'all'")
-        torch.manual_seed(seed)
-        ref_cs3 = ocs3.CS3DGF(seed=seed).eval()
-        signals = {"eeg": r(1, 4, 4096)}
-        if brain == "all":
-            signals.update(fnirs=r(1, 6, 512), ppg=r(1, 4, 256), motion=r(1, 6, 128))
-        cpu = {k: v.float().cpu() for k, v in signals.items()}
-        rpe, rpool = ref_cs3.brain_embeds(pe.float().cpu(), pooled.float().cpu(), cpu.get("eeg"), cpu.get("fnirs"), cpu.get("ppg"), cpu.get("motion"),
-                                          fuse_flag=brain == "all", per_stream=True)
-        pe, pooled = rpe.to(dev), rpool.to(dev)                 # what the ORACLE's DiT is conditioned on
-        model = OminiModel.from_pipe(_Pipe(lx), ref_cs3.state_dict(), dict(model_config or {"union_cond_attn": True}), dev)
-    ids = fm.prepare_latent_image_ids(hw, hw).to(dev)
-    cids = ids.clone()
-    cids[:, 2] -= hw
-    txt_ids = torch.zeros(n_txt, 3, device=dev)
-    guidance = torch.full((1,), 3.5, device=dev)
+        model = OminiModel.from_pipe(_Pipe(lx), T["ref_cs3_sd"], dict(model_config or {"union_cond_attn": True}), dev)
 
-    # ---- oracle trajectory + teacher-forced engine predictions ------------------------------------------------
-    sch = fm.FlowMatchEulerDiscreteScheduler()
-    sig = np.linspace(1.0, 1 / steps, steps)
-    mu = fm.calculate_shift(N, sch.config.base_image_seq_len, sch.config.max_image_seq_len, sch.config.base_shift, sch.config.max_shift)
-    timesteps, _ = fm.retrieve_timesteps(sch, steps, dev, None, sig, mu=mu)
-    lat = lat0.clone()
+    # ---- teacher-forced engine predictions on the oracle's trajectory ------------------------------------------------
     per_step = []
-    t_oracle = 0.0
-    for i, t in enumerate(timesteps):
-        ts = t.expand(1).to(lat.dtype) / 1000
-        kw = dict(hidden_states=lat, encoder_hidden_states=pe, pooled_projections=pooled, timestep=ts, img_ids=ids, txt_ids=txt_ids,
-                  guidance=guidance)
-        torch.cuda.synchronize(dev); t1 = time.time()
-        want = fr.tranformer_forward(tr, cond, cids, None, mc, **kw)[0]
-        torch.cuda.synchronize(dev); t_oracle += time.time() - t1
-        if i % every == 0 or i == len(timesteps) - 1:
+    for i in range(steps):
+        if i % every == 0 or i == steps - 1:
+            kw = dict(hidden_states=T["lats"][i], encoder_hidden_states=pe, pooled_projections=pooled, timestep=T["tss"][i], img_ids=ids, txt_ids=txt_ids,
+                      guidance=guidance)
             got = tranformer_forward(lx, cond, cids, None, mc, return_dict=False, **kw)[0]
-            per_step.append((i, relerr(got, want)))
-        lat = sch.step(want, t, lat)[0]
-    final_oracle = lat
+            per_step.append((i, relerr(got, T["wants"][i])))
+    final_oracle = T["final"]
+    t_oracle_per_fwd = T["oracle_s_per_forward"]
 
     # ---- free-running product loop ---------------------------------------------------------------------------------
     lx.invalidate_conditioning()
@@ -222,7 +279,8 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
            "noise_pred_relerr_mean": round(float(np.mean(errs)), 6), "noise_pred_relerr_last": round(errs[-1], 6),
            "steps_compared": len(errs),
            "final_latent_relerr": round(relerr(final, final_oracle), 6), "final_latent_cosine": round(cosine(final, final_oracle), 8),
-           "oracle_s_per_forward": round(t_oracle / len(timesteps), 3), "wall_s": round(time.time() - t0, 1)}
+           "oracle_s_per_forward": round(t_oracle_per_fwd, 3), "oracle_trajectory": "cached" if cached else "computed",
+           "wall_s": round(time.time() - t0, 1)}
     rec.update(brain_rec)
     if realistic:
         eng = lx.engine
@@ -231,6 +289,6 @@ def full_depth_parity(device="cuda:0", steps: int = 28, num_layers: int = 19, nu
         rec["weights"] = "realistic_stats_: mixed q/k norm gains, outlier channels, non-zero biases (oracle/parity.py)"
         rec["bounded_score_layers"] = {"bounded": sum(1 for b_ in bounds if b_ <= getattr(eng, "_nomax_room", 100.0)), "layers": len(bounds),
                                        "largest_score_bound_log2": round(max(bounds), 1) if bounds else None}
-    del tr, lx, pipe, model
+    del lx, pipe, model
     torch.cuda.empty_cache()
     return rec

@@ -25,7 +25,9 @@ def per_dispatch(path, counter):
 # an existing pmc_traffic.json to merge the record into (`workloads[key]`); without them the record is the headline's, as before
 f_tot, f_n, f_by = per_dispatch(sys.argv[1], "FETCH_SIZE")
 w_tot, w_n, w_by = per_dispatch(sys.argv[2], "WRITE_SIZE")
-sha = hashlib.sha256(open(os.path.join(ROOT, "loongx_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from bench import gemm_sources_sha16      # one hash over every GEMM source file (gemm.hip, gemm8.h, gemm4.h, ...)
+sha = gemm_sources_sha16()
 mb = (2.0 * f_tot / max(f_n, 1) + w_tot / max(w_n, 1)) * 1024 / 1e6
 if len(sys.argv) > 5:
     rec = json.load(open(sys.argv[5]))
