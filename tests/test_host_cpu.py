@@ -170,3 +170,30 @@ def test_ominimodel_constructor_forms_and_lazy_brain_modules():
     assert m.eeg_projection is not None and m.duan_norm_pooled is not None
     m2 = OminiModel.from_pipe(None, synthetic_cs3_state_dict(0), {}, "cpu")
     assert m2._brain_ready and m2.flux_pipe is None
+
+
+def test_runtime_switches_are_the_documented_fifteen():
+    import os
+    """Every LX_* environment variable the product reads (library: getenv / env_int; Python: os.environ) is a row of INTEGRATION.md's
+    switch table, and there are at most 15 of them: one plan per launch shape is the product, A/B arms live in tools/."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for base, _, files in os.walk(os.path.join(root, "loongx_amd")):
+        if "__pycache__" in base or os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                src = open(os.path.join(base, f)).read()
+                found |= set(re.findall(r'(?:getenv|env_int)\("(LX_[A-Z0-9_]+)"', src))
+            elif f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                found |= set(re.findall(r'environ(?:\.get\(|\[)"(LX_[A-Z0-9_]+)"', src))
+    for f in ("inference.py", "bench.py", "test.py"):
+        found |= set(re.findall(r'environ(?:\.get\(|\[)"(LX_[A-Z0-9_]+)"', open(os.path.join(root, f)).read()))
+    found -= {"LX_DEPTH_MODEL"}                       # a model path, not a switch (documented below the table)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    table = doc[doc.index("## Runtime switches (environment)"):]
+    rows = set(re.findall(r"^\| `(LX_[A-Z0-9_]+)`", table, flags=re.M))
+    assert found == rows, (sorted(found - rows), sorted(rows - found))
+    assert len(found) <= 15, sorted(found)
