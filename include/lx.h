@@ -24,9 +24,18 @@
 extern "C" {
 #endif
 
-#define LX_VERSION 400 /* 0.4.0: fp16 operand format (LX_OPERANDS_F16, lx_gemm_desc.f16_ovf in col_scale's slot, LX_ATTN_O_F16 + lx_attn_desc.f16_ovf appended, + lx_ln_modulate_f16_segs, lx_lora_down_f16, lx_convert dst 2 = fp16); the split-K pair kernel and its area of the workspace are gone (lx_gemm_workspace_bytes() shrank; the error word is still the int 64 ints before the end).
-                          * 0.3.3: 0.3.3: + lx_attn_last_kernel (which attention kernel lx_attn_fwd launched: the one-wave-per-SIMD lx_attn4_kernel serves multi-round bounded-score launches); no layout change. 0.3.2: lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change. 0.3.1: lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED). 0.3.0: lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs,
-                          * lx_attn_fwd_split, lx_lora_down_terms. 0.2.0: caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
+/* ABI history:
+ *  0.4.0  fp16 operand format: LX_OPERANDS_F16 (lx_gemm_desc.f16_ovf in col_scale's slot), LX_ATTN_O_F16, lx_attn_desc.qseg_mask (in the
+ *         padding behind `flags`) + f16_ovf (appended), + lx_ln_modulate_f16_segs, lx_lora_down_f16, lx_convert dst 2 = fp16; the split-K pair
+ *         kernel and its area of the workspace are gone (lx_gemm_workspace_bytes() shrank; the error word is still the int 64 ints before
+ *         the end)
+ *  0.3.3  + lx_attn_last_kernel (which attention kernel lx_attn_fwd launched)
+ *  0.3.2  lx_gemm_workspace_bytes() grew (split-tile slots of lx_gemm4_kernel); no layout change
+ *  0.3.1  lx_attn_desc grew (flags, appended: LX_ATTN_Q_LOG2 / LX_ATTN_BOUNDED)
+ *  0.3.0  lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs, lx_attn_fwd_split,
+ *         lx_lora_down_terms
+ *  0.2.0  caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
+#define LX_VERSION 400
 
 typedef enum lx_status {
   LX_OK = 0,
