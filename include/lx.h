@@ -297,12 +297,15 @@ typedef struct lx_attn_desc {
 /* LX_ATTN_O_F16: O is written as IEEE fp16 (nearest even, saturated to +-65504) instead of bf16: the A operand of an LX_OPERANDS_F16
  * output projection (to_out / proj_out). Q, K and V^T stay bf16 (4e-4 of the per-forward budget, tools/bf16_ablation.py). Also accepted
  * by lx_attn_fwd_fp8 (the only flag it takes). */
-enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4, LX_ATTN_O_F16 = 8 };
+/* LX_ATTN_PREFER_4WAVE: take lx_attn4_kernel whenever the launch fits it (LX_ATTN_BOUNDED, addresses within its 32-bit offsets), whatever
+ * the planner's shape rule says -- for benchmarks and tests of that kernel. LX_ATTN_INVARIANT is the opposite pin (always the 8-wave
+ * kernels); the two together are rejected. */
+enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4, LX_ATTN_O_F16 = 8, LX_ATTN_PREFER_4WAVE = 16 };
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 /* Which kernel the calling thread's last successful lx_attn_fwd launched (a planner decision, exposed for benchmarks and tests):
  * LX_ATTN_KERNEL_8WAVE: the 8-wave kernels of attn.hip (two waves per SIMD, 32 query rows per wave);
  * LX_ATTN_KERNEL_4WAVE: lx_attn4_kernel (attn4.hip: one wave per SIMD, 64 query rows per wave, persistent over query tiles) -- bounded-score
- *   launches of at least two rounds of workgroups with at most 64 key tiles per query tile (LX_ATTN4=1 / 0 in the environment: always / never). */
+ *   launches of at least two rounds of workgroups with at most 64 key tiles per query tile (LX_ATTN_PREFER_4WAVE / LX_ATTN_INVARIANT pin the choice per launch). */
 enum { LX_ATTN_KERNEL_NONE = 0, LX_ATTN_KERNEL_8WAVE = 1, LX_ATTN_KERNEL_4WAVE = 2 };
 int lx_attn_last_kernel(void);
 

@@ -931,20 +931,20 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
   a.qt_start[3] = t;
   const int grid = t * d->B * d->H;
   hipStream_t st = (hipStream_t)stream;
-  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT | LX_ATTN_O_F16)) == 0 && (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)),
-               "lx_attn_fwd: flags=%d: unknown bit, or LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2", d->flags);
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED | LX_ATTN_INVARIANT | LX_ATTN_O_F16 | LX_ATTN_PREFER_4WAVE)) == 0 &&
+                   (!(d->flags & LX_ATTN_BOUNDED) || (d->flags & LX_ATTN_Q_LOG2)) && !((d->flags & LX_ATTN_INVARIANT) && (d->flags & LX_ATTN_PREFER_4WAVE)),
+               "lx_attn_fwd: flags=%d: unknown bit, LX_ATTN_BOUNDED without LX_ATTN_Q_LOG2, or LX_ATTN_INVARIANT with LX_ATTN_PREFER_4WAVE", d->flags);
   bool any_bias = false;                       // a finite non-zero bias on a pair that is attended to
   for (int s = 0; s < d->n_seg; ++s)
     for (int k = 0; k < d->n_seg; ++k) any_bias |= ((qmask >> s) & 1) && d->bias[s][k] > -1e37f && d->bias[s][k] != 0.f;
   static const bool nomax_ok = [] { const char* e = getenv("LX_ATTN_NOMAX"); return e ? atoi(e) != 0 : true; }();
   // lx_attn4_kernel (attn4.hip: one wave per SIMD, every K / V^T fragment feeds two MFMAs, persistent over the query tiles) serves the
   // bounded-score contract; its staging addresses a tile as buffer base + 32-bit byte offsets, so the K column block and the V^T image
-  // have to lie within 2 GiB each. LX_ATTN4 = 0: never, 1: whenever it can, unset: where it measured faster than the 8-wave kernel on
+  // have to lie within 2 GiB each. LX_ATTN_PREFER_4WAVE: whenever it can; LX_ATTN_INVARIANT: never; otherwise where it measured faster than the 8-wave kernel on
   // MI355X (profiles/r04a_attn4_ab.txt): launches of at least two rounds of workgroups whose items are at most 64 key tiles long
   // (B = 16, S = 2560: +1.4 %; 16 x 64 x 2048: +1.7 %) -- one round (B = 1: -2.7 % at S = 2560) and long items (S = 8704: -1.4 %) stay
   // on the 8-wave kernel.
-  static const int attn4_mode = [] { const char* e = getenv("LX_ATTN4"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-  if ((d->flags & LX_ATTN_BOUNDED) && nomax_ok && attn4_mode != 0) {
+  if ((d->flags & LX_ATTN_BOUNDED) && nomax_ok && !(d->flags & LX_ATTN_INVARIANT)) {
     long long max_row = 0, key_tiles = 0;
     for (int s = 0; s < d->n_seg; ++s) {
       max_row = std::max(max_row, (long long)d->seg_row0[s] + (long long)d->B * d->seg_len[s]);
@@ -952,7 +952,7 @@ extern "C" int lx_attn_fwd(const lx_attn_desc* d, void* stream) {
     }
     const bool fits = ((max_row + 64) * (long long)d->ldk + (long long)d->H * 128) * 2 < (1ll << 31) &&
                       ((long long)d->B * d->H + 1) * 128 * d->vt_ld * 2 < (1ll << 31);
-    const bool wanted = attn4_mode == 1 || (!(d->flags & LX_ATTN_INVARIANT) && grid >= 2 * lx_attn4_cus() && key_tiles <= 64);
+    const bool wanted = (d->flags & LX_ATTN_PREFER_4WAVE) || (grid >= 2 * lx_attn4_cus() && key_tiles <= 64);
     if (fits && wanted) {
       lx_attn4_launch(&a, grid, any_bias ? 2 : 1, stream);
       LX_LAUNCH_CHECK("lx_attn_fwd (lx_attn4_kernel)");

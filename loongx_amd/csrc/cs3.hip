@@ -606,6 +606,153 @@ __global__ __launch_bounds__(256) void chan_gemm_split_kernel(const float* __res
   }
 }
 
+
+// ---- the gate's two GEMMs, wide form (round 5) -----------------------------------------------------------------------------------------
+// chan_gemm_split_kernel above re-stages and re-splits the X tile once per 64-row block of N (2 x for the gate's first GEMM, 8 x for the
+// second) and splits its W block in every workgroup: 84 us per launch where the bytes are 40 us' worth. Here a workgroup owns a 64-position
+// tile for ALL of N: X is split once per workgroup (XRES: K <= 128, the whole [K, 64] tile resident in LDS; otherwise one 64-deep chunk
+// at a time), W comes from bf16 hi / lo images split ONCE per call (duan_stats_kernel's first batch row does it on the side) and is read
+// as MFMA fragments straight from global memory -- a lane's 8 consecutive k of its row are 16 contiguous bytes, L2-resident after the
+// first workgroups -- one step (128 rows of N x 64 of K) ahead of its MFMAs. Wave w = rows [g * 128 + 32 w, + 32) of group g, both
+// 32-position halves. Needs N % 128 == 0, K % 64 == 0.
+template <bool XRES>
+__global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __restrict__ X, long x_bstride, int ldx, const uint16_t* __restrict__ Wh,
+                                                             const uint16_t* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y,
+                                                             long y_bstride, int ldy, int N, int K, int L, int epi, float* __restrict__ part) {
+  constexpr int NX = XRES ? 2 : 1;                     // 64-deep chunks of X resident at once
+  __shared__ __attribute__((aligned(16))) uint16_t Xh[NX * 64 * CS_LD], Xl[NX * 64 * CS_LD];
+  const int b = blockIdx.y, l0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const float* Xb = X + (size_t)b * x_bstride;
+  const int nchunk = K / CS_KC, nstep = nchunk * (N / 128);
+  const int xl_s = tid & 63, xk_s = (tid >> 6) * 16;
+  const bool x_ok = l0 + xl_s < L;
+  float xr[16];
+  auto fetch_x = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xr[j] = x_ok ? Xb[(size_t)(k0 + xk_s + j) * ldx + l0 + xl_s] : 0.f;
+  };
+  auto store_x = [&](int slot) {
+    u32x4 h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint16_t a = f32_to_bf16(xr[2 * q]), c = f32_to_bf16(xr[2 * q + 1]);
+      h[q >> 2][q & 3] = (uint32_t)a | ((uint32_t)c << 16);
+      l[q >> 2][q & 3] = pack_bf16x2(xr[2 * q] - bf16_to_f32(a), xr[2 * q + 1] - bf16_to_f32(c));
+    }
+    uint16_t* dh = Xh + slot * 64 * CS_LD + xl_s * CS_LD + xk_s;
+    uint16_t* dl = Xl + slot * 64 * CS_LD + xl_s * CS_LD + xk_s;
+    *(u32x4*)dh = h[0]; *(u32x4*)(dh + 8) = h[1];
+    *(u32x4*)dl = l[0]; *(u32x4*)(dl + 8) = l[1];
+  };
+  // W fragments of step s = (group g = s / nchunk, chunk c = s % nchunk): 4 k-steps x {hi, lo}
+  bf16x8 wa[4][2], wb[4][2];
+  auto fetch_w = [&](int s, bf16x8 (&w)[4][2]) {
+    const int g = s / nchunk, c = s - g * nchunk;
+    const size_t o = (size_t)(g * 128 + wave * 32 + l31) * K + c * CS_KC + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      w[ks][0] = *(const bf16x8*)(Wh + o + ks * 16);
+      w[ks][1] = *(const bf16x8*)(Wl + o + ks * 16);
+    }
+  };
+  f32x16 acc[2];
+  const int l_lo = l0 + l31;                           // this lane's position in half 0; half 1 = + 32
+  float* Yb = Y ? Y + (size_t)b * y_bstride : nullptr;
+  auto finish = [&](int g) {                           // acc[h][r]: n = g*128 + wave*32 + 8*(r/4) + 4*hi + r%4 ; l = l_lo + 32 h
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = g * 128 + wave * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+      const float bv = bias ? bias[n] : 0.f;
+      if (epi == 3) {
+        float v = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (l_lo + 32 * h < L) v += 1.0f / (1.0f + __expf(-(acc[h][r] + bv)));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (l31 == 0) part[((size_t)b * gridDim.x + blockIdx.x) * N + n] = v;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int l = l_lo + 32 * h;
+          if (l >= L) continue;
+          float v = acc[h][r] + bv;
+          float* yp = Yb + (size_t)n * ldy + l;
+          if (epi == 1) v += *yp;
+          else if (epi == 2) v = v > 0.f ? v : 0.f;
+          *yp = v;
+        }
+      }
+    }
+  };
+  auto step = [&](int s, const bf16x8 (&w)[4][2]) {
+    const int g = s / nchunk, c = s - g * nchunk;
+    if (c == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    }
+    const int slot = XRES ? c : 0;
+    const int bo = slot * 64 * CS_LD + l31 * CS_LD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bf16x8 bh = *(const bf16x8*)(Xh + bo + h * 32 * CS_LD + ks * 16), bl = *(const bf16x8*)(Xl + bo + h * 32 * CS_LD + ks * 16);
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0], bl, acc[h], 0, 0, 0);       // small terms first
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][1], bh, acc[h], 0, 0, 0);
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0], bh, acc[h], 0, 0, 0);
+      }
+    }
+    if (c == nchunk - 1) finish(g);
+  };
+  fetch_w(0, wa);
+  if constexpr (XRES) {
+    for (int c = 0; c < nchunk; ++c) { fetch_x(c * CS_KC); store_x(c); }
+    __syncthreads();
+    for (int s = 0; s < nstep; s += 2) {
+      if (s + 1 < nstep) fetch_w(s + 1, wb);
+      step(s, wa);
+      if (s + 1 >= nstep) break;
+      if (s + 2 < nstep) fetch_w(s + 2, wa);
+      step(s + 1, wb);
+    }
+  } else {
+    fetch_x(0);
+    for (int s = 0; s < nstep; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (s + u >= nstep) break;
+        __syncthreads();                                 // the previous chunk's fragments have been read
+        store_x(0);
+        __syncthreads();
+        if (s + u + 1 < nstep) {
+          fetch_x(((s + u + 1) % nchunk) * CS_KC);       // the next chunk's loads fly under this chunk's MFMAs
+          fetch_w(s + u + 1, u == 0 ? wb : wa);
+        }
+        step(s + u, u == 0 ? wa : wb);
+      }
+    }
+  }
+}
+
+// fp32 [n] -> bf16 hi / lo images (x = hi + lo to 2^-17): what chan_gemm_wide_kernel reads as W
+__device__ __forceinline__ void split_bf16_store(const float* __restrict__ src, uint16_t* __restrict__ dh, uint16_t* __restrict__ dl, int i, int n) {
+  if (i >= n) return;
+  const float v = src[i];
+  const uint16_t h = f32_to_bf16(v);
+  dh[i] = h;
+  dl[i] = f32_to_bf16(v - bf16_to_f32(h));
+}
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ a, uint16_t* __restrict__ ah, uint16_t* __restrict__ al, int na,
+                                                         const float* __restrict__ b, uint16_t* __restrict__ bh, uint16_t* __restrict__ bl, int nb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  split_bf16_store(a, ah, al, i, na);
+  split_bf16_store(b, bh, bl, i, nb);
+}
+
 }  // namespace
 
 // internal (dgf.hip): the split-bf16 form of lx_chan_gemm_f32, same arguments and epilogues, relative error ~2^-16 instead of exact fp32 products
@@ -617,6 +764,25 @@ int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, 
   hipLaunchKernelGGL(chan_gemm_split_kernel, dim3((L + 63) / 64, (N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, W, ldw, bias, Y,
                      y_bstride, ldy, N, K, L, epilogue, part);
   LX_LAUNCH_CHECK("lx_chan_gemm_split");
+  return LX_OK;
+}
+
+// internal (dgf.hip): the wide form; Wh / Wl = bf16 hi / lo images of W [N, K] (lx_split_bf16_pair). N % 128 == 0, K % 64 == 0.
+int lx_chan_gemm_wide(const float* X, long x_bstride, int ldx, const uint16_t* Wh, const uint16_t* Wl, const float* bias, float* Y, long y_bstride,
+                      int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream) {
+  LX_CHECK_ARG(X && Wh && Wl && B > 0 && L > 0 && N > 0 && N % 128 == 0 && K > 0 && K % 64 == 0, "lx_chan_gemm_wide: N %% 128, K %% 64 (N=%d K=%d)", N, K);
+  LX_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && (epilogue == 3 ? part != nullptr : Y != nullptr), "lx_chan_gemm_wide: epilogue 0..3 (3 needs part, the others Y)");
+  const dim3 grid((L + 63) / 64, B);
+  if (K <= 128)
+    hipLaunchKernelGGL(chan_gemm_wide_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, Wh, Wl, bias, Y, y_bstride, ldy, N, K, L, epilogue, part);
+  else
+    hipLaunchKernelGGL(chan_gemm_wide_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, Wh, Wl, bias, Y, y_bstride, ldy, N, K, L, epilogue, part);
+  LX_LAUNCH_CHECK("lx_chan_gemm_wide");
+  return LX_OK;
+}
+int lx_split_bf16_pair(const float* a, uint16_t* ah, uint16_t* al, int na, const float* b, uint16_t* bh, uint16_t* bl, int nb, void* stream) {
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((max(na, nb) + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, ah, al, na, b, bh, bl, nb);
+  LX_LAUNCH_CHECK("lx_split_bf16_pair");
   return LX_OK;
 }
 

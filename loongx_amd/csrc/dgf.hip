@@ -9,6 +9,9 @@
 
 int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride, int ldy,
                        int B, int N, int K, int L, int epilogue, float* part, void* stream);       // cs3.hip
+int lx_chan_gemm_wide(const float* X, long x_bstride, int ldx, const uint16_t* Wh, const uint16_t* Wl, const float* bias, float* Y, long y_bstride,
+                      int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream);        // cs3.hip
+int lx_split_bf16_pair(const float* a, uint16_t* ah, uint16_t* al, int na, const float* b, uint16_t* bh, uint16_t* bl, int nb, void* stream);
 
 namespace {
 
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256) void duan_mask_kernel(const float* __restrict_
 extern "C" size_t lx_duan_workspace_bytes(int B, int C, int L, int Hd) {
   const size_t ntile = (size_t)(L + 63) / 64;
   // + the gate network's hidden activations [B, Hd, L] for the MFMA form of the gate (C % 4 == 0)
-  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C + (size_t)B * Hd * L) + 512;
+  // + bf16 hi / lo images of the gate's two weight matrices (the wide GEMM form)
+  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C + (size_t)B * Hd * L) + 8 * (size_t)Hd * C + 1024;
 }
 
 extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, const float* gb1, const float* gw2, const float* gb2,
@@ -249,10 +253,23 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
     //  2 x 84 us. A FUSED form -- one workgroup per 128 positions, the hidden layer kept in LDS as bf16 pairs, W1 / W2 staged per
     //  workgroup -- was built and measured in round 5: 195-242 us per call; its 384 MFMAs per wave are 6 us of a ~100-us workgroup, the
     //  rest is staging 512 KB of weights and 32 KB of c per workgroup with one workgroup per CU. Not kept.)
-    int rc = lx_chan_gemm_split(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
-    if (rc != LX_OK) return rc;
-    rc = lx_chan_gemm_split(hid, (long)Hd * L, L, gw2, Hd, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
-    if (rc != LX_OK) return rc;
+    int rc;
+    if (Hd % 128 == 0 && C % 128 == 0 && Hd % 64 == 0) {
+      // wide form (cs3.hip): a workgroup per 64 positions and ALL output rows, X split once per workgroup, W from images split once per call
+      uint16_t* w1h = (uint16_t*)(((uintptr_t)(hid + (size_t)B * Hd * L) + 255) & ~(uintptr_t)255);
+      uint16_t *w1l = w1h + (size_t)Hd * C, *w2h = w1l + (size_t)Hd * C, *w2l = w2h + (size_t)Hd * C;
+      rc = lx_split_bf16_pair(gw1, w1h, w1l, Hd * C, gw2, w2h, w2l, Hd * C, stream);
+      if (rc != LX_OK) return rc;
+      rc = lx_chan_gemm_wide(c, (long)C * L, L, w1h, w1l, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
+      if (rc != LX_OK) return rc;
+      rc = lx_chan_gemm_wide(hid, (long)Hd * L, L, w2h, w2l, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
+      if (rc != LX_OK) return rc;
+    } else {
+      rc = lx_chan_gemm_split(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
+      if (rc != LX_OK) return rc;
+      rc = lx_chan_gemm_split(hid, (long)Hd * L, L, gw2, Hd, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
+      if (rc != LX_OK) return rc;
+    }
   } else {
     hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
   }

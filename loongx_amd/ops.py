@@ -336,7 +336,7 @@ def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt
     return d
 
 
-ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16 = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT, L.LX_ATTN_O_F16
+ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16, ATTN_PREFER_4WAVE = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT, L.LX_ATTN_O_F16, L.LX_ATTN_PREFER_4WAVE
 Q_LOG2_FACTOR = (1.0 / math.sqrt(128.0)) * 1.4426950408889634       # what LX_ATTN_Q_LOG2 expects q to carry already
 
 

@@ -191,9 +191,7 @@ def test_attention_output_as_fp16(ops, kernel):
             ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
             ops.attn_fwd(buf, buf, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0,
                          flags=ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED | (ops.ATTN_O_F16 if f16 else 0), f16_ovf=ovf if f16 else None)
-            import os
-            if os.environ.get("LX_ATTN4") is None:
-                assert ops.lib.lx_attn_last_kernel() == 2          # LX_ATTN_KERNEL_4WAVE
+            assert ops.lib.lx_attn_last_kernel() == 2              # LX_ATTN_KERNEL_4WAVE
             outs[f16] = O.float().cpu()
             assert int(ovf) == 0
         e = relerr(outs[True], outs[False])

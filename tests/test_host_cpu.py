@@ -172,7 +172,7 @@ def test_ominimodel_constructor_forms_and_lazy_brain_modules():
     assert m2._brain_ready and m2.flux_pipe is None
 
 
-def test_runtime_switches_are_the_documented_fifteen():
+def test_runtime_switches_are_the_documented_ones():
     import os
     """Every LX_* environment variable the product reads (library: getenv / env_int; Python: os.environ) is a row of INTEGRATION.md's
     switch table, and there are at most 15 of them: one plan per launch shape is the product, A/B arms live in tools/."""

@@ -797,24 +797,30 @@ def test_attention_segments(ops, lens, mode):
     assert torch.equal(buf[:, : 2 * D], orig[:, : 2 * D])   # K and V columns untouched
 
 
+@pytest.mark.parametrize("kernel", ["max_tracking", "bounded_8wave", "bounded_4wave"])
 @pytest.mark.parametrize("mask", [0b010, 0b101, 0b100])
-def test_attention_query_segment_mask(ops, mask):
+def test_attention_query_segment_mask(ops, mask, kernel):
     """lx_attn_desc.qseg_mask: any subset of the segments has queries (the last single block of a forward: image rows only). The rows of
-    the chosen segments equal the full launch's bit for bit; the other segments' O rows are not written."""
+    the chosen segments equal the full launch's bit for bit; the other segments' O rows are not written. All three kernel families."""
     lens = (64, 128, 200)
     B, H = 2, 3
     D = H * 128
     buf = _qkv_buffer(B, lens, H, seed=5)
     row0, vt0, vt_len = _segments(B, lens)
     VT = torch.zeros(B, H, 128, vt_len, dtype=torch.bfloat16, device=DEV)
+    one = torch.ones(128, device=DEV)
     for s_, Ls in enumerate(lens):
-        ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=row0[s_], n_rows=B * Ls, rows_per_batch=Ls, H=H, wq=None, wk=None,
+        ops.qkv_prep(buf, q_col=2 * D, k_col=0, v_col=D, row0=row0[s_], n_rows=B * Ls, rows_per_batch=Ls, H=H,
+                     wq=None if kernel == "max_tracking" else one * ops.Q_LOG2_FACTOR, wk=None if kernel == "max_tracking" else one,
                      cos=None, sin=None, VT=VT, vt_pos0=vt0[s_])
-    kw = dict(q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=BIASES["cfactor"])
+    flags = {"max_tracking": 0, "bounded_8wave": ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED | ops.ATTN_INVARIANT,
+             "bounded_4wave": ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED | ops.ATTN_PREFER_4WAVE}[kernel]
+    kw = dict(q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=BIASES["cfactor"], flags=flags)
     full = torch.full((buf.shape[0], D), 7.0, dtype=torch.bfloat16, device=DEV)
     part = torch.full((buf.shape[0], D), 7.0, dtype=torch.bfloat16, device=DEV)
     ops.attn_fwd(buf, buf, VT, full, **kw)
     ops.attn_fwd(buf, buf, VT, part, qseg_mask=mask, **kw)
+    assert ops.lib.lx_attn_last_kernel() == (2 if kernel == "bounded_4wave" else 1)
     for s_, Ls in enumerate(lens):
         rows = slice(row0[s_], row0[s_] + B * Ls)
         if (mask >> s_) & 1:
@@ -840,12 +846,14 @@ def test_attention_single_segment_spike(ops):
     assert relerr(buf.float().cpu()[:, 2 * D:].view(1, Ls, 1, 128), ref) < 6e-3
 
 
+@pytest.mark.parametrize("pin", ["8wave", "4wave"])
 @pytest.mark.parametrize("mode", ["none", "cfactor", "independent"])
 @pytest.mark.parametrize("lens,gain", [((16, 16, 16), 1.0), ((64, 128, 200), 2.2), ((512, 1024, 1024), 1.5)])
-def test_attention_bounded_scores(ops, lens, gain, mode):
+def test_attention_bounded_scores(ops, lens, gain, mode, pin):
     """LX_ATTN_Q_LOG2 | LX_ATTN_BOUNDED (include/lx.h): q RMS-normalised with scale * log2 e folded into norm_q, no running maximum in
     the kernel. gain = max|norm_q| = max|norm_k|: 16.33 * 2.2^2 = 79 (+ |log 0.5| * 1.45) is close to the bound of 100 the caller
-    must keep. Checked against fp32 SDPA on the same (prepped) q / k / v and against the max-tracking kernel on the same buffer."""
+    must keep. Checked against fp32 SDPA on the same (prepped) q / k / v and against the max-tracking kernel on the same buffer, on both
+    bounded-score kernels (these small launches are one round: the planner alone would never hand them to lx_attn4_kernel)."""
     B, H = (1, 2) if lens[0] == 512 else (2, 3)
     D = H * 128
     buf = _qkv_buffer(B, lens, H, seed=11)
@@ -862,7 +870,8 @@ def test_attention_bounded_scores(ops, lens, gain, mode):
     prepped = buf.clone()
     bias = BIASES[mode]
     kw = dict(q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, bias=bias)
-    ops.attn_fwd(buf, buf, VT, buf, flags=ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED, **kw)
+    ops.attn_fwd(buf, buf, VT, buf, flags=ops.ATTN_Q_LOG2 | ops.ATTN_BOUNDED | (ops.ATTN_PREFER_4WAVE if pin == "4wave" else 0), **kw)
+    assert ops.lib.lx_attn_last_kernel() == (2 if pin == "4wave" else 1)
     tracked = prepped.clone()
     ops.attn_fwd(tracked, tracked, VT, tracked, flags=ops.ATTN_Q_LOG2, **kw)
     refbuf = prepped.float()

@@ -131,11 +131,13 @@ def test_full_depth_parity_fp8_attention_512(brain):
 
 
 def test_full_depth_parity_fp8_attention_1024():
-    """The shape configs[4] names: 1024x1024 (S = 8704), teacher-forced comparison at every 7th step + the free-running loop."""
+    """The shape configs[4] names: 1024x1024 (S = 8704), all 57 blocks, on an 8-step schedule (an fp32 oracle forward at this size is
+    1.5 s on the GPU: the 28-step run of the same comparison is the `configs4_b4_attnfp8` leg of the bench line -- 6.5e-3 / 6.7e-3 / 1.4e-3 --
+    and was this test until round 5, 47 s of the suite): teacher-forced comparison at every 2nd step + the free-running loop."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle.parity import full_depth_parity
-    rec = full_depth_parity("cuda:0", steps=28, every=7, hw=64, model_config={"union_cond_attn": True, "attn_fp8": True})
+    rec = full_depth_parity("cuda:0", steps=8, every=2, hw=64, model_config={"union_cond_attn": True, "attn_fp8": True})
     print("PARITY_FP8ATTN_1024 " + json.dumps(rec))
     assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= 1.2e-2, rec
     assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT, rec
