@@ -107,6 +107,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the 32 lanes of each half wave (lanes 0-31 / 32-63) without touching LDS: quad, half-row and row mirrors, then lane 15 of rows
+// 0 / 2 into rows 1 / 3 (DPP row_bcast:15). The totals stand in lanes 16-31 and 48-63. (__shfl_xor is ds_bpermute: five dependent LDS
+// round trips per value -- 80 per 32 x 32 block of sigmoids, which is where the gate's second GEMM spent most of its time.)
+__device__ __forceinline__ float half_wave_sum_hi16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
+  return v;
+}
+// the sum over all 64 lanes as a wave-uniform value: the half-wave sums above, lane 31's into rows 2 / 3 (row_bcast:31), lane 63 read back
+// through an SGPR. Seven dependent vector instructions against wave_sum's six ds_bpermute round trips (another summation tree: results
+// differ from wave_sum's in the last bit).
+__device__ __forceinline__ float wave_total(float v) {
+  v = half_wave_sum_hi16(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -615,38 +615,44 @@ __global__ __launch_bounds__(256) void chan_gemm_split_kernel(const float* __res
 // as MFMA fragments straight from global memory -- a lane's 8 consecutive k of its row are 16 contiguous bytes, L2-resident after the
 // first workgroups -- one step (128 rows of N x 64 of K) ahead of its MFMAs. Wave w = rows [g * 128 + 32 w, + 32) of group g, both
 // 32-position halves. Needs N % 128 == 0, K % 64 == 0.
-template <bool XRES>
+template <bool XRES, int EPI, int LT>
 __global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __restrict__ X, long x_bstride, int ldx, const uint16_t* __restrict__ Wh,
                                                              const uint16_t* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y,
-                                                             long y_bstride, int ldy, int N, int K, int L, int epi, float* __restrict__ part) {
+                                                             long y_bstride, int ldy, int N, int K, int L, float* __restrict__ part,
+                                                             float* __restrict__ xsum) {
+  // A workgroup owns 64 * LT positions (LT = 2 halves the L2 traffic of the W fragments, which every workgroup reads in full).
+  // xsum (!XRES only; may be null): [B][L tiles][K] sums of X over this workgroup's positions, per k -- the DUAN's mean of its condition
+  // per channel falls out of the gate's first GEMM, which reads every element of it anyway (duan_stats_kernel then reads x alone)
   constexpr int NX = XRES ? 2 : 1;                     // 64-deep chunks of X resident at once
-  __shared__ __attribute__((aligned(16))) uint16_t Xh[NX * 64 * CS_LD], Xl[NX * 64 * CS_LD];
-  const int b = blockIdx.y, l0 = blockIdx.x * 64;
+  __shared__ __attribute__((aligned(16))) uint16_t Xh[NX * LT * 64 * CS_LD], Xl[NX * LT * 64 * CS_LD];
+  const int b = blockIdx.y, l0 = blockIdx.x * (64 * LT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const float* Xb = X + (size_t)b * x_bstride;
   const int nchunk = K / CS_KC, nstep = nchunk * (N / 128);
   const int xl_s = tid & 63, xk_s = (tid >> 6) * 16;
-  const bool x_ok = l0 + xl_s < L;
-  float xr[16];
-  auto fetch_x = [&](int k0) {
+  auto fetch_x = [&](int k0, float (&xr)[LT][16]) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xr[j] = x_ok ? Xb[(size_t)(k0 + xk_s + j) * ldx + l0 + xl_s] : 0.f;
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xr[t][j] = l0 + t * 64 + xl_s < L ? Xb[(size_t)(k0 + xk_s + j) * ldx + l0 + t * 64 + xl_s] : 0.f;
   };
-  auto store_x = [&](int slot) {
-    u32x4 h[2], l[2];
+  auto store_x = [&](int slot, const float (&xr)[LT][16]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint16_t a = f32_to_bf16(xr[2 * q]), c = f32_to_bf16(xr[2 * q + 1]);
-      h[q >> 2][q & 3] = (uint32_t)a | ((uint32_t)c << 16);
-      l[q >> 2][q & 3] = pack_bf16x2(xr[2 * q] - bf16_to_f32(a), xr[2 * q + 1] - bf16_to_f32(c));
+    for (int t = 0; t < LT; ++t) {
+      u32x4 h[2], l[2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint16_t a = f32_to_bf16(xr[t][2 * q]), c = f32_to_bf16(xr[t][2 * q + 1]);
+        h[q >> 2][q & 3] = (uint32_t)a | ((uint32_t)c << 16);
+        l[q >> 2][q & 3] = pack_bf16x2(xr[t][2 * q] - bf16_to_f32(a), xr[t][2 * q + 1] - bf16_to_f32(c));
+      }
+      uint16_t* dh = Xh + ((slot * LT + t) * 64 + xl_s) * CS_LD + xk_s;
+      uint16_t* dl = Xl + ((slot * LT + t) * 64 + xl_s) * CS_LD + xk_s;
+      *(u32x4*)dh = h[0]; *(u32x4*)(dh + 8) = h[1];
+      *(u32x4*)dl = l[0]; *(u32x4*)(dl + 8) = l[1];
     }
-    uint16_t* dh = Xh + slot * 64 * CS_LD + xl_s * CS_LD + xk_s;
-    uint16_t* dl = Xl + slot * 64 * CS_LD + xl_s * CS_LD + xk_s;
-    *(u32x4*)dh = h[0]; *(u32x4*)(dh + 8) = h[1];
-    *(u32x4*)dl = l[0]; *(u32x4*)(dl + 8) = l[1];
   };
   // W fragments of step s = (group g = s / nchunk, chunk c = s % nchunk): 4 k-steps x {hi, lo}
-  bf16x8 wa[4][2], wb[4][2];
   auto fetch_w = [&](int s, bf16x8 (&w)[4][2]) {
     const int g = s / nchunk, c = s - g * nchunk;
     const size_t o = (size_t)(g * 128 + wave * 32 + l31) * K + c * CS_KC + hi * 8;
@@ -656,85 +662,106 @@ __global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __rest
       w[ks][1] = *(const bf16x8*)(Wl + o + ks * 16);
     }
   };
-  f32x16 acc[2];
-  const int l_lo = l0 + l31;                           // this lane's position in half 0; half 1 = + 32
+  f32x16 acc[2 * LT];
+  const int l_lo = l0 + l31;                           // this lane's position in 32-position block 0; block h = + 32 h
   float* Yb = Y ? Y + (size_t)b * y_bstride : nullptr;
-  auto finish = [&](int g) {                           // acc[h][r]: n = g*128 + wave*32 + 8*(r/4) + 4*hi + r%4 ; l = l_lo + 32 h
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = g * 128 + wave * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-      const float bv = bias ? bias[n] : 0.f;
-      if (epi == 3) {
-        float v = 0.f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          if (l_lo + 32 * h < L) v += 1.0f / (1.0f + __expf(-(acc[h][r] + bv)));
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (l31 == 0) part[((size_t)b * gridDim.x + blockIdx.x) * N + n] = v;
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int l = l_lo + 32 * h;
-          if (l >= L) continue;
-          float v = acc[h][r] + bv;
-          float* yp = Yb + (size_t)n * ldy + l;
-          if (epi == 1) v += *yp;
-          else if (epi == 2) v = v > 0.f ? v : 0.f;
-          *yp = v;
-        }
-      }
-    }
-  };
-  auto step = [&](int s, const bf16x8 (&w)[4][2]) {
+  bf16x8 wa[4][2], wb[4][2];
+  float xr[LT][16];
+  fetch_w(0, wa);
+  if constexpr (XRES) {
+    float xr2[LT][16];
+    fetch_x(0, xr);
+    if (nchunk > 1) fetch_x(CS_KC, xr2);
+    store_x(0, xr);
+    if (nchunk > 1) store_x(1, xr2);
+    __syncthreads();
+  } else {
+    fetch_x(0, xr);
+  }
+  auto do_step = [&](const int s, bf16x8 (&wc)[4][2], bf16x8 (&wn)[4][2]) {
     const int g = s / nchunk, c = s - g * nchunk;
+    if constexpr (!XRES) {
+      __syncthreads();                                 // the previous chunk's fragments have been read
+      store_x(0, xr);
+      if (xsum && g == 0) {                            // (out-of-range positions were loaded as 0)
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float v = xr[0][j];
+          if constexpr (LT == 2) v += xr[1][j];
+          const float tot = wave_total(v);
+          mine = lane == j ? tot : mine;
+        }
+        if (lane < 16) xsum[((size_t)b * gridDim.x + blockIdx.x) * K + c * CS_KC + xk_s + lane] = mine;
+      }
+      __syncthreads();
+      if (s + 1 < nstep) fetch_x(((s + 1) % nchunk) * CS_KC, xr);     // the next chunk's loads fly under this chunk's MFMAs
+    }
+    if (s + 1 < nstep) fetch_w(s + 1, wn);
     if (c == 0) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2 * LT; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
     }
-    const int slot = XRES ? c : 0;
-    const int bo = slot * 64 * CS_LD + l31 * CS_LD + hi * 8;
+    const int bo = (XRES ? c : 0) * (LT * 64) * CS_LD + l31 * CS_LD + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 2 * LT; ++h) {
         const bf16x8 bh = *(const bf16x8*)(Xh + bo + h * 32 * CS_LD + ks * 16), bl = *(const bf16x8*)(Xl + bo + h * 32 * CS_LD + ks * 16);
-        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0], bl, acc[h], 0, 0, 0);       // small terms first
-        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][1], bh, acc[h], 0, 0, 0);
-        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0], bh, acc[h], 0, 0, 0);
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], bl, acc[h], 0, 0, 0);       // small terms first
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], bh, acc[h], 0, 0, 0);
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], bh, acc[h], 0, 0, 0);
       }
     }
-    if (c == nchunk - 1) finish(g);
-  };
-  fetch_w(0, wa);
-  if constexpr (XRES) {
-    for (int c = 0; c < nchunk; ++c) { fetch_x(c * CS_KC); store_x(c); }
-    __syncthreads();
-    for (int s = 0; s < nstep; s += 2) {
-      if (s + 1 < nstep) fetch_w(s + 1, wb);
-      step(s, wa);
-      if (s + 1 >= nstep) break;
-      if (s + 2 < nstep) fetch_w(s + 2, wa);
-      step(s + 1, wb);
-    }
-  } else {
-    fetch_x(0);
-    for (int s = 0; s < nstep; s += 2) {
+    if (c == nchunk - 1) {
+      // acc[h][r]: n = nb + 8*(r/4) + 4*hi + r%4 ; l = l_lo + 32 h
+      const int nb = g * 128 + wave * 32;
+      f32x4 bv[4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (s + u >= nstep) break;
-        __syncthreads();                                 // the previous chunk's fragments have been read
-        store_x(0);
-        __syncthreads();
-        if (s + u + 1 < nstep) {
-          fetch_x(((s + u + 1) % nchunk) * CS_KC);       // the next chunk's loads fly under this chunk's MFMAs
-          fetch_w(s + u + 1, u == 0 ? wb : wa);
+      for (int q = 0; q < 4; ++q) bv[q] = bias ? *(const f32x4*)(bias + nb + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (EPI == 3) {
+        float sg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bb = bv[r >> 2][r & 3];
+          float t = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2 * LT; ++h) {
+            const float sv = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[h][r] + bb)));
+            t += l_lo + 32 * h < L ? sv : 0.f;
+          }
+          sg[r] = t;
         }
-        step(s + u, u == 0 ? wa : wb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sg[r] = half_wave_sum_hi16(sg[r]);
+        if (l31 == 16) {
+          float* pp = part + ((size_t)b * gridDim.x + blockIdx.x) * N + nb + 4 * hi;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)(pp + 8 * q) = f32x4{sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]};
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2 * LT; ++h) {
+          const int l = l_lo + 32 * h;
+          if (l < L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[h][r] + bv[r >> 2][r & 3];
+              float* yp = Yb + (size_t)(nb + 8 * (r >> 2) + 4 * hi + (r & 3)) * ldy + l;
+              if constexpr (EPI == 1) v += *yp;
+              if constexpr (EPI == 2) v = v > 0.f ? v : 0.f;
+              *yp = v;
+            }
+          }
+        }
       }
     }
+  };
+  for (int s = 0; s < nstep; s += 2) {                 // fragment registers ping-pong: no copy (a copy would wait for the X loads in flight too)
+    do_step(s, wa, wb);
+    if (s + 1 < nstep) do_step(s + 1, wb, wa);
   }
 }
 
@@ -768,15 +795,32 @@ int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, 
 }
 
 // internal (dgf.hip): the wide form; Wh / Wl = bf16 hi / lo images of W [N, K] (lx_split_bf16_pair). N % 128 == 0, K % 64 == 0.
+// xsum: null, or [B][ceil(L / tile)][K] per-tile sums of X over the positions (K > 128 only); part rows likewise per `tile` positions.
+// positions per workgroup for the resident-X form (K <= 128; = the tile the `part` rows are sums over): 128 when that still leaves two
+// workgroups per CU -- half the L2 traffic of the W fragments (57 -> 46 us on the gate's second GEMM). The streaming form (K > 128) is
+// better off with 64: at 128 its 280 registers leave one wave per SIMD to hide the HBM latency of X (65 -> 70 us).
+int lx_chan_gemm_wide_tile(int B, int L) { return (long)B * ((L + 127) / 128) >= 512 ? 128 : 64; }
 int lx_chan_gemm_wide(const float* X, long x_bstride, int ldx, const uint16_t* Wh, const uint16_t* Wl, const float* bias, float* Y, long y_bstride,
-                      int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream) {
+                      int ldy, int B, int N, int K, int L, int epilogue, float* part, float* xsum, int tile, void* stream) {
+  LX_CHECK_ARG(tile == 64 || tile == 128, "lx_chan_gemm_wide: tile = 64 or 128 positions per workgroup");
+  LX_CHECK_ARG(!xsum || K > 128, "lx_chan_gemm_wide: xsum needs the streaming form (K > 128)");
   LX_CHECK_ARG(X && Wh && Wl && B > 0 && L > 0 && N > 0 && N % 128 == 0 && K > 0 && K % 64 == 0, "lx_chan_gemm_wide: N %% 128, K %% 64 (N=%d K=%d)", N, K);
   LX_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && (epilogue == 3 ? part != nullptr : Y != nullptr), "lx_chan_gemm_wide: epilogue 0..3 (3 needs part, the others Y)");
-  const dim3 grid((L + 63) / 64, B);
-  if (K <= 128)
-    hipLaunchKernelGGL(chan_gemm_wide_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, Wh, Wl, bias, Y, y_bstride, ldy, N, K, L, epilogue, part);
-  else
-    hipLaunchKernelGGL(chan_gemm_wide_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, x_bstride, ldx, Wh, Wl, bias, Y, y_bstride, ldy, N, K, L, epilogue, part);
+  LX_CHECK_ARG(N % 4 == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && (epilogue != 3 || ((uintptr_t)part & 15) == 0), "lx_chan_gemm_wide: bias / part must be 16-byte aligned");
+  const int lt = tile / 64;
+  const dim3 grid((L + 64 * lt - 1) / (64 * lt), B);
+  hipStream_t st = (hipStream_t)stream;
+#define LX_WIDE3(XR, EP, LT_) hipLaunchKernelGGL((chan_gemm_wide_kernel<XR, EP, LT_>), grid, dim3(256), 0, st, X, x_bstride, ldx, Wh, Wl, bias, Y, y_bstride, ldy, N, K, L, part, xsum)
+#define LX_WIDE(XR, EP) do { if (lt == 2) LX_WIDE3(XR, EP, 2); else LX_WIDE3(XR, EP, 1); } while (0)
+  const bool xres = K <= 128;
+  switch (epilogue) {
+    case 0: if (xres) LX_WIDE(true, 0); else LX_WIDE(false, 0); break;
+    case 1: if (xres) LX_WIDE(true, 1); else LX_WIDE(false, 1); break;
+    case 2: if (xres) LX_WIDE(true, 2); else LX_WIDE(false, 2); break;
+    default: if (xres) LX_WIDE(true, 3); else LX_WIDE(false, 3); break;
+  }
+#undef LX_WIDE3
+#undef LX_WIDE
   LX_LAUNCH_CHECK("lx_chan_gemm_wide");
   return LX_OK;
 }

@@ -10,7 +10,8 @@
 int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, int ldw, const float* bias, float* Y, long y_bstride, int ldy,
                        int B, int N, int K, int L, int epilogue, float* part, void* stream);       // cs3.hip
 int lx_chan_gemm_wide(const float* X, long x_bstride, int ldx, const uint16_t* Wh, const uint16_t* Wl, const float* bias, float* Y, long y_bstride,
-                      int ldy, int B, int N, int K, int L, int epilogue, float* part, void* stream);        // cs3.hip
+                      int ldy, int B, int N, int K, int L, int epilogue, float* part, float* xsum, int tile, void* stream);        // cs3.hip
+int lx_chan_gemm_wide_tile(int B, int L);
 int lx_split_bf16_pair(const float* a, uint16_t* ah, uint16_t* al, int na, const float* b, uint16_t* bh, uint16_t* bl, int nb, void* stream);
 
 namespace {
@@ -23,23 +24,57 @@ __device__ __forceinline__ float block_sum(float v, float* red) {  // 256 thread
   return red[0] + red[1] + red[2] + red[3];
 }
 
+template <bool WITH_C>
 __global__ __launch_bounds__(256) void duan_stats_kernel(const float* __restrict__ x, const float* __restrict__ c,
                                                          float* __restrict__ stats, int C, int L) {
+  // WITH_C = false: the condition's per-channel mean comes out of the gate's first GEMM as per-tile sums (cpart); this kernel reads x alone.
+  // Rows of up to 4096 elements (L % 4 == 0, 16-byte aligned) are held in registers: one pass over memory, all loads in flight at once,
+  // the variance from the registers (same two-pass arithmetic: mean first, then squared deviations).
   __shared__ float red[4];
   const int row = blockIdx.y * C + blockIdx.x;
   const float* xr = x + (size_t)row * L;
   const float* cr = c + (size_t)row * L;
-  float sx = 0.f, sc = 0.f;
-  for (int i = threadIdx.x; i < L; i += 256) { sx += xr[i]; sc += cr[i]; }
-  const float mx = block_sum(sx, red) / (float)L;
-  const float mc = block_sum(sc, red) / (float)L;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < L; i += 256) { const float d = xr[i] - mx; q += d * d; }
-  const float var = block_sum(q, red) / (float)L;
+  float sx = 0.f, sc = 0.f, mx, var;
+  if (L <= 4096 && (L & 3) == 0 && (((uintptr_t)xr | (uintptr_t)cr) & 15) == 0) {
+    f32x4 xv[4], cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = (u * 256 + threadIdx.x) * 4;
+      xv[u] = i < L ? *(const f32x4*)(xr + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (WITH_C) cv[u] = i < L ? *(const f32x4*)(cr + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sx += (xv[u][0] + xv[u][1]) + (xv[u][2] + xv[u][3]);
+      if constexpr (WITH_C) sc += (cv[u][0] + cv[u][1]) + (cv[u][2] + cv[u][3]);
+    }
+    mx = block_sum(sx, red) / (float)L;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = (u * 256 + threadIdx.x) * 4;
+      if (i < L) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[u][e] - mx; q += d * d; }
+      }
+    }
+    var = block_sum(q, red) / (float)L;
+  } else {
+    for (int i = threadIdx.x; i < L; i += 256) {
+      sx += xr[i];
+      if constexpr (WITH_C) sc += cr[i];
+    }
+    mx = block_sum(sx, red) / (float)L;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) { const float d = xr[i] - mx; q += d * d; }
+    var = block_sum(q, red) / (float)L;
+  }
+  float mc = 0.f;
+  if constexpr (WITH_C) mc = block_sum(sc, red) / (float)L;
   if (threadIdx.x == 0) {
     stats[(size_t)row * 4 + 0] = mx;
     stats[(size_t)row * 4 + 1] = var;
-    stats[(size_t)row * 4 + 2] = mc;
+    if constexpr (WITH_C) stats[(size_t)row * 4 + 2] = mc;
   }
 }
 
@@ -92,9 +127,10 @@ __global__ __launch_bounds__(256) void duan_gate_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gpart,
                                                         const float* __restrict__ mw1, const float* __restrict__ mb1,
                                                         const float* __restrict__ mw2, const float* __restrict__ mb2,
-                                                        float* __restrict__ coef, int C, int L, int Hd, int ntile, float eps) {
+                                                        float* __restrict__ coef, int C, int L, int Hd, int ntile, float eps,
+                                                        const float* __restrict__ cpart, int nctile) {
   __shared__ float hid2[128];
-  __shared__ float mc[1024];
+  __shared__ __attribute__((aligned(16))) float mc[1024];
   __shared__ float gb[2][64];              // gamma / beta of this workgroup's 64 channels
   __shared__ float gsum[4][64];
   __shared__ double dred[8];
@@ -102,7 +138,22 @@ __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict_
   const float* st = stats + (size_t)b * C * 4;
   // layer statistics over (C, L): combine per-row (mean, var) exactly in fp64
   double sm = 0.0;
-  for (int ch = tid; ch < C; ch += 256) { sm += (double)st[ch * 4]; mc[ch] = st[ch * 4 + 2]; }
+  for (int ch = tid; ch < C; ch += 256) {
+    sm += (double)st[ch * 4];
+    if (cpart) {                                       // the condition's mean from the gate GEMM's per-tile sums, ascending tile order
+      float a = 0.f;
+      for (int tb = 0; tb < nctile; tb += 64) {         // 64 tiles' rows in flight: the kernel is a chain of memory round trips
+        float v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = tb + u < nctile ? cpart[((size_t)b * nctile + tb + u) * C + ch] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) a += v[u];
+      }
+      mc[ch] = a / (float)L;
+    } else {
+      mc[ch] = st[ch * 4 + 2];
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
   if (lane == 0) dred[wave] = sm;
   __syncthreads();
@@ -119,6 +170,34 @@ __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict_
   const float mul = (float)mu_l, sig_l = sqrtf((float)var_l + eps);
   // gamma / beta MLP, layer 1: hidden unit hd = relu(b1 + W1[hd, :] . pooled condition); wave w takes hd = w, w + 4, ...
   // (four rows x up to 16 column chunks = 64 loads of a lane in flight together: the kernel is a chain of memory round trips otherwise)
+  if ((C & 255) == 0 && (((uintptr_t)mw1) & 15) == 0) {
+    // rows of C = 256 q floats: q 16-byte loads per lane and row; eight rows (<= 32 loads) in flight per batch
+    const int nq = C >> 8;                              // <= 4 (C <= 1024)
+    for (int i0 = 0; wave + 4 * i0 < Hd; i0 += 8) {
+      f32x4 v[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int hd = wave + 4 * (i0 + u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          v[u][q] = (hd < Hd && q < nq) ? *(const f32x4*)(mw1 + (size_t)hd * C + (q * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int hd = wave + 4 * (i0 + u);
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < nq) {
+            const f32x4 m = *(const f32x4*)(mc + (q * 64 + lane) * 4);
+            a = fmaf(v[u][q][0], m[0], a); a = fmaf(v[u][q][1], m[1], a); a = fmaf(v[u][q][2], m[2], a); a = fmaf(v[u][q][3], m[3], a);
+          }
+        }
+        a = wave_total(a);
+        if (lane == 0 && hd < Hd) { a += mb1[hd]; hid2[hd] = a > 0.f ? a : 0.f; }
+      }
+    }
+  } else {
   for (int i0 = 0; wave + 4 * i0 < Hd; i0 += 4) {
     float v[4][16];
 #pragma unroll
@@ -133,25 +212,26 @@ __global__ __launch_bounds__(256) void duan_coef_kernel(const float* __restrict_
       float a = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) a = fmaf(v[u][q], lane + 64 * q < C ? mc[lane + 64 * q] : 0.f, a);
-      a = wave_sum(a);
+      a = wave_total(a);
       if (lane == 0 && hd < Hd) { a += mb1[hd]; hid2[hd] = a > 0.f ? a : 0.f; }
     }
   }
+  }
   __syncthreads();
   // layer 2: rows [0, C) = gamma, [C, 2C) = beta; the 128 rows of this workgroup's 64 channels, 32 per wave, lanes along the hidden units
-  for (int i0 = 0; i0 < 32; i0 += 16) {               // rows r = wave + 4 i: sixteen rows x two hidden-unit chunks in flight
-    float v[16][2];
+  for (int i0 = 0; i0 < 32; i0 += 32) {               // rows r = wave + 4 i: thirty-two rows x two hidden-unit chunks in flight
+    float v[32][2];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int r = wave + 4 * (i0 + u), half = r >> 6, cr = blockIdx.x * 64 + (r & 63);
 #pragma unroll
       for (int q = 0; q < 2; ++q) v[u][q] = (cr < C && lane + 64 * q < Hd) ? mw2[(size_t)(half * C + cr) * Hd + lane + 64 * q] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int r = wave + 4 * (i0 + u), half = r >> 6, cr = blockIdx.x * 64 + (r & 63);
       float a = fmaf(v[u][1], lane + 64 < Hd ? hid2[lane + 64] : 0.f, v[u][0] * (lane < Hd ? hid2[lane] : 0.f));
-      a = wave_sum(a);
+      a = wave_total(a);
       if (lane == 0) gb[half][r & 63] = cr < C ? a + mb2[half * C + cr] : 0.f;
     }
   }
@@ -226,8 +306,8 @@ __global__ __launch_bounds__(256) void duan_mask_kernel(const float* __restrict_
 extern "C" size_t lx_duan_workspace_bytes(int B, int C, int L, int Hd) {
   const size_t ntile = (size_t)(L + 63) / 64;
   // + the gate network's hidden activations [B, Hd, L] for the MFMA form of the gate (C % 4 == 0)
-  // + bf16 hi / lo images of the gate's two weight matrices (the wide GEMM form)
-  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C + (size_t)B * Hd * L) + 8 * (size_t)Hd * C + 1024;
+  // + bf16 hi / lo images of the gate's two weight matrices and the condition's per-tile channel sums (the wide GEMM form)
+  return sizeof(float) * ((size_t)B * C * 4 + (size_t)B * ntile * C + (size_t)B * C * 2 + (size_t)B * C + (size_t)B * Hd * L + (size_t)B * ntile * C) + 8 * (size_t)Hd * C + 2048;
 }
 
 extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, const float* gb1, const float* gw2, const float* gb2,
@@ -237,32 +317,39 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   LX_CHECK_ARG(B > 0 && C > 0 && C <= 1024 && L > 0 && Hd > 0 && Hd <= 128, "lx_duan_fwd: need C <= 1024 and hidden_dim <= 128 (C=%d Hd=%d)", C, Hd);
   LX_CHECK_ARG(keep_k >= 1 && keep_k <= C, "lx_duan_fwd: keep_k=%d out of [1,%d]", keep_k, C);
   LX_CHECK_ARG(ws_bytes >= lx_duan_workspace_bytes(B, C, L, Hd), "lx_duan_fwd: workspace too small");
-  const int ntile = (L + 63) / 64;
+  const bool mfma_gate = C % 4 == 0 && Hd % 4 == 0 && L % 4 == 0;
+  const bool wide = mfma_gate && Hd % 128 == 0 && C % 128 == 0 && C > 128 && (((uintptr_t)gb1 | (uintptr_t)gb2) & 15) == 0;
+  const int tile = wide ? lx_chan_gemm_wide_tile(B, L) : 64;      // positions per row of gpart (cpart: 64)
+  const int ntile = (L + tile - 1) / tile, nctile = (L + 63) / 64;
   float* stats = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   float* gpart = stats + (size_t)B * C * 4;
   float* coef = gpart + (size_t)B * ntile * C;
   float* imp = coef + (size_t)B * C * 2;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(duan_stats_kernel, dim3(C, B), dim3(256), 0, s, x, c, stats, C, L);
-  if (C % 4 == 0 && Hd % 4 == 0 && L % 4 == 0) {
-    // the two 1x1 convolutions of the gate as channel-major GEMMs on the bf16 matrix pipe, every operand a split-bf16 pair (cs3.hip,
-    // lx_chan_gemm_split): hid = relu(W1 c + b1);  gpart[b][tile][ch] = sum over the tile's positions of sigmoid(W2 hid + b2)
+  float* cpart = nullptr;
+  if (wide) hipLaunchKernelGGL(duan_stats_kernel<false>, dim3(C, B), dim3(256), 0, s, x, c, stats, C, L);
+  else hipLaunchKernelGGL(duan_stats_kernel<true>, dim3(C, B), dim3(256), 0, s, x, c, stats, C, L);
+  if (mfma_gate) {
+    // the two 1x1 convolutions of the gate as channel-major GEMMs on the bf16 matrix pipe, every operand a split-bf16 pair (cs3.hip):
+    // hid = relu(W1 c + b1);  gpart[b][tile][ch] = sum over the tile's positions of sigmoid(W2 hid + b2)
     float* hid = (float*)(((uintptr_t)(imp + (size_t)B * C) + 255) & ~(uintptr_t)255);
     // (2^-16 per product at 16/3 of the exact-fp32 MFMA's rate; the gate feeds a mean over L of sigmoids: the kept-channel sets of the
-    //  goldens and of the full-size case are unchanged. Rounds 2-4 ran two exact-fp32 lx_chan_gemm_f32 launches here: 2 x 150 us, now
-    //  2 x 84 us. A FUSED form -- one workgroup per 128 positions, the hidden layer kept in LDS as bf16 pairs, W1 / W2 staged per
-    //  workgroup -- was built and measured in round 5: 195-242 us per call; its 384 MFMAs per wave are 6 us of a ~100-us workgroup, the
-    //  rest is staging 512 KB of weights and 32 KB of c per workgroup with one workgroup per CU. Not kept.)
+    //  goldens and of the full-size case are unchanged. Rounds 2-4 ran two exact-fp32 lx_chan_gemm_f32 launches here: 2 x 150 us; the
+    //  split-bf16 tile kernel 2 x 84 us; the wide form below 52 + 57 us. A FUSED form -- one workgroup per 128 positions, the hidden layer
+    //  kept in LDS as bf16 pairs, W1 / W2 staged per workgroup -- was built and measured in round 5: 195-242 us per call; its 384 MFMAs per
+    //  wave are 6 us of a ~100-us workgroup, the rest is staging 512 KB of weights and 32 KB of c per workgroup with one workgroup per CU.)
     int rc;
-    if (Hd % 128 == 0 && C % 128 == 0 && Hd % 64 == 0) {
-      // wide form (cs3.hip): a workgroup per 64 positions and ALL output rows, X split once per workgroup, W from images split once per call
-      uint16_t* w1h = (uint16_t*)(((uintptr_t)(hid + (size_t)B * Hd * L) + 255) & ~(uintptr_t)255);
+    if (wide) {
+      // wide form: a workgroup per 64 positions and ALL output rows, X split once per workgroup, W from images split once per call;
+      // the first GEMM also leaves the condition's per-tile channel sums (its mean over L is what the gamma / beta MLP takes)
+      cpart = (float*)(((uintptr_t)(hid + (size_t)B * Hd * L) + 255) & ~(uintptr_t)255);
+      uint16_t* w1h = (uint16_t*)(((uintptr_t)(cpart + (size_t)B * nctile * C) + 255) & ~(uintptr_t)255);
       uint16_t *w1l = w1h + (size_t)Hd * C, *w2h = w1l + (size_t)Hd * C, *w2l = w2h + (size_t)Hd * C;
       rc = lx_split_bf16_pair(gw1, w1h, w1l, Hd * C, gw2, w2h, w2l, Hd * C, stream);
       if (rc != LX_OK) return rc;
-      rc = lx_chan_gemm_wide(c, (long)C * L, L, w1h, w1l, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
+      rc = lx_chan_gemm_wide(c, (long)C * L, L, w1h, w1l, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, cpart, 64, stream);
       if (rc != LX_OK) return rc;
-      rc = lx_chan_gemm_wide(hid, (long)Hd * L, L, w2h, w2l, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, stream);
+      rc = lx_chan_gemm_wide(hid, (long)Hd * L, L, w2h, w2l, gb2, nullptr, 0, 0, B, C, Hd, L, 3, gpart, nullptr, tile, stream);
       if (rc != LX_OK) return rc;
     } else {
       rc = lx_chan_gemm_split(c, (long)C * L, L, gw1, C, gb1, hid, (long)Hd * L, L, B, Hd, C, L, 2, nullptr, stream);
@@ -273,7 +360,7 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   } else {
     hipLaunchKernelGGL(duan_gate_kernel, dim3(ntile, B), dim3(256), 0, s, c, gw1, gb1, gw2, gb2, gpart, C, L, Hd, ntile);
   }
-  hipLaunchKernelGGL(duan_coef_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, stats, gpart, mw1, mb1, mw2, mb2, coef, C, L, Hd, ntile, eps);
+  hipLaunchKernelGGL(duan_coef_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, stats, gpart, mw1, mb1, mw2, mb2, coef, C, L, Hd, ntile, eps, cpart, nctile);
   hipLaunchKernelGGL(duan_apply_kernel, dim3(C, B), dim3(256), 0, s, x, coef, y, imp, C, L);
   hipLaunchKernelGGL(duan_mask_kernel, dim3(C, B), dim3(256), 0, s, imp, y, C, L, keep_k);
   LX_LAUNCH_CHECK("lx_duan_fwd");
