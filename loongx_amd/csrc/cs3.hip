@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __rest
                                                              long y_bstride, int ldy, int N, int K, int L, float* __restrict__ part,
                                                              float* __restrict__ xsum) {
   // A workgroup owns 64 * LT positions (LT = 2 halves the L2 traffic of the W fragments, which every workgroup reads in full).
-  // xsum (!XRES only; may be null): [B][L tiles][K] sums of X over this workgroup's positions, per k -- the DUAN's mean of its condition
+  // xsum (!XRES only; may be null): [B][ceil(L / 64)][K] sums of X over each 64 positions, per k -- the DUAN's mean of its condition
   // per channel falls out of the gate's first GEMM, which reads every element of it anyway (duan_stats_kernel then reads x alone)
   constexpr int NX = XRES ? 2 : 1;                     // 64-deep chunks of X resident at once
   __shared__ __attribute__((aligned(16))) uint16_t Xh[NX * LT * 64 * CS_LD], Xl[NX * LT * 64 * CS_LD];
@@ -684,15 +684,16 @@ __global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __rest
       __syncthreads();                                 // the previous chunk's fragments have been read
       store_x(0, xr);
       if (xsum && g == 0) {                            // (out-of-range positions were loaded as 0)
-        float mine = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float v = xr[0][j];
-          if constexpr (LT == 2) v += xr[1][j];
-          const float tot = wave_total(v);
-          mine = lane == j ? tot : mine;
+        for (int t = 0; t < LT; ++t) {                  // one row per 64 positions, as for `part`
+          float mine = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float tot = wave_total(xr[t][j]);
+            mine = lane == j ? tot : mine;
+          }
+          if (lane < 16 && l0 + 64 * t < L) xsum[((size_t)b * ((L + 63) / 64) + blockIdx.x * LT + t) * K + c * CS_KC + xk_s + lane] = mine;
         }
-        if (lane < 16) xsum[((size_t)b * gridDim.x + blockIdx.x) * K + c * CS_KC + xk_s + lane] = mine;
       }
       __syncthreads();
       if (s + 1 < nstep) fetch_x(((s + 1) % nchunk) * CS_KC, xr);     // the next chunk's loads fly under this chunk's MFMAs
@@ -722,24 +723,24 @@ __global__ __launch_bounds__(256) void chan_gemm_wide_kernel(const float* __rest
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = bias ? *(const f32x4*)(bias + nb + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (EPI == 3) {
-        float sg[16];
+        // one row of `part` per 64 positions whatever LT is, summed in the same order: the result does not depend on the tile a launch
+        // shape chose (a data-parallel shard of another batch size reproduces the full batch bit for bit)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float bb = bv[r >> 2][r & 3];
-          float t = 0.f;
+        for (int t = 0; t < LT; ++t) {
+          float sg[16];
 #pragma unroll
-          for (int h = 0; h < 2 * LT; ++h) {
-            const float sv = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[h][r] + bb)));
-            t += l_lo + 32 * h < L ? sv : 0.f;
+          for (int r = 0; r < 16; ++r) {
+            const float bb = bv[r >> 2][r & 3];
+            const float s0 = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[2 * t][r] + bb))), s1 = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[2 * t + 1][r] + bb)));
+            sg[r] = (l_lo + 64 * t < L ? s0 : 0.f) + (l_lo + 64 * t + 32 < L ? s1 : 0.f);
           }
-          sg[r] = t;
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sg[r] = half_wave_sum_hi16(sg[r]);
-        if (l31 == 16) {
-          float* pp = part + ((size_t)b * gridDim.x + blockIdx.x) * N + nb + 4 * hi;
+          for (int r = 0; r < 16; ++r) sg[r] = half_wave_sum_hi16(sg[r]);
+          if (l31 == 16 && l0 + 64 * t < L) {
+            float* pp = part + ((size_t)b * ((L + 63) / 64) + blockIdx.x * LT + t) * N + nb + 4 * hi;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)(pp + 8 * q) = f32x4{sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]};
+            for (int q = 0; q < 4; ++q) *(f32x4*)(pp + 8 * q) = f32x4{sg[4 * q], sg[4 * q + 1], sg[4 * q + 2], sg[4 * q + 3]};
+          }
         }
       } else {
 #pragma unroll
@@ -795,7 +796,7 @@ int lx_chan_gemm_split(const float* X, long x_bstride, int ldx, const float* W, 
 }
 
 // internal (dgf.hip): the wide form; Wh / Wl = bf16 hi / lo images of W [N, K] (lx_split_bf16_pair). N % 128 == 0, K % 64 == 0.
-// xsum: null, or [B][ceil(L / tile)][K] per-tile sums of X over the positions (K > 128 only); part rows likewise per `tile` positions.
+// xsum: null, or [B][ceil(L / 64)][K] sums of X over each 64 positions (K > 128 only); part rows likewise per 64 positions, whatever `tile`.
 // positions per workgroup for the resident-X form (K <= 128; = the tile the `part` rows are sums over): 128 when that still leaves two
 // workgroups per CU -- half the L2 traffic of the W fragments (57 -> 46 us on the gate's second GEMM). The streaming form (K > 128) is
 // better off with 64: at 128 its 280 registers leave one wave per SIMD to hide the HBM latency of X (65 -> 70 us).

@@ -319,8 +319,8 @@ extern "C" int lx_duan_fwd(const float* x, const float* c, const float* gw1, con
   LX_CHECK_ARG(ws_bytes >= lx_duan_workspace_bytes(B, C, L, Hd), "lx_duan_fwd: workspace too small");
   const bool mfma_gate = C % 4 == 0 && Hd % 4 == 0 && L % 4 == 0;
   const bool wide = mfma_gate && Hd % 128 == 0 && C % 128 == 0 && C > 128 && (((uintptr_t)gb1 | (uintptr_t)gb2) & 15) == 0;
-  const int tile = wide ? lx_chan_gemm_wide_tile(B, L) : 64;      // positions per row of gpart (cpart: 64)
-  const int ntile = (L + tile - 1) / tile, nctile = (L + 63) / 64;
+  const int tile = wide ? lx_chan_gemm_wide_tile(B, L) : 64;      // positions per workgroup of the gate's second GEMM (a launch-shape choice:
+  const int ntile = (L + 63) / 64, nctile = ntile;                //  gpart / cpart hold one row per 64 positions either way)
   float* stats = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   float* gpart = stats + (size_t)B * C * 4;
   float* coef = gpart + (size_t)B * ntile * C;
