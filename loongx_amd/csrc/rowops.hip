@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = wave_total(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
       const float d = v[i][c] - mean;
       q += d * d;
     }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = rsqrtf(wave_total(q) / (float)D + eps);
   uint16_t* yr = Y + (size_t)row * ldy;
   const bool with_lora = RQ > 0 && row >= lo.row0 && row < lo.row0 + lo.rows;      // wave-uniform
   float t[RQ > 0 ? 4 * RQ : 1];
