@@ -25,6 +25,8 @@ extern "C" {
 #endif
 
 /* ABI history:
+ *  0.4.1  + lx_ln_modulate_lora_f16_segs; lx_ln_modulate_lora_segs computes its down-projection on the matrix pipe (Adown 16-byte aligned);
+ *         + LX_ATTN_PREFER_4WAVE
  *  0.4.0  fp16 operand format: LX_OPERANDS_F16 (lx_gemm_desc.f16_ovf in col_scale's slot), LX_ATTN_O_F16, lx_attn_desc.qseg_mask (in the
  *         padding behind `flags`) + f16_ovf (appended), + lx_ln_modulate_f16_segs, lx_lora_down_f16, lx_convert dst 2 = fp16; the split-K pair
  *         kernel and its area of the workspace are gone (lx_gemm_workspace_bytes() shrank; the error word is still the int 64 ints before
@@ -35,7 +37,7 @@ extern "C" {
  *  0.3.0  lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs, lx_attn_fwd_split,
  *         lx_lora_down_terms
  *  0.2.0  caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
-#define LX_VERSION 400
+#define LX_VERSION 401
 
 typedef enum lx_status {
   LX_OK = 0,
@@ -234,6 +236,10 @@ int lx_ln_modulate_f16_segs(const float* X, int ldx, const lx_ln_seg* seg, int n
  * second pass over the rows (block.py:24, 299: the q/k/v(/proj_mlp) adapters read the AdaLN-normalised stream). D = 3072 | 256. */
 int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
                              float eps, const void* Adown, int R, float* T, int ldt, int lora_row0, int lora_rows, void* stream);
+/* lx_ln_modulate_lora_segs with fp16 operand images: Y as in lx_ln_modulate_f16_segs, Adown the fp16 image lx_lora_down_f16 takes */
+int lx_ln_modulate_lora_f16_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                                 float eps, const void* Adown, int R, float* T, int ldt, int lora_row0, int lora_rows,
+                                 int32_t* f16_ovf, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-head RMSNorm (weight, eps) + interleaved-pair RoPE on Q and K, in place, and V transposed into the

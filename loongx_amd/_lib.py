@@ -90,6 +90,7 @@ _SIGS = {
     "lx_ln_modulate_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P]),
     "lx_ln_modulate_f16_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _P]),
     "lx_ln_modulate_lora_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
+    "lx_ln_modulate_lora_f16_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P, _P]),
     "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),

@@ -17,24 +17,48 @@ struct LnSegs {   // up to 3 row segments (token streams), each with its own mod
   const float* scale[3];
 };
 
-// RQ > 0: the rows [lora_row0, lora_row0 + lora_rows) (the streams that run with the adapter on) also get their LoRA down-projection
-// T[row - lora_row0, 0..R) = Y_row(bf16) . Adown[R, D]^T (R <= 4 RQ) while the normalised row is still in registers: the separate
-// lx_lora_down launch over the same rows (7 us, 57 per denoise step) disappears. Same operands as that kernel (the bf16-rounded row,
-// bf16 Adown), fp32 accumulation in a different order.
+// LM (round 5): the rows [lora_row0, lora_row0 + lora_rows) (the streams that run with the adapter on) also get their LoRA down-projection
+// T[row - lora_row0, 0..R) = Y_row . Adown[R, D]^T (R <= 16) on the matrix pipe while the workgroup's four normalised rows are at hand:
+// the rows go to LDS as the 16-bit operand images they are stored as, Adown is the MFMA "A" operand (rows = r), the four rows the "B"
+// operand (columns m = 0..3 of 16, the others zero), the four waves split K and add their partial tiles through LDS -- the same operands
+// and instruction as lora_down_mfma_kernel, another split of K (results agree to fp32 summation order). The separate lx_lora_down
+// launch over the same rows (6.7 us, 76 of the 132 per denoise step sit behind a LayerNorm) disappears; workgroups without adapter rows
+// take the plain path (the decision is workgroup-uniform). Rounds 2-4 had a vector-ALU form of this (576-768 FMAs and 12-16 ds_bpermute
+// wave reductions per row): 1.1 % slower per image than the separate launches, never enabled.
 struct LnLora { const uint16_t* A; float* T; int R, ldt, row0, rows; };
 
 // F16: Y is the fp16 operand image of an LX_OPERANDS_F16 GEMM (nearest even, saturated to +-65504; *f16_ovf counts the waves that clipped).
-template <int NCH, int RQ = 0, bool F16 = false>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
+template <int NCH, bool LM = false, bool F16 = false>  // D = NCH*256: lane owns float4 chunks lane, lane+64, ...
+__global__ __launch_bounds__(256, 3) void ln_modulate_kernel(const float* __restrict__ X, int ldx, const LnSegs segs, int mod_ld,
                                                           uint16_t* __restrict__ Y, int ldy, int M, int D, float eps, const LnLora lo = LnLora{},
                                                           int* __restrict__ f16_ovf = nullptr) {
-  static_assert(!(F16 && RQ > 0), "the fused adapter down-projection reads its own bf16 rounding");
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  int sg = 0, acc_rows = 0;
-  while (sg < segs.n - 1 && row >= acc_rows + segs.n_rows[sg]) { acc_rows += segs.n_rows[sg]; ++sg; }
-  const int rin = row - acc_rows;
-  row = segs.row0[sg] + rin;
+  constexpr int RS = NCH * 256 + 32;                    // LDS row stride (elements): + 64 B, so the four rows' fragments fall on distinct banks
+  __shared__ __attribute__((aligned(16))) uint16_t rows_s[LM ? 4 * RS : 8];
+  __shared__ f32x4 red_s[LM ? 4 * 64 : 1];
+  const int wave = threadIdx.x >> 6;
+  const int row_l = blockIdx.x * 4 + wave;              // row in launch order
+  if constexpr (!LM) {
+    if (row_l >= M) return;
+  }
+  const bool valid = row_l < M;
+  auto phys = [&](int rl, int& sg_o, int& rin_o) {      // launch-order row -> (segment, row in segment) -> physical row
+    int sg = 0, acc_rows = 0;
+    while (sg < segs.n - 1 && rl >= acc_rows + segs.n_rows[sg]) { acc_rows += segs.n_rows[sg]; ++sg; }
+    sg_o = sg; rin_o = rl - acc_rows;
+    return segs.row0[sg] + rin_o;
+  };
+  int sg, rin;
+  const int row = phys(min(row_l, M - 1), sg, rin);
+  bool wg_lora = false;                                 // workgroup-uniform: one of its four rows runs the adapter
+  if constexpr (LM) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int rl = blockIdx.x * 4 + w;
+      int s2, r2;
+      const int pr = phys(min(rl, M - 1), s2, r2);
+      wg_lora |= rl < M && pr >= lo.row0 && pr < lo.row0 + lo.rows;
+    }
+  }
   const float* shift = segs.shift[sg];
   const float* scale = segs.scale[sg];
   const int rows_per_batch = segs.rows_per_batch[sg];
@@ -45,18 +69,19 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < NCH; ++i) v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
   // the modulation rows do not depend on the statistics: their loads go out with the row's (one memory round trip instead of two: the
-  // kernel has 2.5 workgroups per CU at S = 2560 and is bound by its own latency chain, 11.1 us per launch in the step, 76 launches)
+  // kernel has 2.5 workgroups per CU at S = 2560 and is bound by its own latency chain, 11 us per launch in the step, 76 launches)
   const int b = rin / rows_per_batch;
   const float* sh = shift + (size_t)b * mod_ld;
   const float* sc = scale + (size_t)b * mod_ld;
-  f32x4 av[RQ > 0 ? 1 : NCH], bv[RQ > 0 ? 1 : NCH];
-  if constexpr (RQ == 0) {
+  f32x4 av[NCH], bv[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      av[i] = *(const f32x4*)(sc + (i * 64 + lane) * 4);
-      bv[i] = *(const f32x4*)(sh + (i * 64 + lane) * 4);
-    }
+  for (int i = 0; i < NCH; ++i) {
+    av[i] = *(const f32x4*)(sc + (i * 64 + lane) * 4);
+    bv[i] = *(const f32x4*)(sh + (i * 64 + lane) * 4);
   }
+  // (hipcc sinks most of these loads below the first reduction again -- 144 registers of loads in flight do not fit the 168 that three
+  //  waves per SIMD allow without spilling; pinning them with an empty asm was tried: 2-19 spilled registers per variant. What reaches
+  //  the memory system early is what fits.)
 #pragma unroll
   for (int i = 0; i < NCH; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float mean = wave_total(s) / (float)D;
@@ -70,50 +95,60 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     }
   const float rstd = rsqrtf(wave_total(q) / (float)D + eps);
   uint16_t* yr = Y + (size_t)row * ldy;
-  const bool with_lora = RQ > 0 && row >= lo.row0 && row < lo.row0 + lo.rows;      // wave-uniform
-  float t[RQ > 0 ? 4 * RQ : 1];
   float f16_mx = 0.f;
-#pragma unroll
-  for (int j = 0; j < (RQ > 0 ? 4 * RQ : 1); ++j) t[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int col = (i * 64 + lane) * 4;
-    f32x4 a, bsh;
-    if constexpr (RQ == 0) { a = av[i]; bsh = bv[i]; }
-    else { a = *(const f32x4*)(sc + col); bsh = *(const f32x4*)(sh + col); }
     float o[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mean) * rstd * (1.0f + a[c]) + bsh[c];
+    for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mean) * rstd * (1.0f + av[i][c]) + bv[i][c];
     u32x2 w;
     w[0] = pack_op16x2<F16>(o[0], o[1], f16_mx);
     w[1] = pack_op16x2<F16>(o[2], o[3], f16_mx);
-    *(u32x2*)(yr + col) = w;
-    if constexpr (RQ > 0) {
-      if (with_lora) {
-        const float y0 = __uint_as_float(w[0] << 16), y1 = __uint_as_float(w[0] & 0xffff0000u);
-        const float y2 = __uint_as_float(w[1] << 16), y3 = __uint_as_float(w[1] & 0xffff0000u);
-        u32x2 ar[4 * RQ];
-#pragma unroll
-        for (int j = 0; j < 4 * RQ; ++j) ar[j] = *(const u32x2*)(lo.A + (size_t)min(j, lo.R - 1) * D + col);
-#pragma unroll
-        for (int j = 0; j < 4 * RQ; ++j) {
-          t[j] = __builtin_fmaf(y0, __uint_as_float(ar[j][0] << 16), t[j]);
-          t[j] = __builtin_fmaf(y1, __uint_as_float(ar[j][0] & 0xffff0000u), t[j]);
-          t[j] = __builtin_fmaf(y2, __uint_as_float(ar[j][1] << 16), t[j]);
-          t[j] = __builtin_fmaf(y3, __uint_as_float(ar[j][1] & 0xffff0000u), t[j]);
-        }
-      }
+    if (valid) *(u32x2*)(yr + col) = w;
+    if constexpr (LM) {
+      if (wg_lora) *(u32x2*)(rows_s + wave * RS + col) = w;
     }
   }
-  if constexpr (RQ > 0) {
-    if (with_lora) {
+  if constexpr (LM) {
+    if (wg_lora) {
+      // K = NCH * 256 in 32-deep MFMA steps; wave w takes steps w, w + 4, ... (2 NCH of them). Adown fragments straight from global
+      // memory (L2-resident: every workgroup of the launch reads the same R rows), all in flight before the barrier.
+      constexpr int NS = 2 * NCH, NB = NS >= 8 ? NS / 2 : NS;     // two batches of fragments: 176 registers (one batch) would leave two waves
+      const int l15 = lane & 15, kq = lane >> 4;                  // per SIMD, and the launch is 2.5 workgroups per CU: a second round
+      const uint16_t* ap = lo.A + (size_t)min(l15, lo.R - 1) * D + kq * 8;
+      __builtin_amdgcn_sched_barrier(0);          // (hipcc would hoist these loads above the row's arithmetic: 176 registers again)
+      bf16x8 af[NB];
 #pragma unroll
-      for (int j = 0; j < 4 * RQ; ++j) t[j] = wave_sum(t[j]);
-      if (lane == 0) {
-        float* tp = lo.T + (size_t)(row - lo.row0) * lo.ldt;
+      for (int u = 0; u < NB; ++u) af[u] = *(const bf16x8*)(ap + (4 * u + wave) * 32);
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const uint16_t* xp = rows_s + (l15 & 3) * RS + kq * 8;
+      const bf16x8 zero = {};
 #pragma unroll
-        for (int j = 0; j < 4 * RQ; ++j)
-          if (j < lo.R) tp[j] = t[j];
+      for (int u0 = 0; u0 < NS; u0 += NB) {
+        if (u0 > 0) {
+#pragma unroll
+          for (int u = 0; u < NB; ++u) af[u] = *(const bf16x8*)(ap + (4 * (u0 + u) + wave) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          bf16x8 xf = *(const bf16x8*)(xp + (4 * (u0 + u) + wave) * 32);
+          xf = l15 < 4 ? xf : zero;
+          if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[u]), __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], xf, acc, 0, 0, 0);
+        }
+      }
+      red_s[wave * 64 + lane] = acc;                  // acc[j]: r = 4 kq + j, row m = l15 (< 4 are real)
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int m = threadIdx.x >> 4, r = threadIdx.x & 15;
+        const float* rp = (const float*)red_s + (m + 16 * (r >> 2)) * 4 + (r & 3);
+        const float t = ((rp[0] + rp[256]) + rp[512]) + rp[768];
+        const int rl = blockIdx.x * 4 + m;
+        int s2, r2;
+        const int pr = phys(min(rl, M - 1), s2, r2);
+        if (rl < M && r < lo.R && pr >= lo.row0 && pr < lo.row0 + lo.rows) lo.T[(size_t)(pr - lo.row0) * lo.ldt + r] = t;
       }
     }
   }
@@ -631,18 +666,20 @@ static int ln_launch(const float* X, int ldx, const LnSegs& segs, int mod_ld, vo
     LX_CHECK_ARG(D == 3072 || D == 256, "lx_ln_modulate_lora_segs: the fused down-projection exists for D = 3072 and 256 (D=%d): use lx_lora_down", D);
     LX_CHECK_ARG(lora->A && lora->T && lora->R >= 1 && lora->R <= 16 && lora->ldt >= lora->R && lora->rows > 0 && lora->row0 >= 0,
                  "lx_ln_modulate_lora_segs: bad adapter arguments (R=%d)", lora->R);
-    LX_CHECK_ARG(((uintptr_t)lora->A & 7) == 0, "lx_ln_modulate_lora_segs: Adown must be 8-byte aligned");
-    const int rq = (lora->R + 3) / 4;
-#define LX_LN_LORA(NCH, RQ) hipLaunchKernelGGL((ln_modulate_kernel<NCH, RQ>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, (int*)nullptr)
-    if (D == 3072) { if (rq == 1) LX_LN_LORA(12, 1); else if (rq == 2) LX_LN_LORA(12, 2); else if (rq == 3) LX_LN_LORA(12, 3); else LX_LN_LORA(12, 4); }
-    else { if (rq == 1) LX_LN_LORA(1, 1); else if (rq == 2) LX_LN_LORA(1, 2); else if (rq == 3) LX_LN_LORA(1, 3); else LX_LN_LORA(1, 4); }
-#undef LX_LN_LORA
+    LX_CHECK_ARG(((uintptr_t)lora->A & 15) == 0, "lx_ln_modulate_lora_segs: Adown must be 16-byte aligned");
+    if (D == 3072) {
+      if (f16) hipLaunchKernelGGL((ln_modulate_kernel<12, true, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, f16_ovf);
+      else hipLaunchKernelGGL((ln_modulate_kernel<12, true, false>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, (int*)nullptr);
+    } else {
+      if (f16) hipLaunchKernelGGL((ln_modulate_kernel<1, true, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, f16_ovf);
+      else hipLaunchKernelGGL((ln_modulate_kernel<1, true, false>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, *lora, (int*)nullptr);
+    }
     LX_LAUNCH_CHECK("lx_ln_modulate_lora_segs");
     return LX_OK;
   }
   if (f16) {
-    if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12, 0, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
-    else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1, 0, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
+    if (D == 3072) hipLaunchKernelGGL((ln_modulate_kernel<12, false, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
+    else if (D == 256) hipLaunchKernelGGL((ln_modulate_kernel<1, false, true>), grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, LnLora{}, f16_ovf);
     else hipLaunchKernelGGL(ln_modulate_generic<true>, grid, block, 0, s, X, ldx, segs, mod_ld, y, ldy, M, D, eps, f16_ovf);
     LX_LAUNCH_CHECK("lx_ln_modulate_f16_segs");
     return LX_OK;
@@ -686,6 +723,21 @@ extern "C" int lx_ln_modulate_f16_segs(const float* X, int ldx, const lx_ln_seg*
     segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
   }
   return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream, nullptr, true, (int*)f16_ovf);
+}
+
+extern "C" int lx_ln_modulate_lora_f16_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,
+                                            float eps, const void* Adown, int R, float* T, int ldt, int lora_row0, int lora_rows,
+                                            int32_t* f16_ovf, void* stream) {
+  LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_ln_modulate_lora_f16_segs: 1..3 segments");
+  LX_CHECK_ARG(((uintptr_t)f16_ovf & 3) == 0, "lx_ln_modulate_lora_f16_segs: f16_ovf must be 4-byte aligned");
+  LnSegs segs;
+  segs.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.row0[i] = seg[i].row0; segs.n_rows[i] = seg[i].n_rows; segs.rows_per_batch[i] = seg[i].rows_per_batch;
+    segs.shift[i] = seg[i].shift; segs.scale[i] = seg[i].scale;
+  }
+  const LnLora lo{(const uint16_t*)Adown, T, R, ldt, lora_row0, lora_rows};
+  return ln_launch(X, ldx, segs, mod_ld, Y, ldy, D, eps, stream, &lo, true, (int*)f16_ovf);
 }
 
 extern "C" int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg* seg, int n_seg, int mod_ld, void* Y, int ldy, int D,

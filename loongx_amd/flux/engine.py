@@ -49,6 +49,9 @@ class DiTEngine:
         # The projection launches normalise / rotate k and q and write V^T in their epilogue (LX_EPI_QKV) wherever the shapes allow it
         # (_rope_pairs decides); False forces the separate lx_qkv_prep pass everywhere (tests compare the two).
         self.qkv_epilogue = True
+        # The LayerNorm launches also compute the LoRA down-projection of the Linear that reads their output (lx_ln_modulate_lora_segs: on
+        # the matrix pipe, inside the same launch); False = the separate lx_lora_down launches everywhere (tests compare the two).
+        self.ln_lora = True
         self.model_config: Dict = {}
         self.c_factor: Optional[float] = None
         # Split-K pair plan of the GEMM (lx_gemm_bf16_ws): needs a caller-owned workspace, one per stream -- this engine owns one
@@ -531,18 +534,30 @@ class DiTEngine:
         return dict(f16=True, f16_ovf=self.f16_ovf) if self.f16 else {}
 
     # ------------------------------------------------------------------------------------------ building blocks
-    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int) -> None:
-        """AdaLN LayerNorm + modulation of every stream of this forward into XN (the 16-bit operand image of this mode)."""
+    def _ln(self, base_by_stream: Dict[str, int], shift_off: int, scale_off: int, lora_for: Optional[str] = None,
+            include_txt: bool = False):
+        """AdaLN LayerNorm + modulation of every stream of this forward into XN (the 16-bit operand image of this mode).
+        lora_for: the Linear that reads XN next (its adapter's down-projection of the adapter rows is computed by the same launch, on the
+        matrix pipe, while the normalised rows are at hand: 76 of the 132 lx_lora_down launches of a denoise step sit behind a LayerNorm).
+        Returns what _gemm_streams takes as `lora_ready` ((adapter, first adapter row), or None when there is nothing to hand over)."""
         row0 = {"txt": self.r_txt, "img": self.r_img, "cond": self.r_cond}
         segs = []
         for s, L in self._streams():
             mods = self.cmods if s == "cond" else self.mods
             b0 = base_by_stream[s]
             segs.append((row0[s], self.B * L, L, mods[:, b0 + shift_off:], mods[:, b0 + scale_off:]))
+        lora, ready = None, None
+        lo = self.w.lora.get(lora_for) if lora_for is not None else None
+        if (lo is not None and self.ln_lora and (self.C > 0 or self.latent_lora) and self.lora_scale == 1.0 and lo.down.shape[0] <= 16
+                and self.cfg.inner_dim in (3072, 256) and self._lora_rows(include_txt) is not None):      # (the widths the kernel is built for)
+            r0, n = self._lora_rows(include_txt)
+            lora = (self._down(lora_for, lo), self.TL[r0:r0 + n, : lo.down.shape[0]], r0, n)       # slab 0 of TLs: the consumer sums one slab
+            ready = (lo, r0)
         if self.f16:
-            ops.ln_modulate_segs(self.X, segs, self.XN16, self.mods.stride(0), f16_ovf=self.f16_ovf)
+            ops.ln_modulate_segs(self.X, segs, self.XN16, self.mods.stride(0), f16_ovf=self.f16_ovf, lora=lora)
         else:
-            ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0))
+            ops.ln_modulate_segs(self.X, segs, self.XN, self.mods.stride(0), lora=lora)
+        return ready
 
     def _lora_rows(self, include_txt: bool):
         """(first row, row count) of the rows that run with the adapter on: the condition stream always; with
@@ -570,14 +585,17 @@ class DiTEngine:
     def _gemm_streams(self, A: torch.Tensor, Cbuf: torch.Tensor, main: str, txt: Optional[str], *, epilogue: int,
                       gate_off: Optional[Dict[str, int]] = None, lora_mod_cols: int = 0, lora_toff_max: int = 0,
                       gelu_col_start: int = 0, only: Optional[Sequence[str]] = None, ncols: Optional[Dict[str, int]] = None,
-                      qkv=None) -> None:
+                      qkv=None, lora_ready=None) -> None:
         """One grouped launch over the token streams. `main` weights serve image+condition rows, `txt` the text rows
         (None => text rows use `main` too: single blocks). `only` restricts the launch to those streams and `ncols[s]` to the
         first ncols[s] output columns (a multiple of 256) for stream s: the last block's outputs nobody reads are not computed."""
         w = self.w
         lora_needed = only is None or "cond" in only or self.latent_lora
         nsplit = self.TL_SPLIT
-        lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
+        if lora_ready is not None:            # the LayerNorm launch that wrote A left this GEMM's adapter term in slab 0 of TL
+            (lo, lr0), nsplit = lora_ready, 1
+        else:
+            lo, lr0 = self._lora_t(A, main, include_txt=txt is None) if lora_needed else (None, None)
         probs = []
         for s, L in self._streams():
             if only is not None and s not in only:
@@ -709,11 +727,11 @@ class DiTEngine:
         base = {"img": b, "cond": b, "txt": b + 6 * D}
         p = f"d{i}"
         Yq, Ya, Yf = self.Y[:, : 3 * D], self.Y[:, 2 * D: 3 * D], self.Y[:, 3 * D:]
-        self._ln(base, 0, D)                                                               # norm1 / norm1_context
+        ready = self._ln(base, 0, D, lora_for=p + ".qkv")                                   # norm1 / norm1_context (+ the q/k/v adapters' down-projection)
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq_txt"], w.t[p + ".wk_txt"])
         fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, Yq, p + ".qkv", p + ".qkv_txt", epilogue=LX_EPI_STORE_BF16, lora_mod_cols=D, lora_toff_max=2,
-                           qkv=nw + (i,) if fused else None)
+                           qkv=nw + (i,) if fused else None, lora_ready=ready)
         self._attention(*nw, prepped=fused, layer=i)
         gate = {s: base[s] + 2 * D for s in base}
         self._gemm_streams(Ya, self.X, p + ".out", p + ".out_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
@@ -724,8 +742,8 @@ class DiTEngine:
                       lora_split_stride=self.TLs.stride(0)) if lo is not None else {}
             ops.gemm([ops.gemm_desc(self._op(a), self._W(p + ".out"), self.rows(self.X, "img"), bias=w.t[p + ".out.b"], epilogue=LX_EPI_RESID_F32,
                                     rows_per_batch=self.C, gate=self.cmods[:, gate["cond"]:], **kw, **self._f16_kw())])
-        self._ln(base, 3 * D, 4 * D)                                                       # norm2 + (scale_mlp, shift_mlp)
-        self._gemm_streams(self.XN, Yf, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU)
+        ready = self._ln(base, 3 * D, 4 * D, lora_for=p + ".ff1")                           # norm2 + (scale_mlp, shift_mlp)
+        self._gemm_streams(self.XN, Yf, p + ".ff1", p + ".ff1_txt", epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, lora_ready=ready)
         gate = {s: base[s] + 5 * D for s in base}
         self._gemm_streams(Yf, self.X, p + ".ff2", p + ".ff2_txt", epilogue=LX_EPI_RESID_F32, gate_off=gate)
 
@@ -743,12 +761,13 @@ class DiTEngine:
         b = cfg.mod_base_single(j)
         base = {"img": b, "cond": b, "txt": b}
         p = f"s{j}"
-        self._ln(base, 0, D)
+        ready = self._ln(base, 0, D, lora_for=p + ".fused", include_txt=True)
         kv_only = {"txt": 2 * D, "cond": 2 * D} if image_out_only else None          # fused columns are [k | v | q | mlp]
         nw = (w.t[p + ".wq"], w.t[p + ".wk"], w.t[p + ".wq"], w.t[p + ".wk"])
         fused = self._qkv_epilogue()
         self._gemm_streams(self.XN, self.Y, p + ".fused", None, epilogue=LX_EPI_STORE_BF16 | LX_EPI_GELU, gelu_col_start=3 * D,
-                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None)
+                           lora_mod_cols=D, lora_toff_max=3, ncols=kv_only, qkv=nw + (cfg.num_layers + j,) if fused else None,
+                           lora_ready=ready)
         self._attention(*nw, prepped=fused, layer=cfg.num_layers + j, img_only=image_out_only)
         gate = {s: b + 2 * D for s in base}
         self._gemm_streams(self.Y[:, 2 * D:], self.X, p + ".out", None, epilogue=LX_EPI_RESID_F32, gate_off=gate,
@@ -1148,7 +1167,7 @@ class DiTEngine:
         key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8, self.f16,
                getattr(self.w, "q_log2_version", 0),      # (a weight broadcast refreshes the scaled norm_q tensors and the per-layer bounds)
                getattr(self.w, "weights_version", 0),     # (... and moves this one unconditionally: dist.broadcast_packed_weights)
-               self.cond_cache, skip)
+               self.cond_cache, skip, self.ln_lora, self.qkv_epilogue)
         g = self.graphs.get(key)
         if g is None:
             mode = (self.precise, self.gemm_fp8, self.f16, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0, skip)

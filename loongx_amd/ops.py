@@ -288,15 +288,23 @@ def qkv_prep(QKV, q_col, k_col, v_col, row0, n_rows, rows_per_batch, H, wq, wk, 
 def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6, lora=None, f16_ovf=None) -> None:
     """segs: list of (row0, n_rows, rows_per_batch, shift_tensor, scale_tensor); one launch. Y bf16, or fp16 (the A operand of an
     fp16-operand GEMM: saturated, f16_ovf = int32 device counter of the rows that clipped).
-    lora = (Adown [R, D] bf16, T [rows, >= R] fp32 (row stride T.stride(0)), first row, row count): also the LoRA down-projection of
-    those rows of Y, T[row - first] = Y_row . Adown^T (what lora_down(Y[first:first+count], Adown, T) computes; D = 3072 | 256)."""
+    lora = (Adown [R, D] in Y's 16-bit format, T [rows, >= R] fp32 (row stride T.stride(0)), first row, row count): also the LoRA
+    down-projection of those rows of Y, T[row - first] = Y_row . Adown^T, on the matrix pipe inside the same launch (what
+    lora_down(Y[first:first+count], Adown, T) computes; D = 3072 | 256)."""
     n = len(segs)
     arr = (L.LnSeg * n)()
     for i, (row0, n_rows, rpb, sh, sc) in enumerate(segs):
         arr[i].row0, arr[i].n_rows, arr[i].rows_per_batch = row0, n_rows, rpb
         arr[i].shift, arr[i].scale = sh.data_ptr(), sc.data_ptr()
+    if Y.dtype == torch.float16 and lora is not None:
+        A, T, r0, cnt = lora
+        _req(A, torch.float16, "Adown"); _req(T, torch.float32, "T")
+        assert A.is_contiguous() and A.shape[1] == X.shape[1] and T.shape[0] >= cnt and T.stride(1) == 1
+        check(lib.lx_ln_modulate_lora_f16_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, Y.data_ptr(), Y.stride(0), X.shape[1], eps,
+                                               A.data_ptr(), A.shape[0], T.data_ptr(), T.stride(0), r0, cnt, _p(f16_ovf), _stream()),
+              "lx_ln_modulate_lora_f16_segs")
+        return
     if Y.dtype == torch.float16:
-        assert lora is None
         check(lib.lx_ln_modulate_f16_segs(X.data_ptr(), X.stride(0), arr, n, mod_ld, Y.data_ptr(), Y.stride(0), X.shape[1], eps, _p(f16_ovf),
                                           _stream()), "lx_ln_modulate_f16_segs")
         return

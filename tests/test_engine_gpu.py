@@ -210,6 +210,54 @@ def test_forward_with_fused_qkv_epilogue(mc):
     assert relerr(outs["1"], outs["0"]) < 1e-2
 
 
+@pytest.mark.parametrize("operands", ["bf16", "fp16"])
+@pytest.mark.parametrize("mc", [{}, {"latent_lora": True}, {"independent_condition": True}])
+def test_lora_down_inside_the_layernorm_launch_matches_the_separate_launches(mc, operands):
+    """engine.ln_lora (default on): the LayerNorm launches also compute the adapter down-projection of the Linear that reads them
+    (lx_ln_modulate_lora[_f16]_segs, MFMA inside the launch) -- q/k/v and ff1 of the double blocks, the fused projection of the single
+    blocks; with latent_lora the image (and in single blocks the text) rows too. Against the fp32 oracle, and against the same engine
+    with the separate lx_lora_down launches: the same operands, another split of K in the fp32 sums."""
+    from oracle import flux_modules as fm
+    tr = tiny_transformer(seed=5)
+    g = torch.Generator().manual_seed(7)
+    B, T, hw = 2, 32, 8
+    N = hw * hw
+    kw = dict(hidden_states=torch.randn(B, N, 64, generator=g), encoder_hidden_states=torch.randn(B, T, 64, generator=g) * 0.5,
+              pooled_projections=torch.randn(B, 32, generator=g), timestep=torch.tensor([0.8, 0.3]),
+              img_ids=fm.prepare_latent_image_ids(hw, hw), txt_ids=torch.zeros(T, 3), guidance=torch.full((B,), 3.5))
+    cond = torch.randn(B, N, 64, generator=g)
+    cids = fm.prepare_latent_image_ids(hw, hw)
+    cids[:, 2] -= hw
+    with torch.no_grad():
+        want = fr.tranformer_forward(tr, cond, cids, None, mc, **kw)[0]
+    d = "cuda"
+    outs = {}
+    from loongx_amd import ops
+    for fusedln in (True, False):
+        eng = _engine(tr)
+        eng.ln_lora = fusedln
+        eng.set_conditioning(kw["encoder_hidden_states"].to(d), kw["pooled_projections"].to(d), kw["guidance"].to(d), kw["txt_ids"].to(d),
+                             kw["img_ids"].to(d), cond.to(d), cids.to(d), c_t=0.0, model_config=dict(mc, operands=operands))
+        calls = []
+        real = ops.lora_down
+        ops.lora_down = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            eng.use_graph = False
+            a = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()
+        finally:
+            ops.lora_down = real
+        eng.use_graph = True
+        b = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()      # captured
+        c = eng.forward(kw["hidden_states"].to(d), kw["timestep"].to(d)).float().cpu().clone()      # replayed
+        assert torch.equal(a, b) and torch.equal(b, c)
+        outs[fusedln] = (a, len(calls))
+    (a1, n1), (a0, n0) = outs[True], outs[False]
+    assert n0 - n1 == 4, (n1, n0)                             # the launches behind a LayerNorm are gone: q/k/v of the 2 double blocks, the fused
+                                                              # projection of the 2 single blocks (to_out / ff.net.2 / proj_out read GEMM outputs)
+    assert relerr(a1, want) < TOL and relerr(a0, want) < TOL
+    assert relerr(a1, a0) < (2e-3 if operands == "bf16" else 4e-4)       # fp32 sums in another order, then 16-bit operand roundings downstream
+
+
 @pytest.mark.parametrize("mc", [{"independent_condition": True}, {"union_cond_attn": False}, {"independent_condition": True, "latent_lora": True}])
 def test_step_invariant_condition_stream_is_cached(monkeypatch, mc):
     """independent_condition / union_cond_attn = False (block.py:106-120): the condition queries see only condition keys and c_t is

@@ -480,23 +480,25 @@ def test_ln_modulate(ops, D):
     assert relerr(Y.float().cpu(), ref.reshape(B * Lr, D).cpu()) < 3e-3
 
 
+@pytest.mark.parametrize("fmt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("D,R", [(3072, 4), (3072, 12), (3072, 16), (256, 12), (256, 5)])
-def test_ln_modulate_with_lora_down(ops, D, R):
-    """lx_ln_modulate_lora_segs: the normalised rows are identical to lx_ln_modulate_segs', and T of the adapter rows equals the
-    down-projection of exactly those bf16 rows (fp64 reference; lx_lora_down as the second opinion); other rows of T untouched."""
+def test_ln_modulate_with_lora_down(ops, D, R, fmt):
+    """lx_ln_modulate_lora[_f16]_segs: the normalised rows are identical to lx_ln_modulate[_f16]_segs', and T of the adapter rows equals
+    the down-projection of exactly those 16-bit rows (fp64 reference; lx_lora_down as the second opinion); other rows of T untouched.
+    42 rows: the last workgroup is half empty, the adapter rows start in the middle of a workgroup."""
     B, lens = 2, [5, 9, 7]                                       # three streams; the adapter rows are the last stream + half of the second
     M = B * sum(lens)
     X = rnd(M, D, seed=1, scale=2.0) + 0.3
     mods = [(rnd(B, D, seed=10 + i), rnd(B, D, seed=20 + i, scale=0.3)) for i in range(3)]
-    A = rnd(R, D, seed=5, scale=D ** -0.5, dtype=torch.bfloat16)
+    A = rnd(R, D, seed=5, scale=D ** -0.5, dtype=torch.bfloat16).to(fmt)
     segs, r = [], 0
     for i, Ls in enumerate(lens):
         segs.append((r, B * Ls, Ls, mods[i][0], mods[i][1]))
         r += B * Ls
-    Y0 = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    Y0 = torch.zeros(M, D, dtype=fmt, device=DEV)
     ops.ln_modulate_segs(X, segs, Y0, D)
     first, cnt = B * lens[0] + 3, M - (B * lens[0] + 3)
-    Y1 = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    Y1 = torch.zeros(M, D, dtype=fmt, device=DEV)
     T = torch.full((M, 16), 7.0, device=DEV)
     ops.ln_modulate_segs(X, segs, Y1, D, lora=(A, T[first:], first, cnt))
     torch.cuda.synchronize()
