@@ -118,6 +118,16 @@ __device__ __forceinline__ float half_wave_sum_hi16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
   return v;
 }
+// the sum over each row of 16 lanes, in every lane of the row: BIT-identical to v += __shfl_xor(v, 1); ... 2; ... 4; ... 8 (after the two
+// quad steps a quad's lanes hold the same bits, so the mirror partners 7 - i / 15 - i carry what the xor partners i ^ 4 / i ^ 8 do), on
+// DPP instead of four dependent ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+  return v;
+}
 // the sum over all 64 lanes as a wave-uniform value: the half-wave sums above, lane 31's into rows 2 / 3 (row_bcast:31), lane 63 read back
 // through an SGPR. Seven dependent vector instructions against wave_sum's six ds_bpermute round trips (another summation tree: results
 // differ from wave_sum's in the last bit).

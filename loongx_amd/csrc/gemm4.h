@@ -459,7 +459,11 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
           float ss = 0.f;
 #pragma unroll
           for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += bias0[c_]; v1[c_] += bias1[c_]; ss = __builtin_fmaf(v0[c_], v0[c_], ss); ss = __builtin_fmaf(v1[c_], v1[c_], ss); }
+#ifdef LX_G4_ROW16_SHFL                                   // (measurement build only, tools/build_variant.sh: the ds_bpermute tree this replaced)
           ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+#else
+          ss = row16_sum(ss);                        // (the 16 lanes of a row: DPP, bit-identical to the xor-shuffle tree it replaces)
+#endif
           const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
           float x[8];
           float (&y)[8] = yy[t];

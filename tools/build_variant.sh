@@ -2,7 +2,7 @@
 # Build loongx_amd/lib/liblx_amd_<name>.so = the shipped library with ONE source recompiled under extra flags (A/B of compile-time
 # knobs on the GPU box: LX_AMD_LIB=loongx_amd/lib/liblx_amd_<name>.so selects it; tools/attn_ab.py takes that as an arm).
 #   tools/build_variant.sh <name> <source stem: attn|attn4|gemm|gemm4|...> [hipcc flags, e.g. -DLX_ATTN_LOOK=4 or -DLX8_ELIM_EXP]
-# (the measurement knobs that stay in the sources: LX_ATTN_ELIM_*, LX8_ELIM_*, LX_A4_ELIM_*, LX_ATTN_PROBE, LX_G4_PROBE, LX_ATTN_LOOK, LX_A4_LOOK, LX_ACC_AGPR)
+# (the measurement knobs that stay in the sources: LX_ATTN_ELIM_*, LX8_ELIM_*, LX_A4_ELIM_*, LX_ATTN_PROBE, LX_G4_PROBE, LX_ATTN_LOOK, LX_A4_LOOK, LX_ACC_AGPR, LX_G4_ROW16_SHFL)
 set -euo pipefail
 NAME=$1; SRC=$2; shift 2
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../loongx_amd/csrc" && pwd)"
