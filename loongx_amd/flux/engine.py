@@ -111,7 +111,8 @@ class DiTEngine:
         self.vt0 = {"txt": 0, "img": _pad64(T), "cond": _pad64(T) + _pad64(N)}
         self.VT = torch.zeros(B, H, 128, _pad64(T) + _pad64(N) + _pad64(C), dtype=bf16, device=dev)
         self.Q8 = self.K8 = self.VT8 = None                       # fp8 attention images, allocated on first use
-        self.TL_SPLIT = 4                 # K-split slabs of the LoRA down-projection (1 / 2 / 8 measured: no better)
+        self.TL_SPLIT = 4                 # K-split slabs of the LoRA down-projection: 35.50 ms per step against 35.72 with 2 and 36.12 with 1
+                                          # (tools/ab_engine_attr.py TL_SPLIT 4 2, round 5; lx_gemm4_kernel sums at most four slabs)
         # precise mode writes one slab per cross term (up to 3: hi.A, lo.A, hi.A_lo) whatever the K-split of the bf16 path is
         self.TLs = torch.zeros(max(self.TL_SPLIT, 3), M, 16, dtype=f32, device=dev)
         self.TL = self.TLs[0]

@@ -41,14 +41,16 @@ ts = torch.full((B,), 0.5, device=dev)
 res = {a.a: [], a.b: []}
 outs = {}
 for val in (a.a, a.b):                      # warm both plans (eager pass + capture)
-    setattr(eng, a.attr, bool(val))
+    setattr(eng, a.attr, (int if a.attr in ('TL_SPLIT',) else bool)(val))
     for _ in range(3):
         outs[val] = eng.forward(lat, ts).float().clone()
 torch.cuda.synchronize()
 for r in range(a.rounds):
     for val in ((a.a, a.b) if r % 2 == 0 else (a.b, a.a)):
-        setattr(eng, a.attr, bool(val))
-        eng.forward(lat, ts)
+        setattr(eng, a.attr, (int if a.attr in ('TL_SPLIT',) else bool)(val))
+        eng.graphs.clear() if a.attr in ('TL_SPLIT',) else None      # (attributes the graph key does not know)
+        for _ in range(2):
+            eng.forward(lat, ts)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
