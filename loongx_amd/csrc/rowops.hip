@@ -513,15 +513,23 @@ __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms ter
   const uint16_t* xp = X + (size_t)min(m0 + l15, M - 1) * ldx + kq * 8;
   const uint16_t* ap = A + (size_t)min(l15, R - 1) * K + kq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // A wave's K steps are 256 apart (12 of them at K = 3072). Written as {load, load, wait, MFMA} per step the loop pays the memory
-  // latency once per step (7.5 us per launch, 133 launches per forward: the whole kernel was that chain); here the loads of up to eight
-  // steps are in flight together and the MFMAs follow in the same ascending-k order (bit-identical sums).
+  // A wave's K steps are 256 apart. Written as {load, load, wait, MFMA} per step the loop pays the memory latency once per step (7.5 us
+  // per launch in round 2: the whole kernel was that chain); round 3 put up to eight steps' loads in flight, in chunks of 8 / 4 / 2 / 1
+  // -- still two to four round trips per wave (3 steps at K = 3072 with four K-split slabs, 12 at 12288, 15 at 15360). Round 5: ONE batch
+  // of 4, 8 or 16 slots covers a wave's whole range; slots past the end carry zero fragments (their MFMAs add +0: same sums bit for
+  // bit as the ascending-k loop), so every launch of the denoise step waits for memory once. The launches are on the step's critical
+  // path (tools/ab_engine_attr.py TL_SPLIT 4 1: 1.8 % of the step between one and four K-split slabs).
   int k = kbeg + wave * 32;
-  auto chunk = [&](auto n_) {
+  const bf16x8 zero = {};
+  auto batch = [&](auto n_) {
     constexpr int NS = decltype(n_)::value;
     bf16x8 af[NS], xf[NS];
 #pragma unroll
-    for (int u = 0; u < NS; ++u) { af[u] = *(const bf16x8*)(ap + k + u * 256); xf[u] = *(const bf16x8*)(xp + k + u * 256); }
+    for (int u = 0; u < NS; ++u) {
+      const bool in = k + u * 256 < kend;
+      af[u] = in ? *(const bf16x8*)(ap + k + u * 256) : zero;
+      xf[u] = in ? *(const bf16x8*)(xp + k + u * 256) : zero;
+    }
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[u]), __builtin_bit_cast(f16x8, xf[u]), acc, 0, 0, 0);
@@ -529,11 +537,11 @@ __global__ __launch_bounds__(512) void lora_down_mfma_kernel(const LoraTerms ter
     }
     k += NS * 256;
   };
-  while (k + 7 * 256 < kend) chunk(std::integral_constant<int, 8>{});
-  if (k + 3 * 256 < kend) chunk(std::integral_constant<int, 4>{});
-  if (k + 256 < kend) chunk(std::integral_constant<int, 2>{});
-  if (k + 256 < kend) chunk(std::integral_constant<int, 2>{});      // (at most 3 steps were left after the 4-chunk)
-  if (k < kend) chunk(std::integral_constant<int, 1>{});
+  const int nsteps = k < kend ? (kend - k + 255) / 256 : 0;      // (wave-uniform)
+  if (nsteps <= 4) batch(std::integral_constant<int, 4>{});
+  else if (nsteps <= 8) batch(std::integral_constant<int, 8>{});
+  else
+    while (k < kend) batch(std::integral_constant<int, 16>{});
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
