@@ -168,9 +168,10 @@ void lx_gemm_reload_env(void);
  * LX_GEMM_PAIR = 0 never | 1 (default) where it measures faster (K >= 6144) | 2 whenever possible (tests).
  * Passing a workspace also selects the plans that depend on the launch's tile count: lx_gemm4_kernel (the 256x256x64 tile with one
  * wave per SIMD, AGPR accumulators) for launches whose tiles fill whole rounds (LX_GEMM4 = 0 never | 1 default | 2 whenever its
- * epilogues allow; LX_GEMM4_SK = 1 default | 0: its split form -- two workgroups per tile, half of K each, each parking the half of
- * the tile's rows the other one finishes -- for a partial last round (up to a third of a round; up to half of one for launches of
- * >= 96 K tiles without LX_EPI_QKV; launches of at most 16 rounds) and for the pair plan's shapes -- which exchanges through the
+ * epilogues allow; LX_GEMM4_SK = 1 default | 0 | 2 two-way only: its split form -- two workgroups per tile, half of K each, each parking
+ * the half of the tile's rows the other one finishes; three, a third of K each, where 3 x the split tiles fit one round and K is long
+ * (>= 96 K tiles) or the tail at most a sixth of a round -- for a partial last round (up to a third of a round; up to half of one for
+ * launches of >= 96 K tiles without LX_EPI_QKV; launches of at most 16 rounds) and for the pair plan's shapes -- which exchanges through the
  * workspace under the same bounded-wait / error-word contract; split-bf16 problems (k_segs >= 2) take the same plans by cost).
  * Without one the plans do not depend
  * on the batch size: a data-parallel shard reproduces the single-GPU batch bit for bit.

@@ -11,7 +11,7 @@
 static double round_us(int bm, int K) { return bm == 256 ? 15.0 + 1.81 * (K / 64) : 10.5 + 1.06 * (K / 64); }
 
 // runtime switches, read once per process (lx_gemm_reload_env() re-reads them): LX_GEMM_BM = 256 | 128 forces an 8-wave tile height,
-// LX_GEMM4 = 0 | 1 | 2 and LX_GEMM4_SK = 0 | 1 select lx_gemm4_kernel / its split form (include/lx.h), LX_GEMM4_FAULT = 1 injects a
+// LX_GEMM4 = 0 | 1 | 2 and LX_GEMM4_SK = 0 | 1 | 2 (two-way only) select lx_gemm4_kernel / its split form (include/lx.h), LX_GEMM4_FAULT = 1 injects a
 // partner time-out into the split form (tests). The A/B knobs of rounds 3-4 (pair kernel, one-grid switch, e4m3 q/k/v epilogue on
 // the 4-wave kernel, tail divisor, round limit) are gone with the plans that lost: one plan per launch shape.
 struct GemmEnv { int bm, g4, sk, g4_fault; };
@@ -225,6 +225,13 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
     // 8-wave mixed plan's half-height tiles -- stays there).
     const int tail_div = !qkv && kt_all >= 96 ? 2 : 3;
     bool split_tail = can_split && full > 0 && tail * tail_div <= NCU;      // (a tail of more than a third of a round: the 8-wave mixed plan's half-height tiles win -- the double blocks' q/k/v launch, 104 tail tiles: 154 vs 136 us)
+    // three workgroups per split tile (thirds of K, round 5) where 3 x the split tiles fit one round AND the K loop is what the tail
+    // costs: long K (>= 96 K tiles: the step-invariant-condition forwards' ff2 / proj_out, 72 tiles: 1.474 -> 1.553 images/s), or a
+    // small tail (up to a sixth of a round: 2 ... 32 tiles at K = 3072: -3 ... -5 us per launch; at 72 tiles the second partner's
+    // sums and the 216 workgroups' operand traffic cost what the shorter loop saves: 270.3 vs 269.5 us, tools/gemm_tail_cost.py).
+    // bf16 / fp16 kernels; LX_GEMM4_SK = 2 keeps the two-way form everywhere (A/B).
+    int np = 2;
+    if (!split && env.sk != 2 && kt_all >= 24 && tail * 3 <= 256 && tail * 3 <= NCU && (split_all || split_tail) && (kt_all >= 96 || tail * 6 <= NCU)) np = 3;
     if (split) {
       // precise mode (two or three passes over K: the K-independent cost of a round and of the exchange weigh a third as much as on the
       // bf16 path; no q/k/v epilogue, no mixed plan to compete with): by cost -- measured slopes per K tile and round, 1.31 us for this
@@ -252,13 +259,13 @@ extern "C" int lx_gemm_bf16_ws(const lx_gemm_desc* problems, int n, void* worksp
         slots = (float*)workspace;
         flags = (int*)((char*)workspace + SK_FLAGS_OFF);
         err = flags + 256;
-        grid = (unsigned)(full + 2 * tail);
+        grid = (unsigned)(full + np * tail);
         sk_full = (int)full;
         sk_parts = env.g4_fault ? 3 : 2;
       }
       if (split) lx_gemm4_launch_split(all, grid, sk_full, sk_parts, slots, flags, err, s);
-      else if (f16) lx_gemm4_launch_f16(all, grid, sk_full, sk_parts, slots, flags, err, s);
-      else lx_gemm4_launch_bf16(all, grid, sk_full, sk_parts, slots, flags, err, s);
+      else if (f16) lx_gemm4_launch_f16(all, grid, sk_full, sk_parts, slots, flags, err, s, np);
+      else lx_gemm4_launch_bf16(all, grid, sk_full, sk_parts, slots, flags, err, s, np);
       LX_LAUNCH_CHECK("lx_gemm_bf16");
       return LX_OK;
     }

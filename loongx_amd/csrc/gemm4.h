@@ -43,7 +43,11 @@ __device__ unsigned long long lx_g4_probe_buf[8192 * 8];
 // hi / lo output pair of LX_EPI_SPLIT_BF16. A separate instantiation, so that the bf16 path keeps its exact instruction stream.
 // F16 = fp16 operands (LX_OPERANDS_F16): v_mfma_f32_16x16x32_f16 on the same fragments, and the 16-bit store of the bf16-store epilogue
 // writes fp16 (saturated, reported through P.f16_ovf); LX_EPI_QKV outputs stay bf16.
-template <bool SPLIT, bool F16 = false>
+// NP = the number of workgroups a split tile is shared by: 2 (above), or 3 (round 5: thirds of K; part 0 owns the 16-row blocks 0-2 of
+// every wave, part 1 blocks 3-5, part 2 blocks 6-7; each parks what the other two own, raises its flag as a count of two readers, waits
+// for both partners and adds both partners' sums) -- for tails of up to a third of a round, where any two-way tail costs at least half
+// a K loop + the exchange (tools/gemm_tail_cost.py: 37 us at K = 3072). Its own instantiation: the two-way kernel keeps its code.
+template <bool SPLIT, bool F16 = false, int NP = 2>
 __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs args, const int sk_full, const int sk_parts, float* __restrict__ sk_slots,
                                                               int* __restrict__ sk_flags, int* __restrict__ sk_err) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + inx;
   } else {                                             // one half of K of a split tile
     const int r = pid - sk_full;
-    lid = sk_full + (r >> 1);
-    part = r & 1;
+    lid = sk_full + r / NP;
+    part = r % NP;
   }
   (void)total;
   const bool split_tile = pid >= sk_full && sk_parts >= 2;          // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   const bool w_tiled = (P.epilogue & LX_W_TILED) != 0;
   const int nk1 = K / BK;                              // K tiles of one pass over K
   const int nkt = SPLIT ? nk1 * max(P.k_segs, 1) : nk1; // K tiles of the tile (all segments); this workgroup's share: [kt_begin, kt_end)
-  const int kt_begin = split_tile && part ? nkt >> 1 : 0;
-  const int kt_end = split_tile && !part ? nkt >> 1 : nkt;
+  const int kt_begin = !split_tile ? 0 : NP == 2 ? (part ? nkt >> 1 : 0) : (part * nkt) / NP;
+  const int kt_end = !split_tile ? nkt : NP == 2 ? (part ? nkt : nkt >> 1) : ((part + 1) * nkt) / NP;
 
   // ---- staging: this wave moves pieces j * 4 + wave (j = 0..7; 1 KiB = 8 rows of 128 B each) of both operand tiles ----
   uint32_t aoff[8], woff[8];
@@ -270,13 +274,20 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   // half of the blocks = half of the time): with one half parking all eight blocks and the other finishing all eight, the launch paid
   // 12.6 us of parking + the wait + a full 38-us epilogue on 120 of the 256 CUs.
   const float* partner = nullptr;                      // the other half's sums (tile-local [256][256] fp32), added in the epilogue
+  const float* partner2 = nullptr;                     // NP = 3: the third workgroup's
   float* my_slot = nullptr;
   if (split_tile) {
     my_slot = sk_slots + (size_t)(pid - sk_full) * SK_SLOT_FLOATS;
-    partner = sk_slots + (size_t)((pid - sk_full) ^ 1) * SK_SLOT_FLOATS;    // read with sc1 loads (written with sc1 stores): no cache maintenance
+    if constexpr (NP == 2) {
+      partner = sk_slots + (size_t)((pid - sk_full) ^ 1) * SK_SLOT_FLOATS;    // read with sc1 loads (written with sc1 stores): no cache maintenance
+    } else {
+      const int gb = (pid - sk_full) - part;
+      partner = sk_slots + (size_t)(gb + (part + 1) % NP) * SK_SLOT_FLOATS;
+      partner2 = sk_slots + (size_t)(gb + (part + 2) % NP) * SK_SLOT_FLOATS;
+    }
   }
-  auto pld4 = [&](size_t off_floats) {                 // 16 B of the partner's slot, agent scope (sc1: not from this CU's L1 / a stale L2 line)
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lx_make_rsrc(partner), (int)(off_floats * 4), 0, PAIR_AUX_SC1);
+  auto pld4 = [&](size_t off_floats, const float* from) {    // 16 B of a partner's slot, agent scope (sc1: not from this CU's L1 / a stale L2 line)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lx_make_rsrc(from), (int)(off_floats * 4), 0, PAIR_AUX_SC1);
     return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
   const int lm0 = wm * 128, ln0 = wn * 128;            // this wave's tile-local origin
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (tid == 0) {
-      const int me = pid - sk_full, other = me ^ 1;
+      const int me = pid - sk_full, other = NP == 2 ? (me ^ 1) : (me - part + (part + 1) % NP), other2 = me - part + (part + 2) % NP;
       // The error word is STICKY until the host resets the workspace (lx_gemm_workspace_status): after a time-out a partner's flag may be
       // raised late and stay up, and a later launch on the same slot (the engine polls the word asynchronously, graph replays keep coming)
       // would pass its wait on that stale flag and add sums the partner has not written. So a workspace with the word up is refused:
@@ -296,14 +307,25 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       bool ok = __hip_atomic_load(sk_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
       if (ok) {
         if (!(sk_parts == 3 && part == 1))             // (3: fault injection, part 1 never raises its flag -- tools/race_screen_g4.py)
-          __hip_atomic_store(sk_flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sk_flags + me, NP - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (a count of readers)
         int spins = 0;
         while (__hip_atomic_load(sk_flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 20)) { ok = false; break; }
         }
-        if (ok) __hip_atomic_store(sk_flags + other, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (each flag: raised by its owner, reset by its reader)
-        else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // lx_gemm_workspace_status reports it
+        if constexpr (NP == 3) {
+          while (ok && __hip_atomic_load(sk_flags + other2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 20)) { ok = false; break; }
+          }
+        }
+        if (ok) {                                      // (each flag: raised by its owner, taken down by its readers)
+          if constexpr (NP == 2) __hip_atomic_store(sk_flags + other, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else {
+            __hip_atomic_fetch_add(sk_flags + other, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sk_flags + other2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else __hip_atomic_store(sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // lx_gemm_workspace_status reports it
       }
     }
     __syncthreads();
@@ -398,11 +420,12 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
       // split owner: the other half's sums of this block are added INTO the patch, row layout (two 16-B sc1 loads per lane and four-row
       // pass), before any epilogue path reads it -- one place for all paths (the V^T path reads the patch by columns: per-element
       // partner loads there cost 256 four-byte loads per lane and tile, the q/k/v launch went from 136 to 203 us)
-      f32x4 pa[4][2];
+      f32x4 pa[4][2], pb[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const size_t po = (size_t)(lm0 + i * 16 + t * 4 + (lane >> 4)) * 256 + ln0 + c8;
-        pa[t][0] = pld4(po); pa[t][1] = pld4(po + 4);
+        pa[t][0] = pld4(po, partner); pa[t][1] = pld4(po + 4, partner);
+        if constexpr (NP == 3) { pb[t][0] = pld4(po, partner2); pb[t][1] = pld4(po + 4, partner2); }
       }
       float* pw = patch + (i & 1) * (16 * G4_PLD);
 #pragma unroll
@@ -411,6 +434,10 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
         f32x4 v0 = *(const f32x4*)q_, v1 = *(const f32x4*)(q_ + 4);
 #pragma unroll
         for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += pa[t][0][c_]; v1[c_] += pa[t][1][c_]; }
+        if constexpr (NP == 3) {                       // (own + next part's + the part after: a fixed order per owner)
+#pragma unroll
+          for (int c_ = 0; c_ < 4; ++c_) { v0[c_] += pb[t][0][c_]; v1[c_] += pb[t][1][c_]; }
+        }
         *(f32x4*)q_ = v0; *(f32x4*)(q_ + 4) = v1;
       }
       __builtin_amdgcn_wave_barrier();
@@ -559,16 +586,35 @@ __global__ __launch_bounds__(G4_THREADS) void lx_gemm4_kernel(const GemmArgs arg
   if (!split_tile) {                                   // a whole tile: its own straight line (a branch in the middle of it cost 3 % per launch)
     if (mw0 < M) put(std::integral_constant<int, 0>{});
     G4_B(0, 1); G4_B(1, 2); G4_B(2, 3); G4_B(3, 4); G4_B(4, 5); G4_B(5, 6); G4_B(6, 7); G4_B(7, -1);
-  } else if (part == 0) {                              // parks 4-7, then owns 0-3
-    if (mw0 + 64 < M) put(std::integral_constant<int, 4>{});
-    G4_K(4, 5); G4_K(5, 6); G4_K(6, 7); G4_K(7, 0);
-    exchange();
-    G4_B(0, 1); G4_B(1, 2); G4_B(2, 3); G4_B(3, -1);
-  } else {                                             // parks 0-3, then owns 4-7
-    if (mw0 < M) put(std::integral_constant<int, 0>{});
-    G4_K(0, 1); G4_K(1, 2); G4_K(2, 3); G4_K(3, 4);
-    exchange();
-    G4_B(4, 5); G4_B(5, 6); G4_B(6, 7); G4_B(7, -1);
+  } else if constexpr (NP == 2) {
+    if (part == 0) {                                   // parks 4-7, then owns 0-3
+      if (mw0 + 64 < M) put(std::integral_constant<int, 4>{});
+      G4_K(4, 5); G4_K(5, 6); G4_K(6, 7); G4_K(7, 0);
+      exchange();
+      G4_B(0, 1); G4_B(1, 2); G4_B(2, 3); G4_B(3, -1);
+    } else {                                           // parks 0-3, then owns 4-7
+      if (mw0 < M) put(std::integral_constant<int, 0>{});
+      G4_K(0, 1); G4_K(1, 2); G4_K(2, 3); G4_K(3, 4);
+      exchange();
+      G4_B(4, 5); G4_B(5, 6); G4_B(6, 7); G4_B(7, -1);
+    }
+  } else {                                             // thirds (consecutive blocks of a sequence alternate between the two patches: i & 1)
+    if (part == 0) {                                   // parks 3-7, then owns 0-2
+      if (mw0 + 48 < M) put(std::integral_constant<int, 3>{});
+      G4_K(3, 4); G4_K(4, 5); G4_K(5, 6); G4_K(6, 7); G4_K(7, 0);
+      exchange();
+      G4_B(0, 1); G4_B(1, 2); G4_B(2, -1);
+    } else if (part == 1) {                            // parks 0-2, 7, 6, then owns 3-5
+      if (mw0 < M) put(std::integral_constant<int, 0>{});
+      G4_K(0, 1); G4_K(1, 2); G4_K(2, 7); G4_K(7, 6); G4_K(6, 3);
+      exchange();
+      G4_B(3, 4); G4_B(4, 5); G4_B(5, -1);
+    } else {                                           // parks 0-5, then owns 6-7
+      if (mw0 < M) put(std::integral_constant<int, 0>{});
+      G4_K(0, 1); G4_K(1, 2); G4_K(2, 3); G4_K(3, 4); G4_K(4, 5); G4_K(5, 6);
+      exchange();
+      G4_B(6, 7); G4_B(7, -1);
+    }
   }
 #undef G4_B
 #undef G4_K

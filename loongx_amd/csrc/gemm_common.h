@@ -85,6 +85,7 @@ void lx_gemm8_launch_fp8(int bm, const GemmArgs& a, hipStream_t s);
 void lx_gemm8_mixed_launch_bf16(const GemmArgs& big, const GemmArgs& tail, int n_big_pad, hipStream_t s);
 void lx_gemm8_mixed_launch_f16(const GemmArgs& big, const GemmArgs& tail, int n_big_pad, hipStream_t s);
 // lx_gemm4_kernel: `grid` workgroups, the first sk_full of them whole tiles, the rest halves of split tiles (sk_parts 1: none | 2 | 3: fault injection)
-void lx_gemm4_launch_bf16(const GemmArgs& a, unsigned grid, int sk_full, int sk_parts, float* slots, int* flags, int* err, hipStream_t s);
-void lx_gemm4_launch_f16(const GemmArgs& a, unsigned grid, int sk_full, int sk_parts, float* slots, int* flags, int* err, hipStream_t s);
+// (np: the workgroups a split tile is shared by, 2 or 3 -- the bf16 and fp16 kernels; the split-bf16 kernel has the two-way form only)
+void lx_gemm4_launch_bf16(const GemmArgs& a, unsigned grid, int sk_full, int sk_parts, float* slots, int* flags, int* err, hipStream_t s, int np = 2);
+void lx_gemm4_launch_f16(const GemmArgs& a, unsigned grid, int sk_full, int sk_parts, float* slots, int* flags, int* err, hipStream_t s, int np = 2);
 void lx_gemm4_launch_split(const GemmArgs& a, unsigned grid, int sk_full, int sk_parts, float* slots, int* flags, int* err, hipStream_t s);

@@ -322,6 +322,87 @@ def test_gemm_split_form_timeout_is_reported_and_poisons_the_workspace(ops, monk
     ops.gemm_workspace_status(ws)
 
 
+@pytest.mark.parametrize("fmt", FMTS)
+def test_gemm_three_way_split_form(ops, monkeypatch, fmt):
+    """THREE workgroups per split tile (thirds of K; lx_gemm4_kernel<.., 3>): what the planner gives a long-K launch of at most a third of a
+    round of tiles -- ff2 on the 1536 text + image rows of a step-invariant-condition forward: 72 tiles, K = 12288, gated fp32 residual +
+    LoRA -- and a small tail (8 tiles behind two whole rounds, bf16 store). Against the plans without a workspace and the two-way form
+    (LX_GEMM4_SK=2) on the same inputs, bit-identical from run to run and under graph replay (a flag is a count of readers: taken down by
+    both), and the forced time-out of a partner is reported."""
+    from loongx_amd._lib import LxError
+    monkeypatch.delenv("LX_GEMM_BM", raising=False)
+    monkeypatch.delenv("LX_GEMM4_SK", raising=False)
+    ops.lib.lx_gemm_reload_env()
+    M, N, K, r = 1536, 3072, 12288, 4
+    A = opd(rnd(M, K, seed=1, dtype=torch.bfloat16), fmt)
+    W = opd(rnd(N, K, seed=2, scale=0.02, dtype=torch.bfloat16), fmt)
+    bias, gate, X0 = rnd(N, seed=3, scale=0.1), rnd(1, N, seed=4), rnd(M, N, seed=5)
+    Ad = opd(rnd(r, K, seed=7, scale=0.05, dtype=torch.bfloat16), fmt)
+    Bu = rnd(N, r, seed=8, scale=0.1)
+    Tls = torch.zeros(4, M, 16, dtype=torch.float32, device=DEV)
+    ops.lora_down(A, Ad, Tls[0][:, :r], n_split=4, split_stride=Tls.stride(0))
+    X = torch.empty_like(X0)
+    d = ops.gemm_desc(A, W, X, bias=bias, epilogue=ops.LX_EPI_RESID_F32, gate=gate, lora_t=Tls[0], lora_up=Bu, lora_nsplit=4,
+                      lora_split_stride=Tls.stride(0), **fkw(fmt))
+    ws = _ws()
+    out = {}
+    for mode in ("none", "three", "two"):
+        if mode == "two":
+            monkeypatch.setenv("LX_GEMM4_SK", "2")
+            ops.lib.lx_gemm_reload_env()
+        X.copy_(X0)
+        ops.gemm([d], None if mode == "none" else ws)
+        torch.cuda.synchronize()
+        out[mode] = X.clone()
+    monkeypatch.delenv("LX_GEMM4_SK")
+    ops.lib.lx_gemm_reload_env()
+    ops.gemm_workspace_status(ws)
+    ref = X0 + gate * (A.float() @ W.float().T + bias + Tls.sum(0)[:, :r] @ Bu.T)
+    assert relerr(out["three"].cpu(), ref.cpu()) < 2e-5
+    assert relerr(out["three"].cpu(), out["none"].cpu()) < 2e-6 and relerr(out["three"].cpu(), out["two"].cpu()) < 2e-6
+    assert not torch.equal(out["three"], out["two"])            # (another split of K: the two forms are different launches)
+    for _ in range(3):
+        X.copy_(X0)
+        ops.gemm([d], ws)
+        assert torch.equal(X, out["three"])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        X.copy_(X0)
+        ops.gemm([d], ws)
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(X, out["three"])
+    ops.gemm_workspace_status(ws)
+    # a small tail: 520 tiles = two rounds + 8, the 8 by three workgroups each
+    N2, K2 = 256 * 52, 3072
+    A2 = opd(rnd(2560, K2, seed=11, dtype=torch.bfloat16), fmt)
+    W2 = opd(rnd(N2, K2, seed=12, scale=0.02, dtype=torch.bfloat16), fmt)
+    b2 = rnd(N2, seed=13, scale=0.1)
+    C = {}
+    for mode in ("none", "three"):
+        c = torch.empty(2560, N2, dtype=torch.float16 if fmt == "f16" else torch.bfloat16, device=DEV)
+        ops.gemm([ops.gemm_desc(A2, W2, c, bias=b2, epilogue=ops.LX_EPI_STORE_BF16 | ops.LX_EPI_GELU, **fkw(fmt))], None if mode == "none" else ws)
+        torch.cuda.synchronize()
+        C[mode] = c.float().cpu()
+    want = torch.nn.functional.gelu(A2.float() @ W2.float().T + b2, approximate="tanh").cpu()
+    assert relerr(C["three"], want) < 4e-3 and relerr(C["three"], C["none"]) < 2e-3
+    ops.gemm_workspace_status(ws)
+    # the forced time-out (part 1 of every split tile never raises its flag): both partners report it
+    monkeypatch.setenv("LX_GEMM4_FAULT", "1")
+    ops.lib.lx_gemm_reload_env()
+    X.copy_(X0)
+    ops.gemm([d], ws); torch.cuda.synchronize()
+    monkeypatch.delenv("LX_GEMM4_FAULT")
+    ops.lib.lx_gemm_reload_env()
+    with pytest.raises(LxError):
+        ops.gemm_workspace_status(ws)
+    X.copy_(X0)
+    ops.gemm([d], ws); torch.cuda.synchronize()
+    assert torch.equal(X, out["three"])
+    ops.gemm_workspace_status(ws)
+
+
 def test_gemm_workspace_error_word_position(ops):
     """The engine polls the workspace's error word asynchronously (FluxEngine.check_status(sync=False)) at a FIXED position: the int 64
     ints before the end (include/lx.h). Raising it by hand must be what lx_gemm_workspace_status reports -- and resets."""

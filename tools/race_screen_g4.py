@@ -118,6 +118,8 @@ def side_load(n):
 
 cases = [("ff2 M=2560 K=12288 (batch 1, 120 tiles: every tile split)", lambda: resid_problem(2560, 4 * D)),
          ("single proj_out M=2560 K=15360", lambda: resid_problem(2560, 5 * D)),
+         ("ff2 M=1536 K=12288 (step-invariant-condition forward, 72 tiles: every tile by THREE workgroups)", lambda: resid_problem(1536, 4 * D)),
+         ("single proj_out M=1536 K=15360 (three-way)", lambda: resid_problem(1536, 5 * D)),
          ("fused [k|v|q|mlp] projection M=2560 N=21504 K=3072, LX_EPI_QKV (840 tiles: split tail)", lambda: fused_projection(1, (512, 1024, 1024))),
          ("ff2 M=8704 K=12288 (1024x1024, batch 1)", lambda: resid_problem(8704, 4 * D)),
          ("single proj_out M=8704 K=15360", lambda: resid_problem(8704, 5 * D)),
