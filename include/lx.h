@@ -25,6 +25,8 @@ extern "C" {
 #endif
 
 /* ABI history:
+ *  0.4.2  + lx_qkv_prep_f16in_segs, lx_qkv_prep_fp8_f16in_segs (the separate RMSNorm + RoPE + V^T pass on a projection an LX_OPERANDS_F16
+ *         launch stored as fp16: stream lengths LX_EPI_QKV does not take)
  *  0.4.1  + lx_ln_modulate_lora_f16_segs; lx_ln_modulate_lora_segs computes its down-projection on the matrix pipe (Adown 16-byte aligned);
  *         + LX_ATTN_PREFER_4WAVE
  *  0.4.0  fp16 operand format: LX_OPERANDS_F16 (lx_gemm_desc.f16_ovf in col_scale's slot), LX_ATTN_O_F16, lx_attn_desc.qseg_mask (in the
@@ -37,7 +39,7 @@ extern "C" {
  *  0.3.0  lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs, lx_attn_fwd_split,
  *         lx_lora_down_terms
  *  0.2.0  caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
-#define LX_VERSION 401
+#define LX_VERSION 402
 
 typedef enum lx_status {
   LX_OK = 0,
@@ -263,6 +265,10 @@ typedef struct lx_qkv_seg {
 } lx_qkv_seg;
 int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
                      int H, float eps, void* VT, int vt_ld, void* stream);
+/* The same on a QKV buffer whose q / k / v columns hold IEEE fp16 (the 16-bit store of an LX_OPERANDS_F16 projection launch WITHOUT LX_EPI_QKV):
+ * q and k are read as fp16 and written back in place as bf16 (what lx_attn_fwd reads), V^T gets bf16(v). block.py:38-41,60-67,74-78,92-99. */
+int lx_qkv_prep_f16in_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                           int H, float eps, void* VT, int vt_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Joint attention over up to 3 token segments [text | image | condition] -- replaces
@@ -333,6 +339,10 @@ int lx_attn_last_kernel(void);
 int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
                          int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
                          float q_scale, float k_scale, float v_scale, void* stream);
+/* lx_qkv_prep_fp8_segs reading fp16 q / k / v columns (see lx_qkv_prep_f16in_segs); the QKV buffer is not modified */
+int lx_qkv_prep_fp8_f16in_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                               int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                               float q_scale, float k_scale, float v_scale, void* stream);
 int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_descale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -174,11 +174,24 @@ def process_shard(rank, world_size, model, n_items, args, device):
         eng = getattr(getattr(model, "transformer", None), "engine", None)
         if eng is not None:
             eng.check_status(sync=True)                              # a split-K pair time-out invalidates this image: raise before it is saved
+            _f16_checked(eng, model.model_config)                    # ... and so does a saturated fp16 operand (policy: --f16-overflow)
         torch.save(host, os.path.join(args.output_dir, item["name"] + ".latent.pt"))
         if rank == 0 and (idx - start) % 10 == 0:
             print(f"Process {rank}: completed {idx - start + 1}/{end - start} images")
     torch.cuda.synchronize()
     return end - start, time.time() - t0
+
+
+def _f16_checked(eng, model_config):
+    """generate(output_type="latent") reads the fp16 saturation counter asynchronously (one image late); before an image is SAVED the
+    counter is read synchronously. "fallback" was already resolved inside generate() (it decides per image, synchronously)."""
+    n = eng.f16_overflow_poll(sync=True)
+    if n:
+        from loongx_amd.flux.generate import F16OverflowError
+        msg = f"fp16 operand mode: {n} saturation event(s) in the image about to be saved"
+        if str(model_config.get("f16_overflow", "raise")) == "raise":
+            raise F16OverflowError(msg)
+        print("WARNING: " + msg)
 
 
 # ---- process model ---------------------------------------------------------------------------------------------------------------
@@ -252,8 +265,18 @@ def main(argv=None):
     p.add_argument("--num_gpus", type=int, default=8, help="Number of GPUs to use for distributed inference")
     p.add_argument("--synthetic", action="store_true", help="synthetic weights / latents / signals (no checkpoints, T5 or VAE needed)")
     p.add_argument("--num_images", type=int, default=2, help="(--synthetic) number of images")
+    p.add_argument("--operands", type=str, default=None, choices=("bf16", "fp16"),
+                   help="16-bit format of the GEMM operand images (model_config['operands']): bf16 | fp16 (1e-3 per forward against the fp32 "
+                        "reference at the bf16 mode's speed; 5 exponent bits: see --f16-overflow). Default: what the config's dtype selects")
+    p.add_argument("--f16-overflow", dest="f16_overflow", type=str, default="raise", choices=("raise", "warn", "fallback"),
+                   help="what an fp16 operand beyond +-65504 does (the kernels saturate and count; the reference clips silently, "
+                        "block.py:275-276): raise | warn | fallback (recompute that image with bf16 operands)")
     args = p.parse_args(argv)
     config = get_config()
+    config.setdefault("model", {})
+    if args.operands:
+        config["model"]["operands"] = args.operands
+    config["model"]["f16_overflow"] = args.f16_overflow
 
     if args.single_image and args.prompt and not args.synthetic:
         from PIL import Image

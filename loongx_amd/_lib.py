@@ -92,10 +92,12 @@ _SIGS = {
     "lx_ln_modulate_lora_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "lx_ln_modulate_lora_f16_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P, _P]),
     "lx_qkv_prep_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
+    "lx_qkv_prep_f16in_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _I, _P]),
     "lx_qkv_prep": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "lx_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "lx_attn_last_kernel": (C.c_int, []),
     "lx_qkv_prep_fp8_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _P, _I, _P, _I, _F, _F, _F, _P]),
+    "lx_qkv_prep_fp8_f16in_segs": (C.c_int, [_P, _I, _I, _I, _I, C.POINTER(QkvSeg), _I, _I, _I, _F, _P, _P, _I, _P, _I, _F, _F, _F, _P]),
     "lx_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnDesc), _F, _F, _P]),
     "lx_split_bf16": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "lx_ln_modulate_split_segs": (C.c_int, [_P, _I, C.POINTER(LnSeg), _I, _I, _P, _I, _I, _I, _F, _P]),

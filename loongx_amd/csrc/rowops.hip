@@ -222,7 +222,31 @@ struct QkvSegs {
 // not bandwidth. The FAST body therefore issues all loads of two of the thread's four rows (q, k, v chunks, RoPE table rows) before
 // anything is computed or stored -- the q / k stores go to the buffer the next rows' loads read, so hipcc cannot hoist them
 // itself -- without branches in between (at a control-flow join its wait-count pass falls back to vmcnt(0)).
-template <bool FAST>
+// IN_F16: the projection launch stored IEEE fp16 (an LX_OPERANDS_F16 16-bit store without LX_EPI_QKV: stream lengths the fused epilogue does
+// not take, or callers that asked for the separate pass). q / k are read as fp16 and written back in place as bf16 -- what the attention
+// kernels read --, V goes to the V^T image rounded fp16 -> bf16. Only the general (non-FAST) body has this form: the path is the rare one.
+__device__ __forceinline__ void unpack16x8(const u32x4 raw, float* x, bool in_f16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (in_f16) {
+      x[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw[i] & 0xffffu));
+      x[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw[i] >> 16));
+    } else {
+      x[2 * i] = __uint_as_float(raw[i] << 16);
+      x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+    }
+  }
+}
+__device__ __forceinline__ u32x4 f16x8_to_bf16x8(const u32x4 raw) {
+  float x[8];
+  unpack16x8(raw, x, true);
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+  return o;
+}
+
+template <bool FAST, bool IN_F16 = false>
 __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
                                                        const QkvSegs segs, float eps, uint16_t* __restrict__ VT, int vt_ld, int H) {
   __shared__ uint16_t vt_s[64][128 + 8];
@@ -322,11 +346,7 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
       u32x4 raw = {0u, 0u, 0u, 0u};
       if (valid) raw = *(const u32x4*)ptr;
       float x[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        x[2 * i] = __uint_as_float(raw[i] << 16);
-        x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
-      }
+      unpack16x8(raw, x, IN_F16);
       if (wn) {
         float ss = 0.f;
 #pragma unroll
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(uint16_t* __restrict__ QK
     if (VT) {  // stash V[key][d] for the transpose
       u32x4 raw = {0u, 0u, 0u, 0u};
       if (valid) raw = *(const u32x4*)(rowp + v_col);
-      *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = raw;
+      *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = IN_F16 ? f16x8_to_bf16x8(raw) : raw;
     }
   }
   }
@@ -394,6 +414,7 @@ __device__ __forceinline__ int vt8_key(int j) {   // byte position within a 64-k
   return (p >> 4) * 32 + 8 * ((p & 15) >> 2) + 4 * g + (p & 3);
 }
 
+template <bool IN_F16>
 __global__ __launch_bounds__(256) void qkv_prep_fp8_kernel(const uint16_t* __restrict__ QKV, int ld, int q_col, int k_col, int v_col,
                                                            const QkvSegs segs, float eps, uint8_t* __restrict__ Q8,
                                                            uint8_t* __restrict__ K8, int ld8, uint8_t* __restrict__ VT8, int vt_ld,
@@ -432,11 +453,7 @@ __global__ __launch_bounds__(256) void qkv_prep_fp8_kernel(const uint16_t* __res
       u32x4 raw = {0u, 0u, 0u, 0u};
       if (valid) raw = *(const u32x4*)(rowp + (which ? k_col : q_col));
       float x[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        x[2 * i] = __uint_as_float(raw[i] << 16);
-        x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
-      }
+      unpack16x8(raw, x, IN_F16);
       if (wn) {
         float ss = 0.f;
 #pragma unroll
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(256) void qkv_prep_fp8_kernel(const uint16_t* __res
     }
     u32x4 raw = {0u, 0u, 0u, 0u};
     if (valid) raw = *(const u32x4*)(rowp + v_col);
-    *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = raw;
+    *(u32x4*)&vt_s[pass * 16 + rloc][sub * 8] = IN_F16 ? f16x8_to_bf16x8(raw) : raw;
   }
   __syncthreads();
   // V^T byte image: thread -> (d, 16 consecutive byte positions of the 64-key tile row)
@@ -762,7 +779,7 @@ extern "C" int lx_ln_modulate_lora_segs(const float* X, int ldx, const lx_ln_seg
 }
 
 static int qkv_launch(void* QKV, int ld, int q_col, int k_col, int v_col, QkvSegs& segs, int n_batches, int H, float eps, void* VT,
-                      int vt_ld, void* stream) {
+                      int vt_ld, void* stream, bool in_f16 = false) {
   LX_CHECK_ARG(QKV && n_batches > 0 && H > 0, "lx_qkv_prep: bad arguments");
   LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep: ld and column offsets must be multiples of 8");
   if (VT) LX_CHECK_ARG(vt_ld % 64 == 0, "lx_qkv_prep: vt_ld must be a multiple of 64");
@@ -777,7 +794,9 @@ static int qkv_launch(void* QKV, int ld, int q_col, int k_col, int v_col, QkvSeg
   segs.tile0[segs.n] = t;
   bool fast = true;
   for (int i = 0; i < segs.n; ++i) fast = fast && segs.wq[i] && segs.wk[i] && segs.cos_tab[i];
-  if (fast) hipLaunchKernelGGL(qkv_prep_kernel<true>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col,
+  if (in_f16) hipLaunchKernelGGL((qkv_prep_kernel<false, true>), dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col,
+                                 k_col, v_col, segs, eps, (uint16_t*)VT, vt_ld, H);
+  else if (fast) hipLaunchKernelGGL(qkv_prep_kernel<true>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col,
                                v_col, segs, eps, (uint16_t*)VT, vt_ld, H);
   else hipLaunchKernelGGL(qkv_prep_kernel<false>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (uint16_t*)QKV, ld, q_col, k_col,
                           v_col, segs, eps, (uint16_t*)VT, vt_ld, H);
@@ -796,8 +815,8 @@ extern "C" int lx_qkv_prep(void* QKV, int ld, int q_col, int k_col, int v_col, i
   return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_rows / rows_per_batch, H, eps, VT, vt_ld, stream);
 }
 
-extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
-                                int H, float eps, void* VT, int vt_ld, void* stream) {
+static int qkv_segs_launch(bool in_f16, void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                           int H, float eps, void* VT, int vt_ld, void* stream) {
   LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_qkv_prep_segs: 1..3 segments");
   QkvSegs segs;
   segs.n = n_seg;
@@ -805,12 +824,22 @@ extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_c
     segs.row0[i] = seg[i].row0; segs.rows_per_batch[i] = seg[i].rows_per_batch; segs.vt_pos0[i] = seg[i].vt_pos0;
     segs.wq[i] = seg[i].wq; segs.wk[i] = seg[i].wk; segs.cos_tab[i] = seg[i].cos_tab; segs.sin_tab[i] = seg[i].sin_tab;
   }
-  return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_batches, H, eps, VT, vt_ld, stream);
+  return qkv_launch(QKV, ld, q_col, k_col, v_col, segs, n_batches, H, eps, VT, vt_ld, stream, in_f16);
 }
 
-extern "C" int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
-                                    int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
-                                    float q_scale, float k_scale, float v_scale, void* stream) {
+extern "C" int lx_qkv_prep_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                                int H, float eps, void* VT, int vt_ld, void* stream) {
+  return qkv_segs_launch(false, QKV, ld, q_col, k_col, v_col, seg, n_seg, n_batches, H, eps, VT, vt_ld, stream);
+}
+
+extern "C" int lx_qkv_prep_f16in_segs(void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg, int n_batches,
+                                      int H, float eps, void* VT, int vt_ld, void* stream) {
+  return qkv_segs_launch(true, QKV, ld, q_col, k_col, v_col, seg, n_seg, n_batches, H, eps, VT, vt_ld, stream);
+}
+
+static int qkv_fp8_segs_launch(bool in_f16, const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                               int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                               float q_scale, float k_scale, float v_scale, void* stream) {
   LX_CHECK_ARG(seg && n_seg >= 1 && n_seg <= 3, "lx_qkv_prep_fp8_segs: 1..3 segments");
   LX_CHECK_ARG(QKV && Q8 && K8 && VT8 && n_batches > 0 && H > 0, "lx_qkv_prep_fp8_segs: bad arguments");
   LX_CHECK_ARG(ld % 8 == 0 && q_col % 8 == 0 && k_col % 8 == 0 && v_col % 8 == 0, "lx_qkv_prep_fp8_segs: ld and column offsets must be multiples of 8");
@@ -829,10 +858,26 @@ extern "C" int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_co
     t += (segs.rows_per_batch[i] + 63) / 64;
   }
   segs.tile0[n_seg] = t;
-  hipLaunchKernelGGL(qkv_prep_fp8_kernel, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QKV, ld, q_col, k_col,
-                     v_col, segs, eps, (uint8_t*)Q8, (uint8_t*)K8, ld8, (uint8_t*)VT8, vt8_ld, H, q_scale, k_scale, v_scale);
+  if (in_f16) hipLaunchKernelGGL(qkv_prep_fp8_kernel<true>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QKV, ld, q_col,
+                                 k_col, v_col, segs, eps, (uint8_t*)Q8, (uint8_t*)K8, ld8, (uint8_t*)VT8, vt8_ld, H, q_scale, k_scale, v_scale);
+  else hipLaunchKernelGGL(qkv_prep_fp8_kernel<false>, dim3(t, H, n_batches), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QKV, ld, q_col,
+                          k_col, v_col, segs, eps, (uint8_t*)Q8, (uint8_t*)K8, ld8, (uint8_t*)VT8, vt8_ld, H, q_scale, k_scale, v_scale);
   LX_LAUNCH_CHECK("lx_qkv_prep_fp8_segs");
   return LX_OK;
+}
+
+extern "C" int lx_qkv_prep_fp8_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                                    int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                                    float q_scale, float k_scale, float v_scale, void* stream) {
+  return qkv_fp8_segs_launch(false, QKV, ld, q_col, k_col, v_col, seg, n_seg, n_batches, H, eps, Q8, K8, ld8, VT8, vt8_ld, q_scale, k_scale, v_scale,
+                             stream);
+}
+
+extern "C" int lx_qkv_prep_fp8_f16in_segs(const void* QKV, int ld, int q_col, int k_col, int v_col, const lx_qkv_seg* seg, int n_seg,
+                                          int n_batches, int H, float eps, void* Q8, void* K8, int ld8, void* VT8, int vt8_ld,
+                                          float q_scale, float k_scale, float v_scale, void* stream) {
+  return qkv_fp8_segs_launch(true, QKV, ld, q_col, k_col, v_col, seg, n_seg, n_batches, H, eps, Q8, K8, ld8, VT8, vt8_ld, q_scale, k_scale, v_scale,
+                             stream);
 }
 
 static int lora_down_launch(const char* name, bool f16, const void* X, int ldx, const void* Adown, float* T, int ldt, int M, int K, int R, int n_split,

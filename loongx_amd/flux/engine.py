@@ -179,29 +179,44 @@ class DiTEngine:
             self.VT8 = torch.zeros(self.VT.shape, dtype=u8, device=self.device)
 
     def _setup_f16(self) -> None:
-        """fp16 images of every weight a GEMM of the forward reads (block weights, embedders, final projection: +17 GB at FLUX.1-dev scale;
-        the stacked modulation weights stay bf16 -- their activations are bf16 hi / lo pairs already) and of the LoRA down-projections,
-        built once per weight set. bf16 -> fp16 is exact for |w| >= 2^-14 and to 2^-24 absolute below (fp16 subnormals, which the MFMA
-        honours: tests/test_f16_gpu.py); the share of weights that lose bits is kept in `w16_inexact_share`."""
+        """fp16 images of every weight a GEMM of the forward reads (block weights, embedders, final projection: +17 GB at FLUX.1-dev scale,
+        resident while the engine is in the fp16 operand mode and released by the first conditioning that selects bf16 operands; the stacked
+        modulation weights stay bf16 -- their activations are bf16 hi / lo pairs already) and of the LoRA down-projections, built once
+        per weight set (the key holds the weights' version counters: a broadcast or a new adapter rebuilds them at the next conditioning or
+        forward). bf16 -> fp16 is exact for 2^-14 <= |w| <= 65504 and to 2^-24 absolute below (fp16 subnormals, which the MFMA honours:
+        tests/test_f16_gpu.py); the share of weights that lose bits is kept in `w16_inexact_share`. A weight beyond fp16's range is
+        SATURATED to +-65504, never turned into inf, and counted in `w16_clipped` -- which f16_overflow_poll() reports with the activations'
+        saturation counter, so the product's f16_overflow policy sees it. One host synchronisation per weight set."""
         if self.f16_ovf is None:
             self.f16_ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
         key = (id(self.w), getattr(self.w, "weights_version", 0), getattr(self.w, "lora_version", 0), len(self.w.lora))
         if self.w16 and self._w16_key == key:
             return
         self.w16 = {}
-        lost = total = 0
+        self._w16_gen = getattr(self, "_w16_gen", 0) + 1          # part of the step graphs' key: they hold the images' addresses
+        stat = torch.zeros(2, dtype=torch.int64, device=self.device)      # [values that lost bits, values clipped]
+        total = 0
+
+        def image(W):
+            h = W.float().clamp_(-65504.0, 65504.0).to(torch.float16)
+            back = h.to(W.dtype)
+            stat[0] += (back != W).sum()
+            stat[1] += (W.float().abs() > 65504.0).sum()
+            return h
+
         for name, W in self.w.t.items():
             if not name.endswith(".w") or name.startswith("mod.") or name.startswith("tte.") or W.dtype != torch.bfloat16:
                 continue
-            h = W.to(torch.float16)
+            h = image(W)
             if getattr(W, "lx_tiled", False):
                 h.lx_tiled = True                          # an elementwise conversion keeps the tiled image
-            lost += int((h.to(torch.bfloat16) != W).sum())
             total += W.numel()
             self.w16[name[:-2]] = h
         for name, lo in self.w.lora.items():
-            self.w16[name + ".down"] = lo.down.to(torch.float16)
+            self.w16[name + ".down"] = image(lo.down)
+        lost, clipped = (int(v) for v in stat.tolist())
         self.w16_inexact_share = lost / max(total, 1)
+        self.w16_clipped = clipped
         self._w16_key = key
 
     def f16_overflow_count(self, reset: bool = True) -> int:
@@ -210,9 +225,39 @@ class DiTEngine:
         if self.f16_ovf is None:
             return 0
         n = int(self.f16_ovf.item())
-        if reset and n:
-            self.f16_ovf.zero_()
+        if reset:
+            self._ovf_event, self._ovf_seen = None, 0          # (an asynchronous read still in flight would report what this call reported)
+            if n:
+                self.f16_ovf.zero_()
         return n
+
+    def f16_overflow_poll(self, sync: bool = False) -> int:
+        """What the product does with the fp16 mode's saturation counter (generate() applies model_config["f16_overflow"] to the result): the
+        number of saturation events not yet reported -- producer waves that clipped an activation to +-65504 (GEMM 16-bit stores, the
+        LayerNorm launches, the attention output) plus the weights `_setup_f16` had to clip (those count on every call: every image
+        computed with them is affected). The reference clips its fp16 activations silently (block.py:275-276, 336-337); here a clipped
+        operand is an event the caller hears about. 0 outside the fp16 operand mode.
+        sync=True drains the stream and reads the counter now. sync=False costs no synchronisation -- the check_status(sync=False)
+        pattern: it looks at the value copied to pinned host memory by the previous call, if that copy has landed, and enqueues the next
+        copy, so an event surfaces at most one call late."""
+        if not self.f16 or self.f16_ovf is None:
+            return 0
+        wclip = int(getattr(self, "w16_clipped", 0))
+        if sync:
+            return self.f16_overflow_count(reset=True) + wclip
+        if getattr(self, "_ovf_host", None) is None:
+            self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._ovf_event, self._ovf_seen = None, 0
+        n = 0
+        if self._ovf_event is not None and self._ovf_event.query():
+            self._ovf_event = None
+            total = int(self._ovf_host[0])
+            n, self._ovf_seen = max(total - self._ovf_seen, 0), total          # the device counter runs on: nothing is reset behind the kernels' back
+        if self._ovf_event is None:
+            self._ovf_host.copy_(self.f16_ovf, non_blocking=True)
+            self._ovf_event = torch.cuda.Event()
+            self._ovf_event.record()
+        return n + wclip
 
     def set_lora_scale(self, s: float) -> None:
         """Multiplier on every adapter term (reference lora_controller.py: scale_layer). Changes what the captured step graphs
@@ -517,6 +562,8 @@ class DiTEngine:
         self.f16 = fmt in ("fp16", "f16", "float16") and not self.precise and not self.gemm_fp8
         if self.f16:
             self._setup_f16()
+        elif self.w16:
+            self.w16, self.graphs = {}, {}                 # leaving the fp16 operand mode: its 17 GB of weight images (and the graphs that read them) go
 
     def _op_dtype(self):
         return torch.float16 if self.f16 else torch.bfloat16
@@ -700,7 +747,7 @@ class DiTEngine:
             # the 64-deep f8f6f4 MFMA; softmax statistics and the output accumulators stay fp32 (include/lx.h, lx_attn_fwd_fp8)
             self._fp8_images()
             if not prepped:                # otherwise the projection epilogue already wrote the three byte images
-                ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8)
+                ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8, in_f16=self.f16)
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                              seg_vt0=seg_vt0, bias=bias, flags=ops.ATTN_O_F16 if self.f16 else 0, **okw)
             return
@@ -712,7 +759,8 @@ class DiTEngine:
                          flags=flags, **okw)
             return
         if not prepped:                    # otherwise the projection launch already normalised / rotated k and q and wrote V^T
-            ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT)
+            # (fp16 operand mode: an unfused projection stored k | v | q as fp16 -- the pass reads them as such and leaves bf16 k / q, bf16 V^T)
+            ops.qkv_prep_segs(Y, 2 * D, 0, D, qsegs, B, H, self.VT, in_f16=self.f16)
         ops.attn_fwd(Y, Y, self.VT, Y, q_col=2 * D, k_col=0, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
                      seg_vt0=seg_vt0, bias=bias, flags=flags, **okw)
 
@@ -1144,6 +1192,8 @@ class DiTEngine:
         pre = step_index is not None and self.sched is not None
         if pre and not 0 <= step_index < len(self.sched[0]):
             raise IndexError(f"step_index {step_index} outside the prepared schedule of {len(self.sched[0])} steps")
+        if self.f16:
+            self._setup_f16()                # (a key comparison: weights broadcast or adapters installed after the conditioning get fresh images)
         timed = ops.TIMER is not None and ops.TIMER.next_call()      # event brackets need the eager launch path
         self.cond_cache = self._cond_cache_ok()
         skip = self.cond_cache and self.cond_cached            # the condition stream's keys / values of this conditioning are cached
@@ -1168,7 +1218,7 @@ class DiTEngine:
         key = (self.shape, tuple(sorted(self.model_config.items())), self.c_factor, pre, self.pair_plan, self.precise, self.gemm_fp8, self.f16,
                getattr(self.w, "q_log2_version", 0),      # (a weight broadcast refreshes the scaled norm_q tensors and the per-layer bounds)
                getattr(self.w, "weights_version", 0),     # (... and moves this one unconditionally: dist.broadcast_packed_weights)
-               self.cond_cache, skip, self.ln_lora, self.qkv_epilogue)
+               self.cond_cache, skip, self.ln_lora, self.qkv_epilogue, getattr(self, "_w16_gen", 0) if self.f16 else 0)
         g = self.graphs.get(key)
         if g is None:
             mode = (self.precise, self.gemm_fp8, self.f16, bool(self.model_config.get("attn_fp8", False)), self.latent_lora, self.C > 0, skip)

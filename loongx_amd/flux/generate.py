@@ -8,10 +8,15 @@ Differences from the reference, all deliberate and recorded in DESIGN.md (SURVEY
       lets each side replace its own embedding (EEG[+PPG] -> prompt_embeds, fNIRS[+Motion] -> pooled), which is what makes
       EEG-only conditioning (BASELINE configs[1]) take effect; bench.py / inference.py --synthetic ask for it explicitly;
   Q5  signals may carry a batch dimension ([B,C,L]); a [C,L] tensor is treated as batch 1 like the reference.
+  Q6  fp16 operand mode (model_config["operands"] = "fp16" / dtype float16): where the reference clips fp16 activations silently
+      (block.py:275-276, 336-337) the kernels saturate AND count; generate() reads the counter once per image and applies
+      model_config["f16_overflow"]: "raise" (default; F16OverflowError), "warn", or "fallback" (the image is computed again from the
+      same start latents with bf16 operands).
 """
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Any, Callable, Dict, List, Optional, Union
 
 import numpy as np
@@ -21,6 +26,13 @@ import yaml
 from .condition import Condition
 from .pipeline import FluxPipelineOutput, calculate_shift, retrieve_timesteps
 from .transformer import tranformer_forward
+
+
+F16_OVERFLOW_POLICIES = ("raise", "warn", "fallback")
+
+
+class F16OverflowError(RuntimeError):
+    """An operand of the fp16 operand mode left fp16's range (+-65504) and was saturated: the image is not what the mode promises."""
 
 
 def get_config(config_path: str = None):
@@ -176,30 +188,60 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
         sched_ts = (th / np.float32(1000)).tolist()
     else:
         sched_ts = (timesteps.to(latents.dtype) / 1000).tolist()
-    with self.progress_bar(total=num_inference_steps) as progress_bar:
-        for i, t in enumerate(timesteps):
-            if self.interrupt:
-                continue
-            timestep = t.expand(latents.shape[0]).to(latents.dtype)
-            noise_pred = tranformer_forward(
-                self.transformer, model_config=model_config,
-                condition_latents=condition_latents if use_condition else None,
-                condition_ids=condition_ids if use_condition else None,
-                condition_type_ids=condition_type_ids if use_condition else None,
-                hidden_states=latents, timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled_prompt_embeds,
-                encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
-                joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, lx_schedule=(i, sched_ts))[0]
-            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
-            if callback_on_step_end is not None:
-                scope = locals()                                        # (a comprehension has its own locals() before 3.12)
-                callback_kwargs = {}
-                for k in callback_on_step_end_tensor_inputs:
-                    callback_kwargs[k] = scope[k]
-                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
-                latents = callback_outputs.pop("latents", latents)
-                prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
-            if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
-                progress_bar.update()
+    engine = getattr(pipeline.transformer, "engine", None)
+    policy = str((model_config or {}).get("f16_overflow", "raise"))
+    if policy not in F16_OVERFLOW_POLICIES:
+        raise ValueError(f'model_config["f16_overflow"] = {policy!r}: one of {F16_OVERFLOW_POLICIES}')
+    start_latents, operands_used = latents, None
+
+    def denoise(latents, prompt_embeds, model_config):
+        with self.progress_bar(total=num_inference_steps) as progress_bar:
+            for i, t in enumerate(timesteps):
+                if self.interrupt:
+                    continue
+                timestep = t.expand(latents.shape[0]).to(latents.dtype)
+                noise_pred = tranformer_forward(
+                    self.transformer, model_config=model_config,
+                    condition_latents=condition_latents if use_condition else None,
+                    condition_ids=condition_ids if use_condition else None,
+                    condition_type_ids=condition_type_ids if use_condition else None,
+                    hidden_states=latents, timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled_prompt_embeds,
+                    encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
+                    joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False, lx_schedule=(i, sched_ts))[0]
+                latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+                if callback_on_step_end is not None:
+                    scope = dict(locals())                                  # (a comprehension has its own locals() before 3.12)
+                    callback_kwargs = {}
+                    for k in callback_on_step_end_tensor_inputs:
+                        callback_kwargs[k] = scope[k]
+                    callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                    latents = callback_outputs.pop("latents", latents)
+                    prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
+                if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
+                    progress_bar.update()
+        return latents
+
+    latents = denoise(start_latents, prompt_embeds, model_config)
+    if engine is not None and engine.f16:
+        # Q6: the saturation counter of this image's fp16 operand images. "fallback" has to know NOW, and a decode drains the stream anyway:
+        # one 4-byte synchronous read. Otherwise (latent output: the host runs ahead of the GPU) the pinned-host asynchronous read of
+        # check_status(sync=False) -- an event then surfaces at the next image's check; callers that keep latents end their loop with
+        # engine.f16_overflow_poll(sync=True) (inference.py does, per image, before it saves).
+        operands_used = "fp16"
+        n_sat = engine.f16_overflow_poll(sync=(policy == "fallback" or output_type != "latent"))
+        if n_sat:
+            what = (f"fp16 operand mode: {n_sat} saturation event(s) (producer waves that clipped an operand to +-65504, or clipped weights: "
+                    f"{getattr(engine, 'w16_clipped', 0)})")
+            if policy == "raise":
+                raise F16OverflowError(what + '; model_config["f16_overflow"] = "fallback" recomputes such images with bf16 operands, "warn" keeps them')
+            if policy == "warn":
+                warnings.warn(what + "; the image was kept", RuntimeWarning, stacklevel=2)
+            else:
+                warnings.warn(what + "; recomputing this image with bf16 operands", RuntimeWarning, stacklevel=2)
+                pipeline.transformer.invalidate_conditioning()
+                timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, None, sigmas, mu=mu)      # (step index back to 0)
+                latents = denoise(start_latents, prompt_embeds, dict(model_config or {}, operands="bf16"))
+                operands_used = "bf16 (fp16 overflow fallback)"
 
     if output_type == "latent":
         image = latents
@@ -227,4 +269,4 @@ def generate(model, pipeline, conditions: List[Condition] = None, config_path: s
             pipeline.transformer.engine.check_status(sync=False)
     if not return_dict:
         return (image,)
-    return FluxPipelineOutput(images=image)
+    return FluxPipelineOutput(images=image, lx_operands=operands_used)

@@ -116,7 +116,8 @@ def tranformer_forward(transformer: LxFluxTransformer, condition_latents: torch.
     mc = dict(model_config or {})
     key = (_tkey(encoder_hidden_states), _tkey(pooled_projections), _tkey(guidance), _tkey(txt_ids), _tkey(img_ids),
            _tkey(condition_latents), _tkey(condition_ids), float(c_t), tuple(sorted(mc.items())), transformer.c_factor,
-           hidden_states.shape[0])
+           hidden_states.shape[0], getattr(eng.w, "weights_version", 0), getattr(eng.w, "lora_version", 0))      # (a weight broadcast or a new
+    # adapter after the conditioning: the cached embedder outputs and modulations were computed from the old weights)
     if key != transformer._cond_key or not eng.cond_ready:
         eng.set_conditioning(encoder_hidden_states, pooled_projections, guidance, txt_ids, img_ids,
                              condition_latents if use_condition else None, condition_ids if use_condition else None,

@@ -319,15 +319,16 @@ def ln_modulate_segs(X, segs, Y, mod_ld, eps=1e-6, lora=None, f16_ovf=None) -> N
           "lx_ln_modulate_segs")
 
 
-def qkv_prep_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, VT, eps=1e-6) -> None:
-    """segs: list of (row0, rows_per_batch, vt_pos0, wq, wk, cos, sin); one launch."""
+def qkv_prep_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, VT, eps=1e-6, in_f16=False) -> None:
+    """segs: list of (row0, rows_per_batch, vt_pos0, wq, wk, cos, sin); one launch. in_f16: the q / k / v columns hold IEEE fp16 (the 16-bit
+    store of an fp16-operand projection without the fused epilogue); q / k are written back as bf16, V^T as bf16 either way."""
     n = len(segs)
     arr = (L.QkvSeg * n)()
     for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
         arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, vt0
         arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
-    check(lib.lx_qkv_prep_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, _p(VT),
-                               VT.shape[-1] if VT is not None else 0, _stream()), "lx_qkv_prep_segs")
+    fn, nm = (lib.lx_qkv_prep_f16in_segs, "lx_qkv_prep_f16in_segs") if in_f16 else (lib.lx_qkv_prep_segs, "lx_qkv_prep_segs")
+    check(fn(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, _p(VT), VT.shape[-1] if VT is not None else 0, _stream()), nm)
 
 
 def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale):
@@ -383,16 +384,17 @@ FP8_K_SCALE, FP8_V_SCALE = 16.0, 1.0
 FP8_Q_SCALE = 2048.0 * (1.0 / math.sqrt(128.0)) * 1.4426950408889634 / FP8_K_SCALE
 
 
-def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8, eps=1e-6) -> None:
-    """segs as in qkv_prep_segs; Q8 / K8: uint8 [rows, H*128]; VT8: uint8 [B, H, 128, Spad]. The bf16 QKV buffer is not modified."""
+def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8, eps=1e-6, in_f16=False) -> None:
+    """segs as in qkv_prep_segs; Q8 / K8: uint8 [rows, H*128]; VT8: uint8 [B, H, 128, Spad]. The 16-bit QKV buffer (bf16, or fp16 with
+    in_f16) is not modified."""
     n = len(segs)
     arr = (L.QkvSeg * n)()
     for i, (row0, rpb, vt0, wq, wk, cos, sin) in enumerate(segs):
         arr[i].row0, arr[i].rows_per_batch, arr[i].vt_pos0 = row0, rpb, vt0
         arr[i].wq, arr[i].wk, arr[i].cos_tab, arr[i].sin_tab = _p(wq), _p(wk), _p(cos), _p(sin)
-    check(lib.lx_qkv_prep_fp8_segs(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, Q8.data_ptr(),
-                                   K8.data_ptr(), Q8.stride(0), VT8.data_ptr(), VT8.shape[-1], FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE,
-                                   _stream()), "lx_qkv_prep_fp8_segs")
+    fn, nm = (lib.lx_qkv_prep_fp8_f16in_segs, "lx_qkv_prep_fp8_f16in_segs") if in_f16 else (lib.lx_qkv_prep_fp8_segs, "lx_qkv_prep_fp8_segs")
+    check(fn(QKV.data_ptr(), QKV.stride(0), q_col, k_col, v_col, arr, n, n_batches, H, eps, Q8.data_ptr(), K8.data_ptr(), Q8.stride(0),
+             VT8.data_ptr(), VT8.shape[-1], FP8_Q_SCALE, FP8_K_SCALE, FP8_V_SCALE, _stream()), nm)
 
 
 def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, flags=0, f16_ovf=None, qseg_mask=0) -> None:

@@ -271,6 +271,48 @@ def test_tiny_forward_f16_operands_against_the_oracle(ops, mc):
     assert lx.engine.w16_inexact_share < 1e-3
 
 
+@pytest.mark.parametrize("case", ["epilogue_off", "ragged", "ragged_attn_fp8"])
+def test_f16_operands_without_the_fused_projection_epilogue(ops, case):
+    """The fp16 operand mode where LX_EPI_QKV is not taken (round-5 advisor finding: the separate pass used to read the fp16 k | v | q
+    store as bf16): qkv_epilogue switched off at fused-capable shapes, and stream lengths that are no multiple of 32 (T = 24 text tokens,
+    a 6 x 5 latent grid: 30 image + 30 condition tokens, as 720 x 480 gives 1350). lx_qkv_prep_f16in_segs / lx_qkv_prep_fp8_f16in_segs
+    read the projection as fp16; the result has to land where the fused form lands against the fp32 oracle."""
+    from oracle import flux_modules as fm
+    from oracle import flux_ref as fr
+    from loongx_amd.flux.transformer import tranformer_forward
+    tr, lx = _tiny_pair(seed=5)
+    g = torch.Generator().manual_seed(4)
+    ragged = case.startswith("ragged")
+    B, T, gh, gw = 2, (24 if ragged else 32), (6 if ragged else 8), (5 if ragged else 8)
+    N = gh * gw
+    mc = {"attn_fp8": True} if case.endswith("attn_fp8") else {}
+    kw = dict(hidden_states=torch.randn(B, N, 64, generator=g), encoder_hidden_states=torch.randn(B, T, 64, generator=g) * 0.5,
+              pooled_projections=torch.randn(B, 32, generator=g), timestep=torch.tensor([0.6, 0.2]),
+              img_ids=fm.prepare_latent_image_ids(gh, gw), txt_ids=torch.zeros(T, 3), guidance=torch.full((B,), 3.5))
+    cond = torch.randn(B, N, 64, generator=g)
+    cids = fm.prepare_latent_image_ids(gh, gw)
+    cids[:, 2] -= gw
+    with torch.no_grad():
+        want = fr.tranformer_forward(tr, cond, cids, None, {}, **kw)[0]
+    lx.engine.qkv_epilogue = case != "epilogue_off"
+    errs = {}
+    try:
+        for fmt in ("bf16", "fp16"):
+            lx.invalidate_conditioning()
+            got = tranformer_forward(lx, cond.cuda(), cids.cuda(), None, dict(mc, operands=fmt), return_dict=False, **{k: v.cuda() for k, v in kw.items()})[0]
+            assert not lx.engine._qkv_epilogue()                       # the separate pass is what ran
+            assert torch.isfinite(got).all()
+            errs[fmt] = relerr(got.cpu(), want)
+        assert lx.engine.f16 and lx.engine.f16_overflow_count() == 0
+    finally:
+        lx.engine.qkv_epilogue = True
+    if mc:
+        assert errs["fp16"] < errs["bf16"] and errs["fp16"] < 7e-2, errs
+    else:
+        # the unfused form rounds k / q twice (fp16 store, then bf16 after RMSNorm + RoPE): the bound of the fused form, a little wider
+        assert errs["fp16"] < 1.5e-3 and errs["fp16"] < errs["bf16"] / 3, errs
+
+
 def test_f16_default_from_dtype_and_block_level_mirrors(ops):
     """operands_default = "fp16" (what dtype=torch.float16 selects) runs the mode without a model_config entry, a call can still ask for
     bf16, and the engine's block-level accessors read the fp16 images as such."""
@@ -293,3 +335,106 @@ def test_f16_default_from_dtype_and_block_level_mirrors(ops):
     with pytest.raises(ValueError):
         lx.invalidate_conditioning()
         tranformer_forward(lx, None, None, None, {"operands": "fp8"}, return_dict=False, **kw)
+
+
+# ---- the PRODUCT's handling of a saturated fp16 operand (generate() / model_config["f16_overflow"]) ---------------------------------------
+def _planted_model(bias_value=None, weight_value=None):
+    """The tiny three-stream model behind generate(), with one value planted through the WEIGHTS that leaves fp16's range on the way:
+    an ff.net[0] bias of 1e5 (the MLP hidden's 16-bit store saturates at run time), or a q/k/v weight of 1e5 (the weight image itself)."""
+    from oracle import cs3 as ocs3
+    from loongx_amd.flux.pipeline import LxFluxPipeline
+    from loongx_amd.flux.transformer import LxFluxTransformer
+    from loongx_amd.flux.weights import FluxConfig
+    from loongx_amd.train.model import OminiModel
+    from oracle import flux_modules as fm
+    tr = fm.FluxTransformer2DModel(num_layers=2, num_single_layers=2, heads=2, head_dim=128, in_channels=64, joint_dim=4096,
+                                   pooled_dim=768, guidance_embeds=True, lora=True)
+    fm.init_synthetic_(tr, seed=4, std=0.03, bias_std=0.02, norm_jitter=0.1)
+    with torch.no_grad():
+        if bias_value is not None:
+            tr.transformer_blocks[0].ff.net[0].proj.bias[5] = bias_value
+        if weight_value is not None:
+            lin = tr.transformer_blocks[1].attn.to_q
+            getattr(lin, "base_layer", lin).weight[3, 7] = weight_value
+    cfg = FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, in_channels=64, joint_attention_dim=4096,
+                     pooled_projection_dim=768, guidance_embeds=True)
+    torch.manual_seed(0)
+    cs3 = ocs3.CS3DGF(seed=0).eval()
+    lxtr = LxFluxTransformer.from_state_dict(tr.eval().state_dict(), cfg, "cuda")
+    return OminiModel.from_pipe(LxFluxPipeline(lxtr), cs3.state_dict(), {}, "cuda")
+
+
+def _gen(model, mc, seed=3):
+    from loongx_amd.flux.condition import Condition
+    from loongx_amd.flux.generate import generate
+    g = torch.Generator().manual_seed(seed)
+    hw = 8
+    lat, cond = torch.randn(1, hw * hw, 64, generator=g), torch.randn(1, hw * hw, 64, generator=g)
+    pe, pooled = torch.randn(1, 512, 4096, generator=g) * 0.1, torch.randn(1, 768, generator=g)
+    c = Condition("subject", latents=cond.cuda(), latent_hw=(hw, hw), position_delta=[0, -hw])
+    return generate(model, model.flux_pipe, conditions=[c], height=hw * 16, width=hw * 16, num_inference_steps=4, latents=lat.cuda(),
+                    prompt_embeds=pe.cuda(), pooled_prompt_embeds=pooled.cuda(), output_type="latent", model_config=mc, default_lora=True,
+                    use_brain_condition=False)
+
+
+def test_generate_applies_the_f16_overflow_policy_to_a_saturated_activation(ops):
+    """Round-5 verdict: the kernels saturate and count, but the PRODUCT never read the counter. A bias of 1e5 on ff.net[0] of the first
+    double block drives one MLP-hidden channel past 65504: under "raise" generate() (latent output: asynchronous read) surfaces it at the
+    next image at the latest and the synchronous poll at once; "warn" keeps the image and says so; "fallback" recomputes the image with
+    bf16 operands -- bit-equal to asking for bf16 in the first place. A clean model raises nothing under any policy."""
+    import warnings as _w
+    from loongx_amd.flux.generate import F16OverflowError
+    model = _planted_model(bias_value=1.0e5)
+    eng = model.transformer.engine
+    want_bf16 = _gen(model, {"operands": "bf16"}).images.clone()
+    assert not eng.w16                                            # the bf16 call left no fp16 weight images behind
+    # raise: the first image returns (its counter read is in flight), the synchronous poll -- what inference.py does before saving -- reports
+    out = _gen(model, {"operands": "fp16", "f16_overflow": "raise"})
+    assert out.lx_operands == "fp16" and eng.f16
+    torch.cuda.synchronize()
+    with pytest.raises(F16OverflowError):
+        _gen(model, {"operands": "fp16", "f16_overflow": "raise"})         # the landed read of image 1 (and image 2's own events)
+    assert eng.f16_overflow_poll(sync=True) > 0                             # image 2 ran: its events are there for the synchronous reader
+    assert eng.f16_overflow_poll(sync=True) == 0                            # ... and were consumed
+    # warn: synchronous path not needed -- the second call sees the first one's read
+    with _w.catch_warnings(record=True) as rec:
+        _w.simplefilter("always")
+        _gen(model, {"operands": "fp16", "f16_overflow": "warn"})
+        torch.cuda.synchronize()
+        out = _gen(model, {"operands": "fp16", "f16_overflow": "warn"})
+    assert any("saturation" in str(r.message) for r in rec) and out.lx_operands == "fp16"
+    eng.f16_overflow_poll(sync=True)
+    # fallback: decided per image, synchronously
+    with pytest.warns(RuntimeWarning, match="recomputing this image with bf16 operands"):
+        out = _gen(model, {"operands": "fp16", "f16_overflow": "fallback"})
+    assert out.lx_operands.startswith("bf16") and torch.equal(out.images, want_bf16)
+    with pytest.raises(ValueError):
+        _gen(model, {"operands": "fp16", "f16_overflow": "ignore"})
+    # inference.py's pre-save check
+    import inference as inf
+    _gen(model, {"operands": "fp16", "f16_overflow": "warn"})
+    with pytest.raises(F16OverflowError):
+        inf._f16_checked(eng, {"f16_overflow": "raise"})
+    # a clean model: no event under any policy, the image is the fp16 one
+    clean = _planted_model()
+    with _w.catch_warnings():
+        _w.simplefilter("error")
+        for pol in ("raise", "warn", "fallback"):
+            o = _gen(clean, {"operands": "fp16", "f16_overflow": pol})
+            torch.cuda.synchronize()
+            assert o.lx_operands == "fp16"
+        assert clean.transformer.engine.f16_overflow_poll(sync=True) == 0
+
+
+def test_a_weight_beyond_fp16_range_is_saturated_counted_and_reported(ops):
+    """W.to(float16) turned |w| > 65504 into inf (then NaN) without a trace. The weight images saturate, `w16_clipped`
+    counts, and generate() reports it under the same policy -- on the FIRST image (the count is known on the host)."""
+    from loongx_amd.flux.generate import F16OverflowError
+    model = _planted_model(weight_value=1.0e5)
+    eng = model.transformer.engine
+    with pytest.raises(F16OverflowError, match="clipped weights: 1"):
+        _gen(model, {"operands": "fp16", "f16_overflow": "raise"})
+    assert eng.w16_clipped == 1 and all(torch.isfinite(v.float()).all() for v in eng.w16.values())
+    with pytest.warns(RuntimeWarning):
+        out = _gen(model, {"operands": "fp16", "f16_overflow": "fallback"})
+    assert out.lx_operands.startswith("bf16") and torch.isfinite(out.images).all()

@@ -1,4 +1,6 @@
 """CPU-only host logic: weight packing / LoRA installation (pure torch, no kernels) and the sigma schedule helpers."""
+import os
+
 import pytest
 import torch
 
@@ -197,3 +199,53 @@ def test_runtime_switches_are_the_documented_ones():
     rows = set(re.findall(r"^\| `(LX_[A-Z0-9_]+)`", table, flags=re.M))
     assert found == rows, (sorted(found - rows), sorted(rows - found))
     assert len(found) <= 15, sorted(found)
+
+
+def test_bench_line_is_bounded():
+    """Round 5's single JSON line grew to 21 KB and the driver's record of the round came back `parsed: null`. The final stdout line is
+    now built by bench.compact_line / bench.emit: worst case = the full round-5 records (headline + six legs with two parity records on the
+    largest), explanatory strings inflated, two legs failing with long error messages -- under 6 KB, one line, JSON round trip, the contract
+    fields and `roofline` / `cpu_baseline` present, every leg in `summary` with its tolerance verdict."""
+    import io
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = json.load(open(os.path.join(root, "profiles", "r05fin_bench_line.json")))
+    sec = r.pop("secondary")
+    r.pop("summary", None)
+    names = ["fp16_operands_b1", "realistic_stats_b1", "configs2_b16", "hw64_b4_bf16", "configs4_b4_attnfp8", "precise_b1"]
+    legs = list(zip(names, sec))
+    bench.stamp_tolerance(r["parity"], {})
+    assert r["parity"]["tolerance_ok"] is True and r["parity"]["tolerance_mode"] == "bf16"
+    for n, lg in legs:
+        mc = {"operands": "fp16"} if n.startswith("fp16") else {"attn_fp8": True} if "fp8" in n else {}
+        for v in (lg.get("parity") or {}).values():
+            bench.stamp_tolerance(v, mc, n.startswith("precise"), n.startswith("realistic"))
+            assert v["tolerance_ok"] is True, (n, v)
+    # inflate what a future edit is most likely to inflate
+    r["config"]["workload"] = r["config"]["workload"] * 4
+    r["roofline"]["kernel"] = r["roofline"]["kernel"] * 5
+    r["cpu_baseline"]["sample"] = r["cpu_baseline"]["sample"] * 3
+    legs.append(("extra_leg_a", {"error": "RuntimeError: " + "x" * 4000, "leg": "extra_leg_a"}))
+    legs.append(("extra_leg_b", {"error": "LxError: " + "y" * 4000, "leg": "extra_leg_b"}))
+    buf = io.StringIO()
+    sidecar = os.path.join(root, "bench_legs.json")
+    had = os.path.exists(sidecar)
+    bench.emit(r, legs, stream=buf)
+    if not had and os.path.exists(sidecar):
+        os.remove(sidecar)
+    out = buf.getvalue()
+    assert out.endswith("\n") and out.count("\n") == 1
+    line = out.strip()
+    assert len(line.encode()) <= bench.LINE_LIMIT < 8192, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity", "summary", "value_fp16_operands", "parity_fp16_operands"):
+        assert k in d, k
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert d["value_fp16_operands"] == sec[0]["value"] and d["parity_fp16_operands"]["ok"] is True
+    assert set(d["summary"]) == {"headline", *names, "extra_leg_a", "extra_leg_b"}
+    assert all(d["summary"][n].get("tolerance_ok") is True for n in names if n != "hw64_b4_bf16")
+    # a tolerance that is NOT held shows: the fp8-attention figures judged as the bf16 mode
+    bad = bench.stamp_tolerance(dict(sec[4]["parity"]["512x512"]), {})
+    assert bad["tolerance_ok"] is False

@@ -39,9 +39,39 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["global_batch"] == 2 and line["steps"] == 1
     assert 20 < line["config"]["weight_broadcast_GB"] < 30 and line["outputs_finite"] and line["value"] > 0
-    assert "secondary" not in line and "parity" not in line and "cpu_baseline" not in line       # N = 1 legs only
+    assert "value_fp16_operands" not in line and "parity" not in line and "cpu_baseline" not in line and set(line["summary"]) == {"headline"}   # N = 1 legs only
+    assert len(r.stdout.splitlines()[-1]) < 6144
     # two ranks time-share one GPU: the aggregate cannot exceed (and should be near) one GPU's rate
     assert 0.5 < line["value"] < 1.3, line["value"]
+
+
+def test_bench_eight_ranks_rehearsal_tiny_shapes_bit_equal_to_single_rank():
+    """The driver's 8-GPU scaling run must not be the first execution of the 8-rank path. `bench.py --gpus 8 --tiny` on ONE GPU (eight
+    ranks on device 0 over gloo): self-launch under torch.distributed.run, rank 0 draws the weights and the other seven receive them by
+    bucketed broadcast, shard by rank (every rank its own seed), barrier-bracketed timed region, max-over-ranks, all_gather of the per-rank
+    results, one bounded JSON line with n_gpus / scaling / rccl_ranks. Every rank's edited latents are BIT-equal to what one process
+    computes for that rank's seed (`--emulate-ranks 8`): data parallelism changes who computes an image, not the image.
+    The full-size run of the same command is profiles/r06_rehearsal8_line.json (23.85 GB broadcast in 1 GiB buckets)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--tiny", "--steps", "1", "--warmup", "1", "--hash-latents", "--no-roofline-events"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--emulate-ranks", "8"] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.splitlines()[-1])
+    want = single["config"]["latent_sha16"]
+    assert len(want) == 8 and len(set(want)) == 8                       # eight different images
+    env.update(LX_DIST_ONE_DEVICE="1", LX_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.splitlines()[-1]
+    assert len(last) < 6144
+    line = json.loads(last)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["rccl_ranks"] == 8 and line["config"]["global_batch"] == 8
+    assert line["config"]["parallelism"] == "dp8" and line["config"]["weight_broadcast_GB"] > 0 and line["outputs_finite"] and line["value"] > 0
+    assert "not the metric" in line["metric"] and "--tiny" in line["config"]["workload"]
+    assert line["config"]["latent_sha16"] == want, (line["config"]["latent_sha16"], want)
 
 
 def test_inference_cli_two_workers_rehearsal_on_one_gpu(tmp_path):

@@ -23,8 +23,10 @@ pytestmark = pytest.mark.gpu
 # A operands of the GEMMs, every kind in proportion to its share of the flops (ff1 2.3e-3, ff2 2.3e-3, single proj_out 1.7e-3, fused
 # single projection 1.5e-3, to_out 1.1e-3, q/k/v 3.5e-4 alone; attention's q / k / v / P together 4.1e-4), adding in quadrature -- no
 # subset cheaper than precise mode brings it under 2e-3.
-BF16_NOISE_PRED_MAX = 6.0e-3
-BF16_FINAL_LATENT = 1.0e-3
+from loongx_amd.tolerances import TOLERANCES  # noqa: E402  (the stated numbers live in ONE module: bench.py stamps its legs with the same ones)
+
+BF16_NOISE_PRED_MAX = TOLERANCES["bf16"]["per_forward_max"]          # 6.0e-3
+BF16_FINAL_LATENT = TOLERANCES["bf16"]["final"]                      # 1.0e-3
 
 
 def test_full_depth_parity_bf16():
@@ -56,8 +58,8 @@ def test_full_depth_parity_bf16_with_the_brain_side(brain):
 # ---- fp16 operand images (round 5) -----------------------------------------------------------------------------------------------
 # tools/bf16_ablation.py (profiles/r05a_fp16_ablation.txt) predicts 7.0e-4 per forward for fp16 GEMM A operands + bf16 attention operands
 # from the fp32 oracle alone; the north star's bound is 1e-3 per forward.
-F16_NOISE_PRED_MAX = 1.0e-3
-F16_FINAL_LATENT = 2.0e-4
+F16_NOISE_PRED_MAX = TOLERANCES["fp16"]["per_forward_max"]           # 1.0e-3
+F16_FINAL_LATENT = TOLERANCES["fp16"]["final"]                       # 2.0e-4
 
 
 @pytest.mark.parametrize("brain", [None, "eeg"])
@@ -82,7 +84,8 @@ def test_full_depth_parity_fp16_operands(brain):
 # where the gain is large), outlier channels in the residual stream (x100-x1000) and in every MLP hidden layer, non-zero biases everywhere.
 # Bounds = 2x what the MI355X measured (round 5, profiles/r05g_parity_realistic.txt), per mode.
 # Measured: bf16 2.48e-3 per forward (max) / 3.9e-4 final latents; fp16 3.05e-4 / 3.9e-5; precise 4e-6 / 1e-6; 35 of 57 layers bounded.
-REALISTIC_BOUNDS = {"bf16": (5.0e-3, 8.0e-4), "fp16": (6.5e-4, 1.0e-4), "precise": (2.0e-5, 5.0e-6)}      # (per forward max, final latents)
+REALISTIC_BOUNDS = {m: (TOLERANCES["realistic_" + m]["per_forward_max"], TOLERANCES["realistic_" + m]["final"]) for m in ("bf16", "fp16", "precise")}
+# = {"bf16": (5.0e-3, 8.0e-4), "fp16": (6.5e-4, 1.0e-4), "precise": (2.0e-5, 5.0e-6)}      (per forward max, final latents)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16", "precise"])
@@ -114,9 +117,9 @@ def test_full_depth_parity_realistic_stats(mode):
 # 1024x1024: 6.3e-3 / 6.6e-3 / 1.4e-3.
 # The e4m3 GEMMs (model_config gemm_fp8, `bench.py --fp8`) do NOT hold it -- 1.0e-1 per forward, whatever the scaling recipe
 # (tools/fp8_ablation.py, profiles/r03a_fp8_ablation.json) -- and are kept as an explicitly lossy option.
-FP8_ATTN_NOISE_PRED_MEAN = 1.0e-2
-FP8_ATTN_NOISE_PRED_MAX = 1.1e-2
-FP8_ATTN_FINAL_LATENT = 2.0e-3
+FP8_ATTN_NOISE_PRED_MEAN = TOLERANCES["attn_fp8"]["per_forward_mean"]      # 1.0e-2
+FP8_ATTN_NOISE_PRED_MAX = TOLERANCES["attn_fp8"]["per_forward_max"]        # 1.1e-2
+FP8_ATTN_FINAL_LATENT = TOLERANCES["attn_fp8"]["final"]                    # 2.0e-3
 
 
 @pytest.mark.parametrize("brain", [None, "all"])
@@ -130,19 +133,30 @@ def test_full_depth_parity_fp8_attention_512(brain):
     assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT and rec["final_latent_cosine"] > 0.99999, rec
 
 
-def test_full_depth_parity_fp8_attention_1024():
-    """The shape configs[4] names: 1024x1024 (S = 8704), all 57 blocks, on an 8-step schedule (an fp32 oracle forward at this size is
-    1.5 s on the GPU: the 28-step run of the same comparison is the `configs4_b4_attnfp8` leg of the bench line -- 6.5e-3 / 6.7e-3 / 1.4e-3 --
-    and was this test until round 5, 47 s of the suite): teacher-forced comparison at every 2nd step + the free-running loop."""
+def test_full_depth_parity_fp8_attention_1024_precheck_8_steps():
+    """A quick pre-check of the shape configs[4] names (1024x1024, S = 8704, all 57 blocks) on an 8-step schedule: the per-forward figures
+    do not depend on the schedule and are held to the stated bounds; the free-running latents do (eight steps of 1/8 carry each
+    forward's error further than 28 of 1/28: measured 2.2e-3), so THEIR stated bound is asserted by the 28-step test below, not here."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle.parity import full_depth_parity
     rec = full_depth_parity("cuda:0", steps=8, every=2, hw=64, model_config={"union_cond_attn": True, "attn_fp8": True})
+    print("PARITY_FP8ATTN_1024_8STEP " + json.dumps(rec))
+    assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= FP8_ATTN_NOISE_PRED_MAX, rec
+    assert rec["final_latent_cosine"] > 0.99999, rec
+
+
+def test_full_depth_parity_fp8_attention_1024():
+    """The shape configs[4] names -- 1024x1024 (S = 8704), all 57 blocks -- on the metric's 28-step schedule, held to the STATED bounds
+    (round 5 had cut this to 8 steps with widened bounds to save 33 s; the stated numbers are asserted again): teacher-forced comparison
+    at every 3rd step + the free-running loop. An fp32 oracle forward at this size is 1.5 s on the GPU: ~45 s, once per process."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=3, hw=64, model_config={"union_cond_attn": True, "attn_fp8": True})
     print("PARITY_FP8ATTN_1024 " + json.dumps(rec))
-    assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= 1.2e-2, rec
-    # the per-forward figures do not depend on the schedule (6.2e-3 / 6.5e-3 here, 6.5e-3 / 6.7e-3 over 28 steps); the free-running latents do:
-    # eight steps of 1/8 carry each forward's error further than 28 of 1/28 -- measured 2.2e-3 (28 steps: 1.4e-3 against the stated 2e-3)
-    assert rec["final_latent_relerr"] <= 3.0e-3 and rec["final_latent_cosine"] > 0.99999, rec
+    assert rec["noise_pred_relerr_mean"] <= FP8_ATTN_NOISE_PRED_MEAN and rec["noise_pred_relerr_max"] <= FP8_ATTN_NOISE_PRED_MAX, rec
+    assert rec["final_latent_relerr"] <= FP8_ATTN_FINAL_LATENT and rec["final_latent_cosine"] > 0.99999, rec
 
 
 def test_fp8_gemm_mode_is_lossy_and_says_so():
