@@ -55,6 +55,21 @@ def test_full_depth_parity_bf16_with_the_brain_side(brain):
     assert rec["final_latent_relerr"] < BF16_FINAL_LATENT and rec["final_latent_cosine"] > 0.9995, rec
 
 
+def test_full_depth_parity_independent_condition():
+    """model_config["independent_condition"] (a reference option: block.py:115-120 masks the condition queries from text / image keys) is a
+    SUPPORTED product mode with its own execution plan: the condition stream is step-invariant, so the engine computes it in the first
+    denoise step and keeps its keys / values per layer (27 of 28 steps run 1536 instead of 2560 rows; the long-K projections of those steps
+    take lx_gemm4_kernel's three-way split form). Full depth, 28 steps, against the oracle run with the same option: the bf16 mode's stated
+    bounds -- the cached forwards (steps 1..27, teacher-forced at 9, 18, 27) included."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.parity import full_depth_parity
+    rec = full_depth_parity("cuda:0", steps=28, every=9, model_config={"union_cond_attn": True, "independent_condition": True})
+    print("PARITY_BF16_INDEPENDENT_CONDITION " + json.dumps(rec))
+    assert rec["noise_pred_relerr_max"] < BF16_NOISE_PRED_MAX, rec
+    assert rec["final_latent_relerr"] < BF16_FINAL_LATENT and rec["final_latent_cosine"] > 0.9995, rec
+
+
 # ---- fp16 operand images (round 5) -----------------------------------------------------------------------------------------------
 # tools/bf16_ablation.py (profiles/r05a_fp16_ablation.txt) predicts 7.0e-4 per forward for fp16 GEMM A operands + bf16 attention operands
 # from the fp32 oracle alone; the north star's bound is 1e-3 per forward.
