@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 /* ABI history:
+ *  0.4.3  + LX_ATTN_P_EXP2; lx_attn_fwd_fp8's default probability bytes are the log-linear code of the score (POW2 scales)
  *  0.4.2  + lx_qkv_prep_f16in_segs, lx_qkv_prep_fp8_f16in_segs (the separate RMSNorm + RoPE + V^T pass on a projection an LX_OPERANDS_F16
  *         launch stored as fp16: stream lengths LX_EPI_QKV does not take)
  *  0.4.1  + lx_ln_modulate_lora_f16_segs; lx_ln_modulate_lora_segs computes its down-projection on the matrix pipe (Adown 16-byte aligned);
@@ -39,7 +40,7 @@ extern "C" {
  *  0.3.0  lx_gemm_desc grew (LX_EPI_QKV e4m3 outputs: qkv_q8 ... qkv_v_scale, appended); + lx_qkv_prep_split_segs, lx_attn_fwd_split,
  *         lx_lora_down_terms
  *  0.2.0  caller-owned GEMM workspace, precise mode, VAE row kernels, channel-major fp32 GEMM */
-#define LX_VERSION 402
+#define LX_VERSION 403
 
 typedef enum lx_status {
   LX_OK = 0,
@@ -313,7 +314,10 @@ typedef struct lx_attn_desc {
 /* LX_ATTN_PREFER_4WAVE: take lx_attn4_kernel whenever the launch fits it (LX_ATTN_BOUNDED, addresses within its 32-bit offsets), whatever
  * the planner's shape rule says -- for benchmarks and tests of that kernel. LX_ATTN_INVARIANT is the opposite pin (always the 8-wave
  * kernels); the two together are rejected. */
-enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4, LX_ATTN_O_F16 = 8, LX_ATTN_PREFER_4WAVE = 16 };
+/* LX_ATTN_P_EXP2 (lx_attn_fwd_fp8 only): probabilities by v_exp_f32 + nearest-even e4m3 rounding. Without it (the default where the scales
+ * fold to a power of two, see lx_attn_fwd_fp8) the kernel takes each probability byte as the log-linear code of its score: one conversion
+ * instead of an exponential -- the chord of 2^f over a mantissa step instead of its rounding; results differ within the e4m3 step. */
+enum { LX_ATTN_Q_LOG2 = 1, LX_ATTN_BOUNDED = 2, LX_ATTN_INVARIANT = 4, LX_ATTN_O_F16 = 8, LX_ATTN_PREFER_4WAVE = 16, LX_ATTN_P_EXP2 = 32 };
 int lx_attn_fwd(const lx_attn_desc* d, void* stream);
 /* Which kernel the calling thread's last successful lx_attn_fwd launched (a planner decision, exposed for benchmarks and tests):
  * LX_ATTN_KERNEL_8WAVE: the 8-wave kernels of attn.hip (two waves per SIMD, 32 query rows per wave);

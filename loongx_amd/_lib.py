@@ -49,7 +49,7 @@ class AttnDesc(C.Structure):
                 ("qseg_mask", C.c_int32), ("f16_ovf", C.c_void_p)]
 
 
-LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT, LX_ATTN_O_F16, LX_ATTN_PREFER_4WAVE = 1, 2, 4, 8, 16
+LX_ATTN_Q_LOG2, LX_ATTN_BOUNDED, LX_ATTN_INVARIANT, LX_ATTN_O_F16, LX_ATTN_PREFER_4WAVE, LX_ATTN_P_EXP2 = 1, 2, 4, 8, 16, 32
 
 
 class AttnF32Desc(C.Structure):

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_pipe_kernel(const AttnArgs arg
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int BH = D.B * D.H;
-  const int bh = blockIdx.x % BH;
-  const int qt = blockIdx.x / BH;
+  int qt, bh;
+  lx_item_decode((int)blockIdx.x, (int)gridDim.x, BH, args.qt_start[3], qt, bh);
   const int b = bh / D.H, h = bh % D.H;
   int sq = 0;
 #pragma unroll
@@ -498,9 +498,23 @@ constexpr int STAGE8_BYTES = K8_BYTES + V8_BYTES;
 // loop body is expanded twice). The O rescale of a tile is applied at the head of the iteration that multiplies it in, K(t+2)
 // and V^T(t+1) are staged into the slots K(t) / V^T(t-1) vacated (one 1-KiB LDS-DMA piece per wave and operand), one barrier per
 // tile. Results differ from lx_attn_fp8_kernel only in rounding (row sums of rounded P, reference max one tile later).
-template <bool DEFER, bool POW2>
+// Round 6 (POW2 form): the probabilities carry a constant factor 2^P8_OFF (it cancels in O / l): a score at the reference becomes 2^6, the
+// deferred-rescale threshold drops from 8 to P8_THR = 2 (P <= 2^8 = 256 < 448 as before), and e4m3's normal range then reaches 12 octaves
+// BELOW the reference instead of 6 (flush to zero under 2^-15.5 of the reference instead of 2^-9.5): with thousands of keys per row the mass
+// that lives there is not negligible (tools/p_loglin.py: peaked rows lose 2-3x less).
+// LOGLIN: the vector pipe is this kernel's bottleneck and 32 v_exp_f32 per tile (quarter rate: 16 cycles each) + 16 v_cvt_pk_fp8_f32 are
+// half of its vector time. An e4m3 byte IS a piecewise-linear code of log2: byte = 8 * (exponent + 7) + mantissa, so for a normal value
+// byte ~ 8 log2(p) + 56. The score MFMAs therefore deliver y = 8 (s - reference) + 8 P8_OFF + 56 directly (MX block scale 2^(3-k), the
+// accumulator they start from holds the rest) and ONE v_cvt_pk_u8_f32 per score (saturating at 0: masked and far keys become zero) writes the
+// probability byte: p = 2^n (1 + m / 8) with m = the 3 leading bits of the score's fraction -- the chord of 2^f instead of its rounding
+// (at most 0.69 of a mantissa step above the true value, +0.46 on average: a constant factor, which cancels). No exp2, no fp8 conversion.
+constexpr float P8_OFF = 6.0f, P8_THR = 2.0f;
+template <bool DEFER, bool POW2, bool LOGLIN = false>
 __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs args, float qk_descale, float v_descale, int e8m0) {
+  static_assert(POW2 || !LOGLIN, "the log-linear probability bytes need the scores as they come out of the matrix pipe (POW2)");
   constexpr int QBLK = 256;
+  // POW2: a finished score y = YU * (s - reference, log2 units) + YZ
+  constexpr float YU = LOGLIN ? 8.0f : 1.0f, YZ = LOGLIN ? 8.0f * P8_OFF + 56.0f : P8_OFF;      // (v_cvt_pk_u8_f32 rounds to nearest even: tools/ubench/cvt_u8)
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE8_BYTES];      // K slot s at s*STAGE8, V^T slot s at s*STAGE8 + K8
   const lx_attn_desc& D = args.d;
   const int tid = threadIdx.x;
@@ -508,8 +522,8 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int BH = D.B * D.H;
-  const int bh = blockIdx.x % BH;
-  const int qt = blockIdx.x / BH;
+  int qt, bh;
+  lx_item_decode((int)blockIdx.x, (int)gridDim.x, BH, args.qt_start[3], qt, bh);
   const int b = bh / D.H, h = bh % D.H;
   int sq = 0;
 #pragma unroll
@@ -659,14 +673,20 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                                 \
       constexpr int kb_ = ((c) >> 1) & 1;                                                                              \
       const int rq_ = ((c) & 1) * 2 + q_;                                                                              \
-      float pv_[4];                                                                                                    \
-      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                               \
-        if constexpr (POW2) { float x_ = SCk[rq_ * 4 + e_]; asm volatile("" : "+v"(x_)); pv_[e_] = LX8_EXP2(x_); } \
-        else pv_[e_] = __builtin_amdgcn_exp2f(fmaf(SCk[rq_ * 4 + e_], c2, off));                                       \
+      if constexpr (LOGLIN) {          /* the score IS the byte: one saturating conversion per score, all four bytes of the word rewritten */ \
+        unsigned w_ = (unsigned)pfw[kb_ * 4 + rq_];                                                                    \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) w_ = __builtin_amdgcn_cvt_pk_u8_f32(SCk[rq_ * 4 + e_], e_, w_); \
+        pfw[kb_ * 4 + rq_] = (int)w_;                                                                                  \
+      } else {                                                                                                         \
+        float pv_[4];                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                             \
+          if constexpr (POW2) { float x_ = SCk[rq_ * 4 + e_]; asm volatile("" : "+v"(x_)); pv_[e_] = LX8_EXP2(x_); } \
+          else pv_[e_] = __builtin_amdgcn_exp2f(fmaf(SCk[rq_ * 4 + e_], c2, off));                                     \
+        }                                                                                                              \
+        int w_ = LX8_CVT(pv_[0], pv_[1], pfw[kb_ * 4 + rq_], false);   /* (old value: both halves are overwritten; a literal 0 costs a v_mov) */ \
+        w_ = LX8_CVT(pv_[2], pv_[3], w_, true);                                                                        \
+        pfw[kb_ * 4 + rq_] = w_;                                                                                       \
       }                                                                                                                \
-      int w_ = LX8_CVT(pv_[0], pv_[1], pfw[kb_ * 4 + rq_], false);   /* (old value: both halves are overwritten; a literal 0 costs a v_mov) */ \
-      w_ = LX8_CVT(pv_[2], pv_[3], w_, true);                                                                          \
-      pfw[kb_ * 4 + rq_] = w_;                                                                                         \
       asm volatile("" : "+v"(pfw[kb_ * 4 + rq_]));                                                                     \
     }                                                                                                                  \
   }
@@ -690,23 +710,24 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     asm volatile("" : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "+v"(mx[3]));                                             \
     float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx[0], mx[1]), mx[2]), mx[3]);                          \
     const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_), __float_as_uint(m_), false, false);         \
-    if constexpr (POW2) t_new = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));      /* already relative to the reference */ \
+    if constexpr (POW2) t_new = (fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) - YZ) * (1.0f / YU);      /* excess over the reference, log2 units */ \
     else t_new = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * c2 + t1.bl;                                 \
     asm volatile("" : "+v"(t_new));                                                                                    \
   } else {                                                                                                             \
     asm volatile("" : "+v"(t_new));                                                                                    \
     if (t1.nvalid > 0) {              /* a tile past the end contributes nothing and must not move the running max */ \
       if constexpr (POW2) {                                                                                            \
-        bool r_ = __builtin_amdgcn_ballot_w64(t_new > (DEFER ? DEFER_THR : 0.f)) != 0;                                 \
+        bool r_ = __builtin_amdgcn_ballot_w64(t_new > (DEFER ? P8_THR : 0.f)) != 0;                                    \
         if (r_) {                     /* move the reference up by this row's excess and re-reference the tile's scores */ \
           const float d_ = fmaxf(t_new, 0.f);                                                                          \
           alpha = __builtin_amdgcn_exp2f(-d_);                                                                         \
           m_run += d_;                                                                                                 \
-          _Pragma("unroll") for (int r2_ = 0; r2_ < 16; ++r2_) { SN0[r2_] -= d_; SN1[r2_] -= d_; }                     \
+          const float dy_ = d_ * YU;                                                                                   \
+          _Pragma("unroll") for (int r2_ = 0; r2_ < 16; ++r2_) { SN0[r2_] -= dy_; SN1[r2_] -= dy_; }                   \
           resc = true;                                                                                                 \
         }                                                                                                              \
         if (r_ || t2.bl != t1.bl) {   /* the accumulator tile t+2's scores start from */                              \
-          const float o_ = t2.bl - m_run;                                                                              \
+          const float o_ = (t2.bl - m_run) * YU + YZ;                                                                  \
           _Pragma("unroll") for (int r2_ = 0; r2_ < 16; ++r2_) offv[r2_] = o_;                                         \
         }                                                                                                              \
       } else {                                                                                                         \
@@ -750,9 +771,15 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 #ifdef LX8_ELIM_DMA
 #define LX8_STAGE_MAYBE(g, PAR)
 #else
+#ifndef LX8_STAGE_K_GAP          /* measurement builds move the two LDS-DMA pieces of a wave to other gaps (tools/build_variant.sh) */
+#define LX8_STAGE_K_GAP 1
+#endif
+#ifndef LX8_STAGE_V_GAP
+#define LX8_STAGE_V_GAP 3          /* (round 6: 5 -> 3, -2.5 % per launch at S = 8704: the piece has two more gaps to land before the end-of-tile wait) */
+#endif
 #define LX8_STAGE_MAYBE(g, PAR)                                                                                        \
-  if ((g) == 1) stage_k(t2, PAR);                                                                                      \
-  if ((g) == 5) stage_v(t1, (PAR) ^ 1);
+  if ((g) == LX8_STAGE_K_GAP) stage_k(t2, PAR);                                                                        \
+  if ((g) == LX8_STAGE_V_GAP) stage_v(t1, (PAR) ^ 1);
 #endif
   // one gap: reads of the NEXT gap's fragment, the vector slice, this gap's MFMA.  S0 = key block 0 (tile t, then t+1 in place),
   // S1C / S1N = key block 1 of tile t / t+1
@@ -838,11 +865,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
       for (int r = 1; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s0[r]), s1a[r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       if constexpr (POW2) {
-        m_run = tmax + t0.bl;                              // log2 units already
-        const float o0 = t0.bl - m_run;
+        m_run = tmax * (1.0f / YU) + t0.bl;                // log2 units (the MX block scale carries YU)
+        const float o0 = (t0.bl - m_run) * YU + YZ;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] += o0; s1a[r] += o0; }
-        const float o1 = t1.bl - m_run;
+        const float o1 = (t1.bl - m_run) * YU + YZ;
 #pragma unroll
         for (int r = 0; r < 16; ++r) offv[r] = o1;
       } else {
@@ -979,7 +1006,7 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   LX_CHECK_ARG(d->ldq % 16 == 0 && d->ldk % 16 == 0 && d->ldo % 4 == 0 && d->vt_ld % 64 == 0, "lx_attn_fwd_fp8: ldq/ldk %% 16 (bytes), ldo %% 4, vt_ld %% 64 required");
   LX_CHECK_ARG(d->q_col % 16 == 0 && d->k_col % 16 == 0 && d->o_col % 4 == 0, "lx_attn_fwd_fp8: column offsets must be 16-byte aligned");
   LX_CHECK_ARG(qk_descale > 0.f && v_descale > 0.f, "lx_attn_fwd_fp8: descale factors must be positive");
-  LX_CHECK_ARG((d->flags & ~LX_ATTN_O_F16) == 0, "lx_attn_fwd_fp8: the only flag is LX_ATTN_O_F16 (the e4m3 kernels fold their own scales)");
+  LX_CHECK_ARG((d->flags & ~(LX_ATTN_O_F16 | LX_ATTN_P_EXP2)) == 0, "lx_attn_fwd_fp8: the flags are LX_ATTN_O_F16 and LX_ATTN_P_EXP2 (the e4m3 kernels fold their own scales)");
   LX_CHECK_ARG(d->n_qseg >= 0 && d->n_qseg <= d->n_seg, "lx_attn_fwd_fp8: n_qseg=%d must be 0..n_seg", d->n_qseg);
   LX_CHECK_ARG(d->qseg_mask >= 0 && d->qseg_mask < (1 << d->n_seg), "lx_attn_fwd_fp8: qseg_mask=%d names a segment >= n_seg", d->qseg_mask);
   const int qmask = lx_attn_qmask(d);
@@ -1008,7 +1035,8 @@ extern "C" int lx_attn_fwd_fp8(const lx_attn_desc* d, float qk_descale, float v_
   const int k = (int)lround(-log2(c2));
   const bool pow2 = k >= 1 && k <= 60 && fabs(c2 * ldexp(1.0, k) - 1.0) < 1e-5;
   hipStream_t st = (hipStream_t)stream;
-  if (pow2) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k);
+  if (pow2 && !(d->flags & LX_ATTN_P_EXP2)) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true, true>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k + 3);
+  else if (pow2) hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, true, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127 - k);
   else hipLaunchKernelGGL((lx_attn_fp8_pipe_kernel<true, false>), dim3(grid), dim3(512), 0, st, a, qk_descale, v_descale, 127);
   LX_LAUNCH_CHECK("lx_attn_fwd_fp8");
   return LX_OK;

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256, 1) void lx_attn4_kernel(const AttnArgs args, c
   auto decode = [&](int w) {
     Item it;
     it.w = w;
-    const int qt = w / BH;
-    it.bh = w - qt * BH;
+    int qt;
+    lx_item_decode(w, n_items, BH, args.qt_start[3], qt, it.bh);
     it.b = it.bh / NH;
     it.h = it.bh - it.b * NH;
     it.sq = (n_seg > 2 && qt >= qs2) ? 2 : ((n_seg > 1 && qt >= qs1) ? 1 : 0);

@@ -25,7 +25,10 @@ namespace {
 constexpr int BN = 256;
 constexpr int BK = 64;
 constexpr int NTHREADS = 512;
-constexpr int GROUP_M = 4;   // M-tile rows per column group of the tile order (4 / 8 / 16 measured identical)
+#ifndef LX_GROUP_M              /* measurement builds (tools/gemm_energy.py): the height of an XCD's tile patch */
+#define LX_GROUP_M 4
+#endif
+constexpr int GROUP_M = LX_GROUP_M;   // M-tile rows per column group of the tile order (4 / 8 / 16 measured identical in time, round 1; in joules, round 6)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

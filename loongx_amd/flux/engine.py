@@ -748,8 +748,9 @@ class DiTEngine:
             self._fp8_images()
             if not prepped:                # otherwise the projection epilogue already wrote the three byte images
                 ops.qkv_prep_fp8_segs(Y, 2 * D, 0, D, qsegs, B, H, self.Q8, self.K8, self.VT8, in_f16=self.f16)
+            f8 = (ops.ATTN_O_F16 if self.f16 else 0) | (ops.ATTN_P_EXP2 if self.model_config.get("attn_fp8_exp2", False) else 0)
             ops.attn_fwd_fp8(self.Q8, self.K8, self.VT8, Y, o_col=2 * D, B=B, H=H, seg_row0=seg_row0, seg_len=seg_len,
-                             seg_vt0=seg_vt0, bias=bias, flags=ops.ATTN_O_F16 if self.f16 else 0, **okw)
+                             seg_vt0=seg_vt0, bias=bias, flags=f8, **okw)
             return
         if cached:
             # keys from the layer's key image, V^T from the layer's V^T image (the condition stream's part written by the first

@@ -345,7 +345,8 @@ def _attn_desc(Q, K, VT, O, q_col, k_col, o_col, B, H, seg_row0, seg_len, seg_vt
     return d
 
 
-ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16, ATTN_PREFER_4WAVE = L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT, L.LX_ATTN_O_F16, L.LX_ATTN_PREFER_4WAVE
+ATTN_Q_LOG2, ATTN_BOUNDED, ATTN_INVARIANT, ATTN_O_F16, ATTN_PREFER_4WAVE, ATTN_P_EXP2 = (L.LX_ATTN_Q_LOG2, L.LX_ATTN_BOUNDED, L.LX_ATTN_INVARIANT, L.LX_ATTN_O_F16,
+                                                                                         L.LX_ATTN_PREFER_4WAVE, L.LX_ATTN_P_EXP2)
 Q_LOG2_FACTOR = (1.0 / math.sqrt(128.0)) * 1.4426950408889634       # what LX_ATTN_Q_LOG2 expects q to carry already
 
 
@@ -398,7 +399,8 @@ def qkv_prep_fp8_segs(QKV, q_col, k_col, v_col, segs, n_batches, H, Q8, K8, VT8,
 
 
 def attn_fwd_fp8(Q8, K8, VT8, O, *, o_col, B, H, seg_row0, seg_len, seg_vt0, bias=None, scale=None, flags=0, f16_ovf=None, qseg_mask=0) -> None:
-    """flags: 0 | ATTN_O_F16 (O written as fp16 for an fp16-operand output projection); qseg_mask as in attn_fwd"""
+    """flags: 0 | ATTN_O_F16 (O written as fp16 for an fp16-operand output projection) | ATTN_P_EXP2 (probabilities by v_exp_f32 + e4m3
+    rounding instead of the log-linear byte code of the score); qseg_mask as in attn_fwd"""
     d = _attn_desc(Q8, K8, VT8, O, 0, 0, o_col, B, H, seg_row0, seg_len, seg_vt0, bias, scale)
     d.flags, d.f16_ovf, d.qseg_mask = flags, _p(f16_ovf), qseg_mask
     args = (C.byref(d), 1.0 / (FP8_Q_SCALE * FP8_K_SCALE), 1.0 / FP8_V_SCALE, _stream())

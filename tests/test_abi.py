@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/lx.h but not exported by liblx_amd.so"
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
-    assert _lib.lib.lx_version() == 402
+    assert _lib.lib.lx_version() == 403
 
 
 def test_struct_layouts_match_header():

@@ -32,7 +32,7 @@ if fp8:
     Q8 = torch.zeros(M, D, dtype=torch.uint8, device=dev); K8 = torch.zeros_like(Q8)
     VT8 = torch.zeros(B, H, 128, sum(lens), dtype=torch.uint8, device=dev)
     ops.qkv_prep_fp8_segs(buf, 2 * D, 0, D, segs, B, H, Q8, K8, VT8)
-    run = lambda: ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0)
+    run = lambda: ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=int(os.environ.get("AB_FLAGS8", "0")))      # (AB_FLAGS8=32: LX_ATTN_P_EXP2)
 else:
     VT = torch.zeros(B, H, 128, sum(lens), dtype=torch.bfloat16, device=dev)
     q = buf.clone()

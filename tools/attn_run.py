@@ -15,7 +15,10 @@ ap.add_argument("--big", action="store_true")
 ap.add_argument("--shape", default="")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--flags", type=int, default=3)
+ap.add_argument("--fp8", action="store_true", help="lx_attn_fwd_fp8 (flags then: 0 = log-linear probability bytes, 32 = LX_ATTN_P_EXP2)")
 a = ap.parse_args()
+if a.fp8 and a.flags == 3:
+    a.flags = 0
 dev = "cuda"
 B, H = 1, 24
 lens = (512, 4096, 4096) if a.big else (512, 1024, 1024)
@@ -35,13 +38,20 @@ O = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
 VT = torch.zeros(B, H, 128, sum(lens), dtype=torch.bfloat16, device=dev)
 q = buf.clone()
 ops.qkv_prep_segs(q, 2 * D, 0, D, segs, B, H, VT)
+run = lambda: ops.attn_fwd(q, q, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=a.flags)
+if a.fp8:
+    segs8 = [(row0[i], lens[i], vt0[i], None, None, None, None) for i in range(len(lens))]
+    Q8 = torch.zeros(M, D, dtype=torch.uint8, device=dev); K8 = torch.zeros_like(Q8)
+    VT8 = torch.zeros(B, H, 128, sum(lens), dtype=torch.uint8, device=dev)
+    ops.qkv_prep_fp8_segs(buf, 2 * D, 0, D, segs8, B, H, Q8, K8, VT8)
+    run = lambda: ops.attn_fwd_fp8(Q8, K8, VT8, O, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=a.flags)
 for _ in range(a.iters):
-    ops.attn_fwd(q, q, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=a.flags)
+    run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(a.iters):
-    ops.attn_fwd(q, q, VT, O, q_col=2 * D, k_col=0, o_col=0, B=B, H=H, seg_row0=row0, seg_len=list(lens), seg_vt0=vt0, flags=a.flags)
+    run()
 e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) * 1e3 / a.iters
