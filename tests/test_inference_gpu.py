@@ -133,3 +133,14 @@ def test_inference_cli_synthetic_in_process(tmp_path, monkeypatch):
     item = inf.synthetic_item(1, 256, torch.device("cuda", 0), 42)
     want = inf.inference_single(made["m"], item, "subject", [0, -16], 256)
     assert lat.shape == (256, 64) and torch.equal(lat, want.cpu())
+    # round 6: `--operands fp16 --f16-overflow fallback` reaches the engine through the config's model section, every saved image passed the
+    # synchronous saturation check, and the fp16 latents are the bf16 ones to the two formats' rounding difference
+    out16 = str(tmp_path / "out16")
+    inf.main(["--synthetic", "--num_images", "2", "--num_gpus", "1", "--output_dir", out16, "--target_size", "256", "--position_delta_y", "-16",
+              "--operands", "fp16", "--f16-overflow", "fallback"])
+    eng = made["m"].transformer.engine
+    assert eng.f16 and made["m"].model_config["operands"] == "fp16" and made["m"].model_config["f16_overflow"] == "fallback"
+    assert eng.f16_overflow_poll(sync=True) == 0
+    lat16 = torch.load(os.path.join(out16, files[1]))
+    d = float((lat16.double() - lat.double()).norm() / lat.double().norm())
+    assert 1e-6 < d < 2e-2, d
