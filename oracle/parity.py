@@ -128,7 +128,7 @@ def engine_for(tr, device, num_layers: int = 19, num_single_layers: int = 38, he
 # is rebuilt per mode. clear_cache() drops everything.
 _ORACLE_MODELS: Dict = {}
 _TRAJECTORIES: Dict = {}
-_ENGINE_ONLY_KEYS = ("operands", "attn_fp8", "gemm_fp8", "precise")
+_ENGINE_ONLY_KEYS = ("operands", "attn_fp8", "attn_fp8_exp2", "gemm_fp8", "precise", "f16_overflow")
 
 
 def clear_cache() -> None:
