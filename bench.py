@@ -382,7 +382,7 @@ def compact_line(res, legs):
     record)]. Strings that explain (kernel names, sources) are cut to what identifies them; the full records are in bench_legs.json."""
     cut = lambda v, n: (v if len(v) <= n else v[: n - 1] + "~") if isinstance(v, str) else v
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "outputs_finite", "model_tflops_per_gpu", "mfma_frac_end_to_end")
+            "outputs_finite", "model_tflops_per_gpu", "mfma_frac_end_to_end", "bench_wall_s")
     out = {k: res[k] for k in keep if k in res}
     cfg = dict(res.get("config") or {})
     cfg["workload"] = cut(cfg.get("workload", ""), 260)
