@@ -882,6 +882,9 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
 #ifdef LX_ATTN_PROBE
     pr_loop0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef LX8_YOUNG_PRIO          /* measurement build: static priority for the second-dispatched half (guide: two waves per SIMD, item 4) */
+    if (wave >= 4) __builtin_amdgcn_s_setprio(LX8_YOUNG_PRIO);
+#endif
     while (true) {
       LX8_ITER(s0, s1a, s1b, 0);
       if (t0.nvalid == 0) break;
