@@ -652,6 +652,11 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
   };
 
 #define LX8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef LX8_ELIM_BAR            /* timing experiment (RACY, wrong numbers): no end-of-tile barrier -- the bound on what fewer barriers could buy */
+#define LX8_BARRIER()
+#else
+#define LX8_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
   // hipcc linearises pure arithmetic freely inside a basic block (sched_barrier only holds what already sits on either side of it):
   // every slice takes its inputs through an empty asm at the head of its gap and leaves its results through one at the end, and
   // the gap's MFMA takes its fragment through one in front of it and hands its result through one behind it -- that is what keeps
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void lx_attn_fp8_pipe_kernel(const AttnArgs
     LX8_PROBE_A();                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
     LX8_PROBE_B();                                                                                                     \
-    LX8_FENCE(); __builtin_amdgcn_s_barrier(); LX8_FENCE();                                                            \
+    LX8_FENCE(); LX8_BARRIER(); LX8_FENCE();                                                                           \
     LX8_PROBE_C();                                                                                                     \
     t0 = t1; t1 = t2;                                                                                                  \
     gen_next();                                                                                                        \
